@@ -1,0 +1,171 @@
+/* walnuts_hip.h -- C ABI of the MI355X-native many-chain Walnuts/NUTS leapfrog engine.
+ *
+ * This is the drop-in boundary for ONE path of flatironinstitute/walnuts: the
+ * per-chain trajectory loop (detail::transition_w and everything below it,
+ * include/walnutpie/walnuts.hpp:520-563) together with the per-chain warmup
+ * adaptation wrapped around it (AdaptiveWalnuts, adaptive_walnuts.hpp:182-363),
+ * run for C chains at once on one GPU.  Plain pointers and sizes only.
+ *
+ * Two layers:
+ *   1. walnutpie_sample_device(): the sibling of the reference's
+ *      walnutpie_sample_cfunc() (python/src/walnutpie/walnutpy.cpp:134-222) with
+ *      the host callback (LOGP_CFUNC, void* data) replaced by a built-in device
+ *      model id + parameter vector.  Same trailing argument list, same output
+ *      buffer layout, same error object and accessors.
+ *   2. wn_engine_*(): the batched equivalents of the C++ objects behind it --
+ *      walnutpie::AdaptiveWalnuts::operator() (adaptive_walnuts.hpp:234-251),
+ *      ::sampler() (:263-271) and walnutpie::WalnutsSampler::operator()
+ *      (walnuts.hpp:682-692) -- each call advancing ALL chains by one transition.
+ *
+ * A host LOGP_CFUNC cannot be called from a GPU-resident trajectory, so
+ * walnutpie_sample_cfunc / walnutpie_sample_bridgestan are intentionally NOT
+ * provided here; callers with host models keep using the reference library.
+ *
+ * Every function returns 0 on success and -1 on failure; on failure *err (when
+ * err != NULL) receives a WalnutpyError to be freed with walnutpie_destroy_error,
+ * exactly as in python/src/walnutpie/errors.hpp:10-72.
+ */
+#ifndef WALNUTS_HIP_H
+#define WALNUTS_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WALNUTS_HIP_EXPORT __attribute__((visibility("default")))
+
+/* ---- errors: python/src/walnutpie/errors.hpp:10-24, walnutpy.cpp:371-389 ---- */
+typedef enum { generic = 0, config = 1, interrupt = 2 } WalnutpyErrorType;
+typedef struct WalnutpyError WalnutpyError;
+WALNUTS_HIP_EXPORT const char* walnutpie_get_error_message(const WalnutpyError* err);
+WALNUTS_HIP_EXPORT WalnutpyErrorType walnutpie_get_error_type(const WalnutpyError* err);
+WALNUTS_HIP_EXPORT void walnutpie_destroy_error(WalnutpyError* err);
+
+/* progress callback: python/src/walnutpie/handlers.hpp:15 */
+typedef void (*PRINT_CALLBACK)(const char* msg, size_t len, bool bad);
+
+/* ---- built-in device models (the LogpGrad contract, concepts.hpp:258-262) ---- */
+typedef enum {
+  WN_MODEL_STD_NORMAL = 0,  /* examples/walnutpie_api.cpp:37-41; no parameters            */
+  WN_MODEL_DIAG_NORMAL = 1, /* examples/examples.cpp:20-31; params = sigma_sq[num_params]  */
+  WN_MODEL_FUNNEL = 2       /* Neal's funnel, x0 ~ N(0,9), x_i ~ N(0,e^x0); no parameters  */
+} wn_model;
+
+/* ---- replaces walnutpie_sample_cfunc (walnutpy.cpp:134-149) ------------------- */
+WALNUTS_HIP_EXPORT int walnutpie_sample_device(
+    int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
+    unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
+    int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
+    int max_step_halvings, int min_micro_steps, double max_hamiltonian_error, double step_size_converge_tol,
+    double mass_converge_tol, double rhat_converge_tol, double mass_init_count, double mass_additive_smoothing,
+    double max_macro_steps_target, double step_size_init, double step_accept_rate_target,
+    double step_learning_rate, double step_gradient_decay, double step_sq_gradient_decay,
+    double step_stabilization, double step_learn_rate_decay, bool save_warmup, double* out, size_t out_size,
+    int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
+    WalnutpyError** err);
+
+/* ---- batched engine ------------------------------------------------------------- */
+typedef struct wn_engine wn_engine;
+
+/* SamplingConfig (config.hpp:885-1059, defaults :947-953) + WarmupConfig
+ * (config.hpp:513-850, defaults :626-640) fields that reach the per-chain path,
+ * plus launch geometry knobs (0 = choose automatically). */
+typedef struct wn_config {
+  int32_t max_trajectory_doublings; /* 5 */
+  int32_t max_step_halvings;        /* 5 */
+  int32_t min_micro_steps;          /* 1 */
+  int32_t device;                   /* HIP device ordinal */
+  double max_hamiltonian_error;     /* 0.5 */
+  double mass_init_count;           /* 4 */
+  double max_macro_steps_target;    /* 15 */
+  double step_accept_rate_target;   /* 0.8 */
+  double step_learning_rate;        /* 0.05 */
+  double step_gradient_decay;       /* 0.8 */
+  double step_sq_gradient_decay;    /* 0.9 */
+  double step_stabilization;        /* 1e-4 */
+  double step_learn_rate_decay;     /* 0.5 */
+  int32_t waves_per_chain;          /* NW: wavefronts cooperating on one chain */
+  int32_t elems_per_lane;           /* EPL: vector elements held per lane */
+  int32_t workgroups_per_cu;        /* resident chains per compute unit */
+  int32_t lds_vectors;              /* span-pool vectors kept in LDS (-1: as many as fit) */
+} wn_config;
+
+WALNUTS_HIP_EXPORT void wn_default_config(wn_config* cfg);
+
+/* model_params: host pointer (copied). */
+WALNUTS_HIP_EXPORT int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params,
+                                        size_t num_chains, const wn_config* cfg, WalnutpyError** err);
+WALNUTS_HIP_EXPORT void wn_engine_destroy(wn_engine* e);
+
+/* InitConfig (config.hpp:74-185): positions [C*D], masses [C*D] (masses, not inverse
+ * masses), step sizes [C]; host pointers. */
+WALNUTS_HIP_EXPORT int wn_engine_set_positions(wn_engine* e, const double* positions, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_set_masses(wn_engine* e, const double* masses, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_set_step_sizes(wn_engine* e, const double* step_sizes, WalnutpyError** err);
+/* device-side InitConfigBuilder steps (config.hpp:258-268,360-370,470-476 + util.hpp:242-303) on the
+ * counter-based streams: positions ~ N(0, scale^2); mass = (1-s)*|grad| + s; step-size search */
+WALNUTS_HIP_EXPORT int wn_engine_init_positions(wn_engine* e, uint64_t seed, uint32_t chain_offset, double scale,
+                                                WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_init_masses_from_grad(wn_engine* e, double smoothing, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_adapt_step(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyError** err);
+/* the same step-size search with the momentum normals [C*D] supplied by the host (lets a caller feed the
+ * reference's own mt19937_64(seed_seq{seed,2}) stream, walnutpy.cpp:75-80) */
+WALNUTS_HIP_EXPORT int wn_engine_adapt_step_with_normals(wn_engine* e, const double* normals, WalnutpyError** err);
+/* counter-based generator: key = seed, chain ids chain_offset .. chain_offset+C-1
+ * (the role of api.hpp:46-51's per-chain seed_seq{seed, m+1}) */
+WALNUTS_HIP_EXPORT int wn_engine_seed(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyError** err);
+/* host-generated variates for the NEXT transition only (exact libstdc++ stream parity
+ * runs): normals [C*D], canonical uniforms [C*u_per_chain] consumed in order. */
+WALNUTS_HIP_EXPORT int wn_engine_set_variates(wn_engine* e, const double* normals, const double* uniforms,
+                                              int u_per_chain, WalnutpyError** err);
+
+/* AdaptiveWalnuts::operator() for all chains.  draws_dev: nullable DEVICE pointer; chain c's
+ * position is written to draws_dev + c*draws_stride (doubles). */
+WALNUTS_HIP_EXPORT int wn_engine_warmup_step(wn_engine* e, double* draws_dev, int64_t draws_stride,
+                                             WalnutpyError** err);
+/* AdaptiveWalnuts::sampler(): freeze step size, inverse mass and min micro steps. */
+WALNUTS_HIP_EXPORT int wn_engine_freeze(wn_engine* e, WalnutpyError** err);
+/* WalnutsSampler::operator() for all chains. */
+WALNUTS_HIP_EXPORT int wn_engine_sample_step(wn_engine* e, double* draws_dev, int64_t draws_stride,
+                                             WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_synchronize(wn_engine* e, WalnutpyError** err);
+
+/* state -> host buffers */
+WALNUTS_HIP_EXPORT int wn_engine_get_positions(wn_engine* e, double* out /*[C*D]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_inv_mass(wn_engine* e, double* out /*[C*D]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_step_sizes(wn_engine* e, double* out /*[C]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_logp(wn_engine* e, double* out /*[C]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_min_micro(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_depths(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_grad_evals(wn_engine* e, int64_t* out /*[C]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_rng_draws(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_adam(wn_engine* e, double* out /*[C*6]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_estimator(wn_engine* e, double* draw_mean, double* draw_ssd,
+                                               double* score_mean, double* score_ssd, double* weights /*[C*2]*/,
+                                               WalnutpyError** err);
+/* sum over chains of gradient evaluations so far (device-side reduction) */
+WALNUTS_HIP_EXPORT int wn_engine_total_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err);
+
+/* introspection */
+WALNUTS_HIP_EXPORT int wn_engine_lanes(const wn_engine* e);        /* L = 64*NW: the reduction width   */
+WALNUTS_HIP_EXPORT int wn_engine_dim_padded(const wn_engine* e);   /* Dp                                */
+WALNUTS_HIP_EXPORT int wn_engine_workgroups(const wn_engine* e);   /* persistent grid size              */
+WALNUTS_HIP_EXPORT int wn_engine_lds_vectors(const wn_engine* e);  /* pool vectors resident in LDS      */
+WALNUTS_HIP_EXPORT int64_t wn_engine_iteration(const wn_engine* e);
+WALNUTS_HIP_EXPORT void* wn_engine_stream(const wn_engine* e);     /* hipStream_t the kernels run on    */
+/* device pointer to the [C][Dp] position plane (for RCCL all-gather of draws) */
+WALNUTS_HIP_EXPORT double* wn_engine_positions_device(const wn_engine* e);
+/* HIP-event time of the last transition kernel launch, milliseconds */
+WALNUTS_HIP_EXPORT int wn_engine_last_kernel_ms(wn_engine* e, float* ms, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane);
+/* (internal) allocates the error object handed back through WalnutpyError** */
+WALNUTS_HIP_EXPORT void* wn_internal_make_error(const char* msg, int type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WALNUTS_HIP_H */

@@ -1,0 +1,36 @@
+"""Builds tests/cpusim/libwalnuts_sim.so: the product's host + kernel sources compiled by g++ against
+the lock-step workgroup emulation in wn_cpusim.h.  TEST INFRASTRUCTURE (see wn_cpusim.h)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "walnuts_amd", "csrc")
+OUT = os.path.join(HERE, "libwalnuts_sim.so")
+SOURCES = ["wn_engine.hip", "wn_sample.hip", "wn_kernels_std_normal.hip", "wn_kernels_diag_normal.hip",
+           "wn_kernels_funnel.hip"]
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [
+        os.path.join(HERE, "wn_cpusim.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(HERE, os.path.basename(s) + ".sim.o")
+        objs.append(o)
+        procs.append(subprocess.Popen(
+            ["g++", "-x", "c++", "-std=c++20", "-O1", "-g", "-ffp-contract=off", "-fPIC", "-pthread", "-DWN_CPU_SIM",
+             "-DWN_SIM_GEOMETRIES", "-I", HERE, "-I", CSRC, "-c", s, "-o", o]))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("cpusim compile failed")
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

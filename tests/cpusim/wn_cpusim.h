@@ -1,0 +1,186 @@
+// wn_cpusim.h -- TEST INFRASTRUCTURE: a lock-step host emulation of one HIP workgroup plus the sliver
+// of the HIP runtime API that walnuts_amd/csrc uses.  tests/cpusim/build.py compiles the product's
+// .hip sources with g++ -DWN_CPU_SIM against this header into tests/cpusim/libwalnuts_sim.so so that
+// the `-m "not gpu"` suite can drive the real host logic and the kernels' control flow (span pool,
+// random-number order, adaptation) against the oracle.  It is slow (one OS thread per lane, a barrier
+// per cross-lane operation), is never linked into libwalnuts_hip.so and proves nothing about the GPU
+// build: device parity is established by the `-m gpu` tests only.
+#pragma once
+
+#include <atomic>
+#include <barrier>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#define __device__
+#define __global__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(x)
+#define WN_LDS
+typedef double v2f64 __attribute__((vector_size(16)));
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+
+namespace wnsim {
+struct Block {
+  unsigned nthreads = 0;
+  std::unique_ptr<std::barrier<>> bar;
+  std::vector<uint64_t> xchg;
+  double* smem = nullptr;
+};
+inline thread_local Block* blk = nullptr;
+inline thread_local dim3 tidx, bidx, gdim, bdim;
+inline void sync() { blk->bar->arrive_and_wait(); }
+template <class T>
+T exchange(T v, unsigned src_tid) {
+  static_assert(sizeof(T) <= 8, "exchange moves at most 8 bytes");
+  uint64_t raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  blk->xchg[tidx.x] = raw;
+  sync();
+  const uint64_t r = blk->xchg[src_tid];
+  sync();
+  T out;
+  std::memcpy(&out, &r, sizeof(T));
+  return out;
+}
+// value of the wavefront's first lane (all lanes are active everywhere in these kernels)
+template <class T>
+T readfirstlane(T v) {
+  return exchange(v, tidx.x & ~63u);
+}
+
+template <class K, class... A>
+void launch(K kernel, dim3 grid, dim3 block, size_t smem_bytes, A... args) {
+  for (unsigned b = 0; b < grid.x; ++b) {
+    Block B;
+    B.nthreads = block.x;
+    B.bar = std::make_unique<std::barrier<>>(static_cast<std::ptrdiff_t>(block.x));
+    B.xchg.assign(block.x, 0);
+    const size_t bytes = ((smem_bytes + 63) / 64 + 1) * 64;
+    B.smem = static_cast<double*>(std::aligned_alloc(64, bytes));
+    std::memset(B.smem, 0xCD, bytes);
+    std::vector<std::thread> th;
+    th.reserve(block.x);
+    for (unsigned t = 0; t < block.x; ++t) {
+      th.emplace_back([&, t] {
+        blk = &B;
+        tidx = dim3(t);
+        bidx = dim3(b);
+        gdim = grid;
+        bdim = block;
+        kernel(args...);
+      });
+    }
+    for (auto& x : th) x.join();
+    std::free(B.smem);
+  }
+}
+}  // namespace wnsim
+
+#define threadIdx wnsim::tidx
+#define blockIdx wnsim::bidx
+#define gridDim wnsim::gdim
+#define blockDim wnsim::bdim
+#define WN_DYN_SMEM(name) double* name = wnsim::blk->smem
+#define __builtin_amdgcn_readfirstlane(x) wnsim::readfirstlane(x)
+
+template <class T>
+inline T __shfl_xor(T v, int off, int = 64) {
+  const unsigned base = wnsim::tidx.x & ~63u;
+  return wnsim::exchange(v, base + ((wnsim::tidx.x & 63u) ^ static_cast<unsigned>(off)));
+}
+template <class T>
+inline T __shfl(T v, int src, int = 64) {
+  return wnsim::exchange(v, (wnsim::tidx.x & ~63u) + static_cast<unsigned>(src));
+}
+inline void __syncthreads() { wnsim::sync(); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+using std::fabs;
+using std::fmax;
+
+// ---- the sliver of the HIP runtime the host code uses ------------------------------------------
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+inline const char* hipGetErrorString(hipError_t) { return "cpusim error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+struct hipDeviceProp_t {
+  int multiProcessorCount;
+};
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  p->multiProcessorCount = 2;
+  return hipSuccess;
+}
+typedef void* hipStream_t;
+constexpr unsigned hipStreamNonBlocking = 1;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  *s = reinterpret_cast<void*>(0x1);
+  return hipSuccess;
+}
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+struct hipEventSim {
+  std::chrono::steady_clock::time_point t;
+};
+typedef hipEventSim* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = new hipEventSim();
+  return hipSuccess;
+}
+inline hipError_t hipEventDestroy(hipEvent_t e) {
+  delete e;
+  return hipSuccess;
+}
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+  e->t = std::chrono::steady_clock::now();
+  return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
+inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = std::aligned_alloc(64, ((n + 63) / 64) * 64);
+  std::memset(*p, 0xCD, n);
+  return *p ? hipSuccess : 1;
+}
+inline hipError_t hipFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+  std::memcpy(d, s, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height,
+                                   hipMemcpyKind, hipStream_t) {
+  for (size_t r = 0; r < height; ++r)
+    std::memcpy(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+  return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+  std::memset(d, v, n);
+  return hipSuccess;
+}
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+  wnsim::launch(kernel, grid, block, static_cast<size_t>(smem), __VA_ARGS__)

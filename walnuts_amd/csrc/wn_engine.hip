@@ -1,0 +1,587 @@
+// wn_engine.hip -- host side of the C ABI in include/walnuts_hip.h: owns the chain-major
+// HBM planes, picks the launch geometry and drives the persistent transition kernel.
+#include "wn_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/walnuts_hip.h"
+#include "wn_elementwise.h"
+#include "wn_init.h"
+#include "wn_launch.h"
+#include "wn_traj.h"
+
+// ---- errors (python/src/walnutpie/errors.hpp:10-72) --------------------------------------
+struct WalnutpyError {
+  std::string msg;
+  WalnutpyErrorType type;
+};
+
+namespace {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) {
+    std::stringstream ss;
+    ss << "HIP error in " << what << ": " << hipGetErrorString(e);
+    throw std::runtime_error(ss.str());
+  }
+}
+#define HIP_OK(expr) hip_check((expr), #expr)
+
+template <class F>
+int guarded(WalnutpyError** err, F f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::invalid_argument& e) {
+    if (err) *err = new WalnutpyError{e.what(), config};
+  } catch (const std::exception& e) {
+    if (err) *err = new WalnutpyError{e.what(), generic};
+  } catch (...) {
+    if (err) *err = new WalnutpyError{"Unknown error", generic};
+  }
+  return -1;
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) HIP_OK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+struct wn_engine {
+  int model = 0, D = 0, Dp = 0;
+  size_t C = 0;
+  wn_config cfg{};
+  wn::Geometry geo{};
+  int device = 0;
+  int num_cus = 256;
+  int grid = 0;
+  int pool_lds = 0, pool_total = 0;
+  size_t smem = 0;
+  hipStream_t stream = nullptr;
+
+  DevBuf<double> theta, mass, inv_mass, draw_mean, draw_ssd, score_mean, score_ssd;
+  DevBuf<double> step_init, step_size, adam, est_weight, mm_state, logp, model_params, arena, z_buf, u_buf;
+  DevBuf<int32_t> min_micro, depth, rng_draws;
+  DevBuf<int64_t> grad_evals;
+  DevBuf<uint32_t> counter;
+  DevBuf<unsigned long long> scratch64;
+
+  uint64_t seed = 0;
+  uint32_t chain_offset = 0;
+  uint32_t transition = 0;
+  int64_t warmup_iter = 0;
+  int64_t iteration = 0;
+  bool adapters_ready = false;
+  bool frozen = false;
+  bool variates_pending = false;
+  int u_stride = 0;
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+
+  ~wn_engine() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  void use_device() { HIP_OK(hipSetDevice(device)); }
+
+  void upload_rows(DevBuf<double>& dst, const double* host, double pad_value) {
+    // host [C][D] -> device [C][Dp]; padding columns keep their fill value
+    use_device();
+    if (Dp != D) {
+      std::vector<double> padded(C * static_cast<size_t>(Dp), pad_value);
+      for (size_t c = 0; c < C; ++c) std::memcpy(&padded[c * Dp], host + c * D, sizeof(double) * D);
+      HIP_OK(hipMemcpyAsync(dst.p, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+    } else {
+      HIP_OK(hipMemcpyAsync(dst.p, host, C * static_cast<size_t>(D) * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+    }
+  }
+  void download_rows(const DevBuf<double>& src, double* host) {
+    use_device();
+    HIP_OK(hipMemcpy2DAsync(host, sizeof(double) * D, src.p, sizeof(double) * Dp, sizeof(double) * D, C,
+                            hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+  }
+  template <class T>
+  void download(const DevBuf<T>& src, T* host, size_t count) {
+    use_device();
+    HIP_OK(hipMemcpyAsync(host, src.p, count * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+  }
+  void fill(DevBuf<double>& b, double v) {
+    std::vector<double> h(b.n, v);
+    HIP_OK(hipMemcpyAsync(b.p, h.data(), b.n * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+  }
+
+  void ensure_adapters() {
+    if (adapters_ready) return;
+    use_device();
+    const int blocks = static_cast<int>(std::min<size_t>((C * Dp + 255) / 256, 4096));
+    hipLaunchKernelGGL(wn::begin_warmup_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<int>(C), Dp,
+                       cfg.mass_init_count, mass.p, draw_mean.p, draw_ssd.p, score_mean.p, score_ssd.p,
+                       est_weight.p, step_init.p, adam.p, mm_state.p);
+    HIP_OK(hipGetLastError());
+    adapters_ready = true;
+    warmup_iter = 0;
+  }
+
+  wn::Params make_params(bool warm, double* draws_dev, int64_t draws_stride) {
+    wn::Params P{};
+    P.num_chains = static_cast<int32_t>(C);
+    P.dim = D;
+    P.dim_padded = Dp;
+    P.warmup = warm ? 1 : 0;
+    P.theta = theta.p;
+    P.inv_mass = inv_mass.p;
+    P.est_draw_mean = draw_mean.p;
+    P.est_draw_ssd = draw_ssd.p;
+    P.est_score_mean = score_mean.p;
+    P.est_score_ssd = score_ssd.p;
+    P.step_size = step_size.p;
+    P.min_micro = min_micro.p;
+    P.adam = adam.p;
+    P.est_weight = est_weight.p;
+    P.mm_state = mm_state.p;
+    P.logp_out = logp.p;
+    P.depth_out = depth.p;
+    P.grad_evals = grad_evals.p;
+    P.rng_draws = rng_draws.p;
+    P.draws_out = draws_dev;
+    P.draws_stride = draws_stride;
+    P.model_params = model_params.p;
+    P.max_depth = cfg.max_trajectory_doublings;
+    P.max_halvings = cfg.max_step_halvings;
+    P.cfg_min_micro = cfg.min_micro_steps;
+    P.max_error = cfg.max_hamiltonian_error;
+    P.mass_init_count = cfg.mass_init_count;
+    P.macro_target = cfg.max_macro_steps_target;
+    P.adam_target = cfg.step_accept_rate_target;
+    P.adam_lr = cfg.step_learning_rate;
+    P.adam_b1 = cfg.step_gradient_decay;
+    P.adam_b2 = cfg.step_sq_gradient_decay;
+    P.adam_eps = cfg.step_stabilization;
+    P.adam_decay = cfg.step_learn_rate_decay;
+    P.seed = seed;
+    P.chain_offset = chain_offset;
+    P.transition = transition;
+    P.rng_mode = variates_pending ? wn::kRngBuffer : wn::kRngPhilox;
+    P.u_stride = u_stride;
+    P.z_buf = z_buf.p;
+    P.u_buf = u_buf.p;
+    P.warmup_iter = warmup_iter;
+    P.arena = arena.p;
+    P.arena_stride = static_cast<int64_t>(pool_total - pool_lds) * Dp;
+    P.pool_lds = pool_lds;
+    P.pool_total = pool_total;
+    P.work_counter = counter.p;
+    return P;
+  }
+
+  void step(bool warm, double* draws_dev, int64_t draws_stride) {
+    use_device();
+    wn::Params P = make_params(warm, draws_dev, draws_stride);
+    HIP_OK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), stream));
+    HIP_OK(hipEventRecord(ev0, stream));
+    wn::launch_transition(model, geo, grid, smem, stream, P);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(ev1, stream));
+    timed = true;
+    variates_pending = false;
+    ++transition;
+    ++iteration;
+    if (warm) ++warmup_iter;
+  }
+};
+
+namespace {
+
+int required_pool(const wn_config& c, bool start_regs) {
+  // accumulated span 6 + its selection 1, one entry (<=3) per stack level 0..max_depth-2, the span
+  // under construction 3, the parked state of a reversibility check 3, restart state, slack
+  const int levels = std::max(1, c.max_trajectory_doublings - 1);
+  return 7 + 3 * levels + 3 + 3 + (start_regs ? 0 : 3) + 2;
+}
+
+void build_engine(wn_engine& e, int model, int num_params, const double* model_params, size_t num_chains,
+                  const wn_config& cfg) {
+  if (num_params < 1) throw std::invalid_argument("num_params must be positive");
+  if (num_chains < 1) throw std::invalid_argument("num_chains must be positive");
+  if (model < 0 || model > 2) throw std::invalid_argument("unknown device model id");
+  if (cfg.max_trajectory_doublings < 1) throw std::invalid_argument("max_nuts_depth must be positive");
+  if (cfg.max_trajectory_doublings > wn::kMaxLevels + 1)
+    throw std::invalid_argument("max_trajectory_doublings exceeds the device span stack");
+  if (cfg.max_step_halvings < 1) throw std::invalid_argument("max_step_halvings must be positive");
+  if (cfg.min_micro_steps < 1) throw std::invalid_argument("min_micro_steps must be positive");
+  if (!(cfg.max_hamiltonian_error > 0) || !std::isfinite(cfg.max_hamiltonian_error))
+    throw std::invalid_argument("max_hamiltonian_error must be positive and finite");
+  if (model == WN_MODEL_DIAG_NORMAL && model_params == nullptr)
+    throw std::invalid_argument("diag-normal model needs sigma_sq[num_params]");
+  if (model == WN_MODEL_FUNNEL && num_params < 2) throw std::invalid_argument("funnel needs num_params >= 2");
+
+  e.model = model;
+  e.D = num_params;
+  e.C = num_chains;
+  e.cfg = cfg;
+  e.device = cfg.device;
+  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane);
+  e.Dp = 64 * e.geo.nw * e.geo.epl;
+  e.use_device();
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, e.device));
+  e.num_cus = prop.multiProcessorCount;
+  HIP_OK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+  HIP_OK(hipEventCreate(&e.ev0));
+  HIP_OK(hipEventCreate(&e.ev1));
+
+  // residency: how many chains (workgroups) share a CU, and how much of the span pool sits in LDS
+  const size_t lds_per_cu = 160 * 1024;
+  e.pool_total = std::min(required_pool(cfg, e.geo.start_regs), wn::kMaxPool);
+  int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo);
+  wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
+  const size_t fixed = wn::transition_smem_bytes(e.geo.nw, 0, e.Dp);
+  const size_t budget = lds_per_cu / wg_per_cu;
+  const size_t vec_bytes = sizeof(double) * e.Dp;
+  int lds_vecs = budget > fixed + 1024 ? static_cast<int>((budget - fixed - 1024) / vec_bytes) : 0;
+  if (cfg.lds_vectors >= 0 && cfg.lds_vectors < lds_vecs) lds_vecs = cfg.lds_vectors;
+  e.pool_lds = std::min(lds_vecs, e.pool_total);
+  e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds, e.Dp);
+  e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(e.num_cus) * wg_per_cu));
+
+  const size_t plane = num_chains * static_cast<size_t>(e.Dp);
+  for (DevBuf<double>* b : {&e.theta, &e.mass, &e.inv_mass, &e.draw_mean, &e.draw_ssd, &e.score_mean, &e.score_ssd})
+    b->alloc(plane);
+  e.step_init.alloc(num_chains);
+  e.step_size.alloc(num_chains);
+  e.adam.alloc(6 * num_chains);
+  e.est_weight.alloc(2 * num_chains);
+  e.mm_state.alloc(2 * num_chains);
+  e.logp.alloc(num_chains);
+  e.min_micro.alloc(num_chains);
+  e.depth.alloc(num_chains);
+  e.rng_draws.alloc(num_chains);
+  e.grad_evals.alloc(num_chains);
+  e.counter.alloc(1);
+  e.scratch64.alloc(1);
+  const size_t arena_vecs = static_cast<size_t>(e.pool_total - e.pool_lds);
+  e.arena.alloc(std::max<size_t>(1, static_cast<size_t>(e.grid) * arena_vecs * e.Dp));
+  e.model_params.alloc(e.Dp);
+
+  // InitConfigBuilder defaults (config.hpp:197-207): step 0.1, positions 0, masses 1
+  HIP_OK(hipMemsetAsync(e.theta.p, 0, plane * sizeof(double), e.stream));
+  e.fill(e.mass, 1.0);
+  e.fill(e.inv_mass, 1.0);
+  e.fill(e.step_init, 0.1);
+  HIP_OK(hipMemsetAsync(e.grad_evals.p, 0, num_chains * sizeof(int64_t), e.stream));
+  HIP_OK(hipMemsetAsync(e.depth.p, 0, num_chains * sizeof(int32_t), e.stream));
+  HIP_OK(hipMemsetAsync(e.rng_draws.p, 0, num_chains * sizeof(int32_t), e.stream));
+  HIP_OK(hipMemsetAsync(e.logp.p, 0, num_chains * sizeof(double), e.stream));
+  {
+    std::vector<double> mp(e.Dp, 1.0);
+    if (model_params) std::copy(model_params, model_params + num_params, mp.begin());
+    HIP_OK(hipMemcpyAsync(e.model_params.p, mp.data(), mp.size() * sizeof(double), hipMemcpyHostToDevice, e.stream));
+    HIP_OK(hipStreamSynchronize(e.stream));
+  }
+  wn::prepare_kernels(model, e.geo, e.smem);
+}
+
+void run_init(wn_engine& e, bool pos, bool masses, bool step, double scale, double smoothing, uint64_t pos_seed,
+              uint32_t pos_off, uint64_t step_seed, uint32_t step_off, const double* z_dev = nullptr) {
+  e.use_device();
+  wn::InitParams Q{};
+  Q.num_chains = static_cast<int32_t>(e.C);
+  Q.dim = e.D;
+  Q.dim_padded = e.Dp;
+  Q.do_positions = pos;
+  Q.do_masses = masses;
+  Q.do_step = step;
+  Q.theta = e.theta.p;
+  Q.mass = e.mass.p;
+  Q.step_init = e.step_init.p;
+  Q.grad_evals = e.grad_evals.p;
+  Q.model_params = e.model_params.p;
+  Q.z_buf = z_dev;
+  Q.scale = scale;
+  Q.smoothing = smoothing;
+  Q.pos_seed = pos_seed;
+  Q.step_seed = step_seed;
+  Q.pos_chain_offset = pos_off;
+  Q.step_chain_offset = step_off;
+  const int grid = static_cast<int>(std::min<size_t>(e.C, static_cast<size_t>(e.num_cus) * 8));
+  wn::launch_init(e.model, e.geo, grid, wn::transition_smem_bytes(e.geo.nw, 0, e.Dp), e.stream, Q);
+  HIP_OK(hipGetLastError());
+  e.adapters_ready = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* walnutpie_get_error_message(const WalnutpyError* err) {
+  if (err == nullptr) return "Something went wrong: No error found";
+  return err->msg.c_str();
+}
+WalnutpyErrorType walnutpie_get_error_type(const WalnutpyError* err) { return err == nullptr ? generic : err->type; }
+void walnutpie_destroy_error(WalnutpyError* err) { delete err; }
+
+void wn_default_config(wn_config* c) {
+  c->max_trajectory_doublings = 5;
+  c->max_step_halvings = 5;
+  c->min_micro_steps = 1;
+  c->device = 0;
+  c->max_hamiltonian_error = 0.5;
+  c->mass_init_count = 4.0;
+  c->max_macro_steps_target = 15.0;
+  c->step_accept_rate_target = 0.8;
+  c->step_learning_rate = 0.05;
+  c->step_gradient_decay = 0.8;
+  c->step_sq_gradient_decay = 0.9;
+  c->step_stabilization = 1e-4;
+  c->step_learn_rate_decay = 0.5;
+  c->waves_per_chain = 0;
+  c->elems_per_lane = 0;
+  c->workgroups_per_cu = 0;
+  c->lds_vectors = -1;
+}
+
+int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params, size_t num_chains,
+                     const wn_config* cfg, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (out == nullptr || cfg == nullptr) throw std::invalid_argument("null argument");
+    auto e = std::make_unique<wn_engine>();
+    build_engine(*e, model, num_params, model_params, num_chains, *cfg);
+    *out = e.release();
+  });
+}
+void wn_engine_destroy(wn_engine* e) { delete e; }
+
+int wn_engine_set_positions(wn_engine* e, const double* positions, WalnutpyError** err) {
+  return guarded(err, [&] { e->upload_rows(e->theta, positions, 0.0); });
+}
+int wn_engine_set_masses(wn_engine* e, const double* masses, WalnutpyError** err) {
+  return guarded(err, [&] {
+    for (size_t i = 0; i < e->C * static_cast<size_t>(e->D); ++i)
+      if (!(masses[i] > 0) || !std::isfinite(masses[i])) throw std::invalid_argument("masses must be positive and finite");
+    e->fill(e->mass, 1.0);
+    e->upload_rows(e->mass, masses, 1.0);
+    e->adapters_ready = false;
+  });
+}
+int wn_engine_set_step_sizes(wn_engine* e, const double* steps, WalnutpyError** err) {
+  return guarded(err, [&] {
+    for (size_t i = 0; i < e->C; ++i)
+      if (!(steps[i] > 0) || !std::isfinite(steps[i])) throw std::invalid_argument("step size must be positive and finite");
+    e->use_device();
+    HIP_OK(hipMemcpyAsync(e->step_init.p, steps, e->C * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    e->adapters_ready = false;
+  });
+}
+int wn_engine_init_positions(wn_engine* e, uint64_t seed, uint32_t chain_offset, double scale, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (!(scale > 0) || !std::isfinite(scale)) throw std::invalid_argument("init_scale must be positive and finite");
+    run_init(*e, true, false, false, scale, 0.0, seed, chain_offset, 0, 0);
+  });
+}
+int wn_engine_init_masses_from_grad(wn_engine* e, double smoothing, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (!(smoothing > 0 && smoothing < 1)) throw std::invalid_argument("mass_smoothing must be in (0, 1)");
+    run_init(*e, false, true, false, 1.0, smoothing, 0, 0, 0, 0);
+  });
+}
+int wn_engine_adapt_step(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyError** err) {
+  return guarded(err, [&] { run_init(*e, false, false, true, 1.0, 0.0, 0, 0, seed, chain_offset); });
+}
+int wn_engine_adapt_step_with_normals(wn_engine* e, const double* normals, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    if (e->z_buf.n == 0) e->z_buf.alloc(e->C * static_cast<size_t>(e->Dp));
+    HIP_OK(hipMemsetAsync(e->z_buf.p, 0, e->z_buf.n * sizeof(double), e->stream));
+    e->upload_rows(e->z_buf, normals, 0.0);
+    run_init(*e, false, false, true, 1.0, 0.0, 0, 0, 0, 0, e->z_buf.p);
+  });
+}
+void* wn_internal_make_error(const char* msg, int type) {
+  return new WalnutpyError{msg, static_cast<WalnutpyErrorType>(type)};
+}
+int wn_engine_seed(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->seed = seed;
+    e->chain_offset = chain_offset;
+    e->transition = 0;
+  });
+}
+int wn_engine_set_variates(wn_engine* e, const double* normals, const double* uniforms, int u_per_chain,
+                           WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (u_per_chain < 1) throw std::invalid_argument("u_per_chain must be positive");
+    e->use_device();
+    if (e->z_buf.n == 0) e->z_buf.alloc(e->C * static_cast<size_t>(e->Dp));
+    if (e->u_buf.n < e->C * static_cast<size_t>(u_per_chain)) e->u_buf.alloc(e->C * static_cast<size_t>(u_per_chain));
+    HIP_OK(hipMemsetAsync(e->z_buf.p, 0, e->z_buf.n * sizeof(double), e->stream));
+    e->upload_rows(e->z_buf, normals, 0.0);
+    HIP_OK(hipMemcpyAsync(e->u_buf.p, uniforms, e->C * static_cast<size_t>(u_per_chain) * sizeof(double),
+                          hipMemcpyHostToDevice, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    e->u_stride = u_per_chain;
+    e->variates_pending = true;
+  });
+}
+
+int wn_engine_warmup_step(wn_engine* e, double* draws_dev, int64_t draws_stride, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e->frozen) throw std::runtime_error("warmup_step after freeze");
+    e->ensure_adapters();
+    e->step(true, draws_dev, draws_stride);
+  });
+}
+int wn_engine_freeze(wn_engine* e, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->ensure_adapters();
+    e->use_device();
+    const int blocks = static_cast<int>(std::min<size_t>((e->C * e->Dp + 255) / 256, 4096));
+    hipLaunchKernelGGL(wn::freeze_kernel, dim3(blocks), dim3(256), 0, e->stream, static_cast<int>(e->C), e->Dp,
+                       e->draw_ssd.p, e->score_ssd.p, e->est_weight.p, e->adam.p, e->mm_state.p,
+                       e->cfg.max_macro_steps_target, e->cfg.min_micro_steps, e->inv_mass.p, e->step_size.p,
+                       e->min_micro.p);
+    HIP_OK(hipGetLastError());
+    e->frozen = true;
+  });
+}
+int wn_engine_sample_step(wn_engine* e, double* draws_dev, int64_t draws_stride, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (!e->frozen) throw std::runtime_error("sample_step before freeze");
+    e->step(false, draws_dev, draws_stride);
+  });
+}
+int wn_engine_synchronize(wn_engine* e, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    HIP_OK(hipStreamSynchronize(e->stream));
+  });
+}
+
+int wn_engine_get_positions(wn_engine* e, double* out, WalnutpyError** err) {
+  return guarded(err, [&] { e->download_rows(e->theta, out); });
+}
+int wn_engine_get_inv_mass(wn_engine* e, double* out, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (!e->frozen) throw std::runtime_error("inverse mass is available after freeze");
+    e->download_rows(e->inv_mass, out);
+  });
+}
+int wn_engine_get_step_sizes(wn_engine* e, double* out, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e->frozen) {
+      e->download(e->step_size, out, e->C);
+    } else if (e->adapters_ready) {
+      std::vector<double> a(6 * e->C);
+      e->download(e->adam, a.data(), a.size());
+      for (size_t c = 0; c < e->C; ++c) out[c] = wnd::dexp(a[6 * c]);
+    } else {
+      e->download(e->step_init, out, e->C);
+    }
+  });
+}
+int wn_engine_get_logp(wn_engine* e, double* out, WalnutpyError** err) {
+  return guarded(err, [&] { e->download(e->logp, out, e->C); });
+}
+int wn_engine_get_min_micro(wn_engine* e, int32_t* out, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e->frozen) {
+      e->download(e->min_micro, out, e->C);
+    } else {
+      std::vector<double> mm(2 * e->C);
+      e->download(e->mm_state, mm.data(), mm.size());
+      for (size_t c = 0; c < e->C; ++c) {
+        const long long est = std::llround(mm[2 * c] / mm[2 * c + 1] / e->cfg.max_macro_steps_target);
+        out[c] = static_cast<int32_t>(std::max<long long>(est, e->cfg.min_micro_steps));
+      }
+    }
+  });
+}
+int wn_engine_get_depths(wn_engine* e, int32_t* out, WalnutpyError** err) {
+  return guarded(err, [&] { e->download(e->depth, out, e->C); });
+}
+int wn_engine_get_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err) {
+  return guarded(err, [&] { e->download(e->grad_evals, out, e->C); });
+}
+int wn_engine_get_rng_draws(wn_engine* e, int32_t* out, WalnutpyError** err) {
+  return guarded(err, [&] { e->download(e->rng_draws, out, e->C); });
+}
+int wn_engine_get_adam(wn_engine* e, double* out, WalnutpyError** err) {
+  return guarded(err, [&] { e->download(e->adam, out, 6 * e->C); });
+}
+int wn_engine_get_estimator(wn_engine* e, double* dm, double* ds, double* sm, double* ss, double* w,
+                            WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->download_rows(e->draw_mean, dm);
+    e->download_rows(e->draw_ssd, ds);
+    e->download_rows(e->score_mean, sm);
+    e->download_rows(e->score_ssd, ss);
+    e->download(e->est_weight, w, 2 * e->C);
+  });
+}
+int wn_engine_total_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    HIP_OK(hipMemsetAsync(e->scratch64.p, 0, sizeof(unsigned long long), e->stream));
+    hipLaunchKernelGGL(wn::sum_i64_kernel, dim3(256), dim3(256), 0, e->stream, e->grad_evals.p,
+                       static_cast<int>(e->C), e->scratch64.p);
+    HIP_OK(hipGetLastError());
+    unsigned long long v = 0;
+    HIP_OK(hipMemcpyAsync(&v, e->scratch64.p, sizeof(v), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    *out = static_cast<int64_t>(v);
+  });
+}
+
+int wn_engine_lanes(const wn_engine* e) { return 64 * e->geo.nw; }
+int wn_engine_dim_padded(const wn_engine* e) { return e->Dp; }
+int wn_engine_workgroups(const wn_engine* e) { return e->grid; }
+int wn_engine_lds_vectors(const wn_engine* e) { return e->pool_lds; }
+int64_t wn_engine_iteration(const wn_engine* e) { return e->iteration; }
+void* wn_engine_stream(const wn_engine* e) { return reinterpret_cast<void*>(e->stream); }
+double* wn_engine_positions_device(const wn_engine* e) { return e->theta.p; }
+int wn_engine_last_kernel_ms(wn_engine* e, float* ms, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (!e->timed) throw std::runtime_error("no transition has been launched");
+    e->use_device();
+    HIP_OK(hipEventSynchronize(e->ev1));
+    HIP_OK(hipEventElapsedTime(ms, e->ev0, e->ev1));
+  });
+}
+int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane) {
+  try {
+    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane).nw;
+  } catch (...) {
+    return -1;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// wn_launch.h -- launch geometry table and per-model kernel dispatch (host side).
+#pragma once
+
+#include "wn_hip.h"
+
+#include <stdexcept>
+
+#include "wn_params.h"
+
+namespace wn {
+
+struct InitParams;
+
+// NW wavefronts cooperate on one chain, each lane holds EPL elements of every vector:
+// padded dimension Dp = 64*NW*EPL.  START_REGS: the macro step's restart state stays in VGPRs.
+struct Geometry {
+  int nw, epl;
+  bool start_regs;
+};
+
+// X(NW, EPL, START_REGS)
+#if defined(WN_SIM_GEOMETRIES)  // tests/cpusim: small workgroups only; (1,4) exercises the pool-resident restart state
+#define WN_FOR_EACH_GEOMETRY(X) X(1, 2, true) X(1, 4, false) X(2, 2, true)
+#elif defined(WN_FAST_BUILD)
+#define WN_FOR_EACH_GEOMETRY(X) X(1, 2, true) X(4, 4, true) X(2, 8, true)
+#else
+#define WN_FOR_EACH_GEOMETRY(X)                                                                     \
+  X(1, 2, true) X(1, 4, true) X(1, 8, true) X(1, 16, true) X(2, 4, true) X(2, 8, true) X(4, 4, true) \
+  X(4, 8, true) X(8, 4, true) X(8, 8, true) X(16, 4, true) X(16, 8, false)
+#endif
+
+inline bool geometry_exists(int nw, int epl, bool* start_regs) {
+#define WN_X(NW, EPL, SR)          \
+  if (nw == NW && epl == EPL) {    \
+    *start_regs = SR;              \
+    return true;                   \
+  }
+  WN_FOR_EACH_GEOMETRY(WN_X)
+#undef WN_X
+  return false;
+}
+
+inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
+  Geometry g{0, 0, true};
+  if (nw_req > 0 && epl_req > 0) {
+    if (!geometry_exists(nw_req, epl_req, &g.start_regs) || 64 * nw_req * epl_req < dim)
+      throw std::invalid_argument("unsupported waves_per_chain / elems_per_lane for this num_params");
+    g.nw = nw_req;
+    g.epl = epl_req;
+    return g;
+  }
+  static const int pref[][2] = {{1, 2}, {1, 4}, {2, 4}, {4, 4}, {4, 8}, {8, 8}, {16, 8}};
+  for (const auto& p : pref) {
+    if (64 * p[0] * p[1] >= dim && geometry_exists(p[0], p[1], &g.start_regs)) {
+      g.nw = p[0];
+      g.epl = p[1];
+      return g;
+    }
+  }
+  // fast builds carry a reduced table: take the smallest entry that fits
+  int best = 1 << 30;
+#define WN_X(NW, EPL, SR)                                  \
+  if (64 * NW * EPL >= dim && 64 * NW * EPL < best) {      \
+    best = 64 * NW * EPL;                                  \
+    g = Geometry{NW, EPL, SR};                             \
+  }
+  WN_FOR_EACH_GEOMETRY(WN_X)
+#undef WN_X
+  if (g.nw == 0) throw std::invalid_argument("num_params exceeds the register-resident kernels (max 8192)");
+  return g;
+}
+
+inline int default_workgroups_per_cu(const Geometry& g) { return g.nw >= 8 ? 1 : 8 / g.nw; }
+
+// defined once per model in wn_kernels_<model>.hip
+#define WN_DECLARE_MODEL(tag)                                                                              \
+  void launch_transition_##tag(const Geometry&, int grid, size_t smem, hipStream_t, const Params&);        \
+  void launch_init_##tag(const Geometry&, int grid, size_t smem, hipStream_t, const InitParams&);          \
+  void prepare_##tag(const Geometry&, size_t smem);
+WN_DECLARE_MODEL(std_normal)
+WN_DECLARE_MODEL(diag_normal)
+WN_DECLARE_MODEL(funnel)
+#undef WN_DECLARE_MODEL
+
+inline void launch_transition(int model, const Geometry& g, int grid, size_t smem, hipStream_t s, const Params& p) {
+  switch (model) {
+    case kStdNormal: launch_transition_std_normal(g, grid, smem, s, p); break;
+    case kDiagNormal: launch_transition_diag_normal(g, grid, smem, s, p); break;
+    case kFunnel: launch_transition_funnel(g, grid, smem, s, p); break;
+    default: throw std::invalid_argument("unknown device model id");
+  }
+}
+inline void launch_init(int model, const Geometry& g, int grid, size_t smem, hipStream_t s, const InitParams& q) {
+  switch (model) {
+    case kStdNormal: launch_init_std_normal(g, grid, smem, s, q); break;
+    case kDiagNormal: launch_init_diag_normal(g, grid, smem, s, q); break;
+    case kFunnel: launch_init_funnel(g, grid, smem, s, q); break;
+    default: throw std::invalid_argument("unknown device model id");
+  }
+}
+inline void prepare_kernels(int model, const Geometry& g, size_t smem) {
+  switch (model) {
+    case kStdNormal: prepare_std_normal(g, smem); break;
+    case kDiagNormal: prepare_diag_normal(g, smem); break;
+    case kFunnel: prepare_funnel(g, smem); break;
+    default: throw std::invalid_argument("unknown device model id");
+  }
+}
+
+}  // namespace wn

@@ -1,0 +1,72 @@
+// wn_params.h -- plain-data launch parameters shared by the host side (wn_capi.cpp) and the kernels.
+#pragma once
+
+#include <stdint.h>
+
+namespace wn {
+
+constexpr int kMaxLevels = 16;   // span-stack levels => max_trajectory_doublings <= 17
+constexpr int kMaxPool = 64;     // vector buffers per resident chain (free mask is 64 bits)
+constexpr int kMetaDoubles = 96; // per-wave scalar scratch kept in LDS (see Traj::Meta)
+
+enum ModelKind : int32_t { kStdNormal = 0, kDiagNormal = 1, kFunnel = 2 };
+enum RngMode : int32_t { kRngPhilox = 0, kRngBuffer = 1 };
+
+// Every [C][Dp] plane is chain-major: one chain's vector is contiguous, rows are
+// padded to Dp = 64*NW*EPL doubles so that lane l of the chain's workgroup owns
+// the 16-byte pairs (k*L + l), k = 0..EPL/2-1 (L = 64*NW lanes per chain).
+struct Params {
+  // geometry
+  int32_t num_chains;
+  int32_t dim;        // D
+  int32_t dim_padded; // Dp
+  int32_t warmup;     // 1: AdaptiveWalnuts transition, 0: WalnutsSampler transition
+  // per-chain planes [C][Dp]
+  double* theta;
+  double* inv_mass;        // sampling phase: frozen inverse mass diagonal
+  double* est_draw_mean;   // MassEstimator state (adaptive_walnuts.hpp:25-105)
+  double* est_draw_ssd;
+  double* est_score_mean;
+  double* est_score_ssd;
+  // per-chain scalars
+  double* step_size;   // [C] sampling: frozen step; warmup: exp(adam.theta) is used instead
+  int32_t* min_micro;  // [C] sampling: frozen
+  double* adam;        // [C][6] theta, m, v, t, b1pow, b2pow
+  double* est_weight;  // [C][2] draw, score
+  double* mm_state;    // [C][2] total, count (MinMicroStepsAdaptHandler)
+  double* logp_out;    // [C]
+  int32_t* depth_out;  // [C]
+  int64_t* grad_evals; // [C] running totals
+  int32_t* rng_draws;  // [C] scalar draws of the last transition
+  // output of this transition
+  double* draws_out;   // nullable; row c at draws_out + c*draws_stride, D doubles
+  int64_t draws_stride;
+  // model
+  const double* model_params; // DIAG_NORMAL: sigma_sq [Dp] (padding = 1.0)
+  // configuration (SamplingConfig / WarmupConfig)
+  int32_t max_depth;
+  int32_t max_halvings;
+  int32_t cfg_min_micro;
+  int32_t pad0;
+  double max_error;
+  double mass_init_count;
+  double macro_target;
+  double adam_target, adam_lr, adam_b1, adam_b2, adam_eps, adam_decay;
+  // randomness
+  uint64_t seed;
+  uint32_t chain_offset;
+  uint32_t transition;
+  int32_t rng_mode;
+  int32_t u_stride;      // kRngBuffer: uniforms per chain
+  const double* z_buf;   // kRngBuffer: [C][Dp] standard normals
+  const double* u_buf;   // kRngBuffer: [C][u_stride] canonical uniforms
+  int64_t warmup_iter;   // AdaptiveWalnuts::iteration_
+  // scratch
+  double* arena;         // [slots][pool_global][Dp]
+  int64_t arena_stride;  // doubles per slot
+  int32_t pool_lds;      // vector buffers living in LDS
+  int32_t pool_total;    // LDS + arena buffers
+  uint32_t* work_counter;
+};
+
+}  // namespace wn

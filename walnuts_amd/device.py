@@ -1,0 +1,152 @@
+"""``walnuts_device``: the reference's ``walnuts_pyfunc`` (python/src/walnutpie/pyfunc.py:45-286) for built-in
+device models.  Same keyword arguments, defaults, output arrays and error mapping; the host log-density
+callable is replaced by ``model`` (+ ``model_params``)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Generic, Optional, TypeVar
+
+import numpy as np
+
+from . import _ffi
+
+T = TypeVar("T")
+
+
+@dataclass
+class WarmupInfo(Generic[T]):  # python/src/walnutpie/util.py:47-66
+    stepsize: float
+    inv_metric: Optional[np.ndarray]
+    warmup_draws: Optional[T]
+
+
+class WalnutsOutputArray(np.ndarray):  # python/src/walnutpie/pyfunc.py (ndarray with a .warmup attribute)
+    warmup: WarmupInfo
+
+    def __new__(cls, input_array, warmup: WarmupInfo):
+        obj = np.asarray(input_array).view(cls)
+        obj.warmup = warmup
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is None:
+            return
+        self.warmup = getattr(obj, "warmup", None)
+
+
+def _prepare_output_buffer(*, num_chains, num_params, max_sampling_iter, max_warmup_iter, save_warmup):
+    # python/src/walnutpie/util.py:16-32
+    if num_chains < 1:
+        raise ValueError("num_chains must be at least 1")
+    if max_warmup_iter < 0:
+        raise ValueError("max_warmup_iter must be non-negative")
+    if max_sampling_iter < 1:
+        raise ValueError("max_sampling_iter must be at least 1")
+    num_draws = max_sampling_iter + max_warmup_iter * save_warmup
+    return np.zeros((num_chains, num_draws, num_params), dtype=np.float64)
+
+
+def _prepare_inv_metric(init_inv_metric, metric_size, num_chains):
+    # python/src/walnutpie/util.py:35-46
+    if init_inv_metric is None:
+        return None
+    init_inv_metric = np.asarray(init_inv_metric, dtype=np.float64)
+    if init_inv_metric.shape == metric_size:
+        return np.ascontiguousarray(np.repeat(init_inv_metric[np.newaxis], num_chains, axis=0))
+    if init_inv_metric.shape == (num_chains, *metric_size):
+        return np.ascontiguousarray(init_inv_metric)
+    raise ValueError(f"Invalid initial metric size. Expected a {metric_size} or {(num_chains, *metric_size)} matrix.")
+
+
+def walnuts_device(
+    model: int,
+    *,
+    model_params: Optional[np.ndarray] = None,
+    num_params: Optional[int] = None,
+    inits: Optional[np.ndarray] = None,
+    num_chains: int = 4,
+    seed: Optional[int] = None,
+    id: int = 1,
+    init_radius: float = 2.0,
+    init_inv_metric: Optional[np.ndarray] = None,
+    save_inv_metric: bool = False,
+    min_warmup_iter: int = 50,
+    max_warmup_iter: int = 1000,
+    min_sampling_iter: int = 50,
+    max_sampling_iter: int = 1000,
+    max_trajectory_doublings: int = 5,
+    max_step_halvings: int = 5,
+    min_micro_steps: int = 1,
+    max_hamiltonian_error: float = 0.5,
+    step_size_converge_tol: float = 0.1,
+    mass_converge_tol: float = 1.0,
+    rhat_converge_tol: float = 1.01,
+    mass_init_count: float = 4.0,
+    mass_additive_smoothing: float = 1e-5,
+    max_macro_steps_target: float = 15.0,
+    step_size_init: float = 1.0,
+    step_accept_rate_target: float = 0.8,
+    step_learning_rate: float = 0.05,
+    step_gradient_decay: float = 0.8,
+    step_sq_gradient_decay: float = 0.9,
+    step_stabilization: float = 1e-4,
+    step_learn_rate_decay: float = 0.5,
+    save_warmup: bool = False,
+    refresh: int = 0,
+    lib_path: Optional[str] = None,
+) -> list:
+    lib = _ffi.load_library(lib_path)
+    if inits is not None:
+        inits = np.asarray(inits, dtype=np.float64)
+        if inits.ndim == 1:
+            inits = np.repeat(inits[np.newaxis], num_chains, axis=0)
+        if inits.shape[0] != num_chains:
+            raise ValueError("inits must have one row per chain")
+        inits = np.ascontiguousarray(inits)
+        if num_params is None:
+            num_params = inits.shape[1]
+        elif num_params != inits.shape[1]:
+            raise ValueError("num_params does not match inits")
+    if num_params is None:
+        raise ValueError("At least one of num_params or inits must be specified")
+    if seed is None:
+        seed = int(np.random.randint(0, 2**32 - 1, dtype=np.uint32))
+    mp = None if model_params is None else np.ascontiguousarray(np.asarray(model_params, dtype=np.float64))
+    if mp is not None and mp.size != num_params:
+        raise ValueError("model_params must have num_params entries")
+
+    out = _prepare_output_buffer(num_chains=num_chains, num_params=num_params, max_sampling_iter=max_sampling_iter,
+                                 max_warmup_iter=max_warmup_iter, save_warmup=save_warmup)
+    inv_metric_init = _prepare_inv_metric(init_inv_metric, (num_params,), num_chains)
+    final_lengths = np.zeros(2 * num_chains, dtype=np.intc)
+    stepsize_out = np.zeros(num_chains, dtype=np.float64)
+    inv_metric_out = np.zeros((num_chains, num_params), dtype=np.float64) if save_inv_metric else None
+
+    def _print(msg, length, bad):
+        print(msg[:length].decode("utf-8", "replace"), end="", flush=True)
+
+    cb = _ffi.PRINT_CALLBACK(_print)
+    dp = _ffi._dp
+    err = C.c_void_p()
+    rc = lib.walnutpie_sample_device(
+        model, None if mp is None else mp.ctypes.data_as(dp), num_params,
+        None if inits is None else inits.ctypes.data_as(dp), num_chains, seed, id, init_radius,
+        None if inv_metric_init is None else inv_metric_init.ctypes.data_as(dp), min_warmup_iter, max_warmup_iter,
+        min_sampling_iter, max_sampling_iter, max_trajectory_doublings, max_step_halvings, min_micro_steps,
+        max_hamiltonian_error, step_size_converge_tol, mass_converge_tol, rhat_converge_tol, mass_init_count,
+        mass_additive_smoothing, max_macro_steps_target, step_size_init, step_accept_rate_target, step_learning_rate,
+        step_gradient_decay, step_sq_gradient_decay, step_stabilization, step_learn_rate_decay, save_warmup,
+        out.ctypes.data_as(dp), out.size, final_lengths.ctypes.data_as(C.POINTER(C.c_int)),
+        stepsize_out.ctypes.data_as(dp), None if inv_metric_out is None else inv_metric_out.ctypes.data_as(dp),
+        refresh, cb, C.byref(err))
+    _ffi.check(lib, rc, err)
+
+    results = []  # python/src/walnutpie/pyfunc.py:270-286
+    for c in range(num_chains):
+        n_warm, n_samp = int(final_lengths[c]), int(final_lengths[num_chains + c])
+        warm = out[c, :n_warm] if save_warmup else None
+        info = WarmupInfo(stepsize=float(stepsize_out[c]),
+                          inv_metric=None if inv_metric_out is None else inv_metric_out[c], warmup_draws=warm)
+        results.append(WalnutsOutputArray(out[c, n_warm:n_warm + n_samp], info))
+    return results

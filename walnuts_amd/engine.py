@@ -1,0 +1,187 @@
+"""Batched engine handle: the per-transition verbs of include/walnuts_hip.h.
+
+``DeviceEngine`` advances ALL chains by one transition per call; its methods are named after the reference
+objects they batch: ``warmup_step`` = ``AdaptiveWalnuts::operator()`` (adaptive_walnuts.hpp:234-251),
+``freeze`` = ``AdaptiveWalnuts::sampler()`` (:263-271), ``sample_step`` = ``WalnutsSampler::operator()``
+(walnuts.hpp:682-692); the init methods follow ``InitConfigBuilder`` (config.hpp:195-484).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+
+MODEL_STD_NORMAL, MODEL_DIAG_NORMAL, MODEL_FUNNEL = 0, 1, 2
+_dp = _ffi._dp
+
+
+def default_config(lib_path: Optional[str] = None, **overrides) -> _ffi.Config:
+    cfg = _ffi.Config()
+    _ffi.load_library(lib_path).wn_default_config(C.byref(cfg))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class DeviceEngine:
+    def __init__(self, model: int, dim: int, num_chains: int, cfg: Optional[_ffi.Config] = None,
+                 params: Optional[np.ndarray] = None, lib_path: Optional[str] = None):
+        self.lib = _ffi.load_library(lib_path)
+        self.cfg = cfg if cfg is not None else default_config(lib_path)
+        self.C, self.D = int(num_chains), int(dim)
+        p = None if params is None else _f64(params)
+        if p is not None and p.size != dim:
+            raise ValueError("model params must have num_params entries")
+        h, err = C.c_void_p(), C.c_void_p()
+        rc = self.lib.wn_engine_create(C.byref(h), model, dim, None if p is None else p.ctypes.data_as(_dp),
+                                       num_chains, C.byref(self.cfg), C.byref(err))
+        _ffi.check(self.lib, rc, err)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wn_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, fn, *args):
+        err = C.c_void_p()
+        _ffi.check(self.lib, fn(self.h, *args, C.byref(err)), err)
+
+    # ---- InitConfigBuilder
+    def set_positions(self, pos):
+        a = _f64(pos).reshape(self.C, self.D)
+        self._call(self.lib.wn_engine_set_positions, a.ctypes.data_as(_dp))
+
+    def set_masses(self, mass):
+        a = _f64(mass).reshape(self.C, self.D)
+        self._call(self.lib.wn_engine_set_masses, a.ctypes.data_as(_dp))
+
+    def set_step_sizes(self, steps):
+        a = _f64(np.broadcast_to(np.asarray(steps, dtype=np.float64), (self.C,)))
+        self._call(self.lib.wn_engine_set_step_sizes, a.ctypes.data_as(_dp))
+
+    def init_positions(self, seed: int, chain_offset: int, scale: float):
+        self._call(self.lib.wn_engine_init_positions, seed, chain_offset, scale)
+
+    def init_masses_from_grad(self, smoothing: float):
+        self._call(self.lib.wn_engine_init_masses_from_grad, smoothing)
+
+    def adapt_step(self, seed: int, chain_offset: int = 0):
+        self._call(self.lib.wn_engine_adapt_step, seed, chain_offset)
+
+    def adapt_step_with_normals(self, normals):
+        a = _f64(normals).reshape(self.C, self.D)
+        self._call(self.lib.wn_engine_adapt_step_with_normals, a.ctypes.data_as(_dp))
+
+    def seed_chains(self, seed: int, chain_offset: int = 0):
+        self._call(self.lib.wn_engine_seed, seed, chain_offset)
+
+    def set_variates(self, normals, uniforms):
+        z = _f64(normals).reshape(self.C, self.D)
+        u = _f64(uniforms).reshape(self.C, -1)
+        self._call(self.lib.wn_engine_set_variates, z.ctypes.data_as(_dp), u.ctypes.data_as(_dp), u.shape[1])
+
+    # ---- transitions.  draws_ptr: integer device address (e.g. torch tensor .data_ptr()) or None
+    def warmup_step(self, draws_ptr: Optional[int] = None, stride: int = 0):
+        self._call(self.lib.wn_engine_warmup_step, C.c_void_p(draws_ptr), stride)
+
+    def freeze(self):
+        self._call(self.lib.wn_engine_freeze)
+
+    def sample_step(self, draws_ptr: Optional[int] = None, stride: int = 0):
+        self._call(self.lib.wn_engine_sample_step, C.c_void_p(draws_ptr), stride)
+
+    def synchronize(self):
+        self._call(self.lib.wn_engine_synchronize)
+
+    # ---- state
+    def _get(self, fn, shape, dtype=np.float64, ptr=_dp):
+        out = np.empty(shape, dtype=dtype)
+        self._call(fn, out.ctypes.data_as(ptr))
+        return out
+
+    def positions(self):
+        return self._get(self.lib.wn_engine_get_positions, (self.C, self.D))
+
+    def inv_mass(self):
+        return self._get(self.lib.wn_engine_get_inv_mass, (self.C, self.D))
+
+    def step_sizes(self):
+        return self._get(self.lib.wn_engine_get_step_sizes, (self.C,))
+
+    def logp(self):
+        return self._get(self.lib.wn_engine_get_logp, (self.C,))
+
+    def adam(self):
+        return self._get(self.lib.wn_engine_get_adam, (self.C, 6))
+
+    def min_micro(self):
+        return self._get(self.lib.wn_engine_get_min_micro, (self.C,), np.int32, _ffi._i32p)
+
+    def depths(self):
+        return self._get(self.lib.wn_engine_get_depths, (self.C,), np.int32, _ffi._i32p)
+
+    def grad_evals(self):
+        return self._get(self.lib.wn_engine_get_grad_evals, (self.C,), np.int64, _ffi._i64p)
+
+    def rng_draws(self):
+        return self._get(self.lib.wn_engine_get_rng_draws, (self.C,), np.int32, _ffi._i32p)
+
+    def estimator(self):
+        dm, ds, sm, ss = (np.empty((self.C, self.D)) for _ in range(4))
+        w = np.empty((self.C, 2))
+        self._call(self.lib.wn_engine_get_estimator, *(x.ctypes.data_as(_dp) for x in (dm, ds, sm, ss, w)))
+        return dict(draw_mean=dm, draw_ssd=ds, score_mean=sm, score_ssd=ss, weights=w)
+
+    def total_grad_evals(self) -> int:
+        v = C.c_int64()
+        self._call(self.lib.wn_engine_total_grad_evals, C.byref(v))
+        return v.value
+
+    def last_kernel_ms(self) -> float:
+        v = C.c_float()
+        self._call(self.lib.wn_engine_last_kernel_ms, C.byref(v))
+        return v.value
+
+    @property
+    def lanes(self) -> int:
+        return self.lib.wn_engine_lanes(self.h)
+
+    @property
+    def dim_padded(self) -> int:
+        return self.lib.wn_engine_dim_padded(self.h)
+
+    @property
+    def workgroups(self) -> int:
+        return self.lib.wn_engine_workgroups(self.h)
+
+    @property
+    def lds_vectors(self) -> int:
+        return self.lib.wn_engine_lds_vectors(self.h)
+
+    @property
+    def iteration(self) -> int:
+        return self.lib.wn_engine_iteration(self.h)
+
+    @property
+    def stream(self) -> int:
+        return self.lib.wn_engine_stream(self.h) or 0
+
+    @property
+    def positions_device_ptr(self) -> int:
+        return self.lib.wn_engine_positions_device(self.h) or 0

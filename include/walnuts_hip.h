@@ -161,6 +161,14 @@ WALNUTS_HIP_EXPORT void* wn_engine_stream(const wn_engine* e);     /* hipStream_
 WALNUTS_HIP_EXPORT double* wn_engine_positions_device(const wn_engine* e);
 /* HIP-event time of the last transition kernel launch, milliseconds */
 WALNUTS_HIP_EXPORT int wn_engine_last_kernel_ms(wn_engine* e, float* ms, WalnutpyError** err);
+/* per-launch HIP-event durations of the transition kernel since the last reset (recorded on the engine's
+ * stream around every launch); num_launches may exceed max_launches */
+WALNUTS_HIP_EXPORT int wn_engine_timing_reset(wn_engine* e, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_kernel_times(wn_engine* e, float* ms_out, int max_launches, int* num_launches,
+                                              WalnutpyError** err);
+/* run on a caller-owned hipStream_t (e.g. the framework's current stream, so that RCCL collectives on the
+ * draws are ordered after the kernels without host synchronisation) */
+WALNUTS_HIP_EXPORT int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane);
 /* (internal) allocates the error object handed back through WalnutpyError** */
 WALNUTS_HIP_EXPORT void* wn_internal_make_error(const char* msg, int type);

@@ -214,6 +214,20 @@ struct PhiloxRandom final : RandomSource {
   }
 };
 
+// host-supplied variates for one transition (the device engine's kRngBuffer mode)
+struct BufferRandom final : RandomSource {
+  const double* z;
+  const double* u;
+  size_t n_u;
+  BufferRandom(const double* zz, const double* uu, size_t nu) : z(zz), u(uu), n_u(nu) {}
+  double uniform01() override {
+    const size_t j = static_cast<size_t>(scalar_draws++);
+    return j < n_u ? u[j] : 0.5;
+  }
+  bool bernoulli() override { return uniform01() < 0.5; }
+  void normals(size_t n, double* out) override { std::copy(z, z + n, out); }
+};
+
 // ---------------------------------------------------------------------------
 // Adam on log step size (adam.hpp:35-109)
 // ---------------------------------------------------------------------------
@@ -567,6 +581,21 @@ struct wno_engine {
   bool adapt_ready = false;
   bool trace_on = false;
   int64_t iteration = 0;
+  Vec var_z, var_u;  // pending host-supplied variates (one transition)
+  size_t var_nu = 0;
+
+  // the RandomSource a chain uses for the next transition
+  struct RngLease {
+    RandomSource* r;
+    std::unique_ptr<RandomSource> owned;
+  };
+  RngLease lease_rng(Chain& ch) {
+    if (var_nu == 0) return {ch.rng.get(), nullptr};
+    const size_t c = static_cast<size_t>(&ch - chains.data());
+    auto b = std::make_unique<BufferRandom>(var_z.data() + c * D, var_u.data() + c * var_nu, var_nu);
+    RandomSource* raw = b.get();
+    return {raw, std::move(b)};
+  }
 
   void ensure_adapters() {
     if (adapt_ready) return;
@@ -583,7 +612,7 @@ struct wno_engine {
     adapt_ready = true;
   }
 
-  Ctx make_ctx(Chain& ch, const double* im, double step, size_t min_micro, Adam* adam) {
+  Ctx make_ctx(Chain& ch, RandomSource* rng, const double* im, double step, size_t min_micro, Adam* adam) {
     Ctx c;
     c.model = &model;
     c.im = im;
@@ -594,7 +623,7 @@ struct wno_engine {
     c.max_error = cfg.max_hamiltonian_error;
     c.mo = mo;
     c.red = red;
-    c.rng = ch.rng.get();
+    c.rng = rng;
     c.adam = adam;
     c.trace = trace_on ? &ch.trace : nullptr;
     if (trace_on) ch.trace.clear();
@@ -605,12 +634,13 @@ struct wno_engine {
     Vec im(D), chol(D);
     ch.est.inv_mass(im.data());
     for (size_t i = 0; i < D; ++i) chol[i] = std::sqrt(1.0 / im[i]);
-    ch.rng->begin_transition(ch.transitions);
-    Ctx c = make_ctx(ch, im.data(), ch.adam.step_size(), ch.mm.value(), &ch.adam);
+    RngLease lease = lease_rng(ch);
+    lease.r->begin_transition(ch.transitions);
+    Ctx c = make_ctx(ch, lease.r, im.data(), ch.adam.step_size(), ch.mm.value(), &ch.adam);
     transition(c, chol.data(), static_cast<size_t>(cfg.max_trajectory_doublings), ch.theta, ch.depth, ch.grad_sel,
                ch.logp);
     ch.grad_evals += c.grad_evals;
-    ch.last_scalar_draws = ch.rng->scalar_draws;
+    ch.last_scalar_draws = lease.r->scalar_draws;
     ch.est.observe(ch.theta.data(), ch.grad_sel.data(), ch.iteration);
     ch.mm.observe(static_cast<size_t>(1) << ch.depth);
     ++ch.iteration;
@@ -629,12 +659,13 @@ struct wno_engine {
   }
 
   void sample_chain(Chain& ch) {  // walnuts.hpp:682-692
-    ch.rng->begin_transition(ch.transitions);
-    Ctx c = make_ctx(ch, ch.inv_mass.data(), ch.step, ch.min_micro, nullptr);
+    RngLease lease = lease_rng(ch);
+    lease.r->begin_transition(ch.transitions);
+    Ctx c = make_ctx(ch, lease.r, ch.inv_mass.data(), ch.step, ch.min_micro, nullptr);
     transition(c, ch.chol.data(), static_cast<size_t>(cfg.max_trajectory_doublings), ch.theta, ch.depth,
                ch.grad_sel, ch.logp);
     ch.grad_evals += c.grad_evals;
-    ch.last_scalar_draws = ch.rng->scalar_draws;
+    ch.last_scalar_draws = lease.r->scalar_draws;
     ++ch.transitions;
   }
 
@@ -821,9 +852,16 @@ void wno_seed_chains(wno_engine* e, uint64_t seed, uint32_t chain_offset) {
   }
 }
 
+void wno_set_variates(wno_engine* e, const double* normals, const double* uniforms, size_t u_per_chain) {
+  e->var_z.assign(normals, normals + e->C * e->D);
+  e->var_u.assign(uniforms, uniforms + e->C * u_per_chain);
+  e->var_nu = u_per_chain;
+}
+
 void wno_warmup_step(wno_engine* e, int num_threads) {
   e->ensure_adapters();
   e->for_chains(num_threads, [&](Chain& ch) { e->warmup_chain(ch); });
+  e->var_nu = 0;
   ++e->iteration;
 }
 
@@ -834,6 +872,7 @@ void wno_freeze(wno_engine* e) {
 
 void wno_sample_step(wno_engine* e, int num_threads) {
   e->for_chains(num_threads, [&](Chain& ch) { e->sample_chain(ch); });
+  e->var_nu = 0;
   ++e->iteration;
 }
 

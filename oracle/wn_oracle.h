@@ -85,6 +85,10 @@ void wno_adapt_step(wno_engine* e, uint64_t s0, uint64_t s1);
  * chain ids chain_offset+m */
 void wno_seed_chains(wno_engine* e, uint64_t seed, uint32_t chain_offset);
 
+/* host-supplied variates for the NEXT transition only: normals [C*D], canonical uniforms [C*u_per_chain]
+ * consumed in order, bernoulli = (u < 0.5) as libstdc++ does (mirrors wn_engine_set_variates) */
+void wno_set_variates(wno_engine* e, const double* normals, const double* uniforms, size_t u_per_chain);
+
 /* ---- stepping ----------------------------------------------------------- */
 void wno_warmup_step(wno_engine* e, int num_threads); /* AdaptiveWalnuts::operator() for all chains */
 void wno_freeze(wno_engine* e);                       /* AdaptiveWalnuts::sampler() */

@@ -77,6 +77,7 @@ def lib():
     L.wno_init_masses_from_grad.argtypes = [vp, dbl, i32]
     L.wno_adapt_step.argtypes = [vp, u64, u64]
     L.wno_seed_chains.argtypes = [vp, u64, u32]
+    L.wno_set_variates.argtypes = [vp, _dp, _dp, sz]
     L.wno_warmup_step.argtypes = [vp, i32]
     L.wno_freeze.argtypes = [vp]
     L.wno_sample_step.argtypes = [vp, i32]
@@ -178,6 +179,11 @@ class Engine:
 
     def seed_chains(self, seed: int, chain_offset: int = 0):
         self.L.wno_seed_chains(self.h, seed, chain_offset)
+
+    def set_variates(self, normals, uniforms):
+        z = _f64(normals).reshape(self.C, self.D)
+        u = _f64(uniforms).reshape(self.C, -1)
+        self.L.wno_set_variates(self.h, _p(z), _p(u), u.shape[1])
 
     # --- stepping
     def warmup_step(self, threads: int = 1):

@@ -1,0 +1,109 @@
+"""Shared parity driver: runs the same call sequence on the product engine (HIP library on a GPU, or the
+test-only CPU emulation of it) and on the oracle configured to replay the device's execution order
+(portable maths, counter-based stream, reductions over `engine.lanes` lanes), and demands bit equality.
+
+Bit-exact is the bar for the element-wise leapfrog state AND for every reduced scalar, because both sides
+execute the same IEEE operations in the same order; the <=1e-10 relative bar of BASELINE.json's north star
+is the distance between this device-order oracle and the reference-order oracle (sequential sums, libm),
+checked separately in tests/test_oracle_kat.py and test_*_parity.py::test_reference_order_tolerance.
+"""
+import numpy as np
+
+import walnuts_amd as wa
+import wno
+
+MODELS = {"std_normal": (wa.MODEL_STD_NORMAL, wno.MODEL_STD_NORMAL),
+          "diag_normal": (wa.MODEL_DIAG_NORMAL, wno.MODEL_DIAG_NORMAL),
+          "funnel": (wa.MODEL_FUNNEL, wno.MODEL_FUNNEL)}
+
+CFG_FIELDS = ("max_trajectory_doublings", "max_step_halvings", "min_micro_steps", "max_hamiltonian_error",
+              "mass_init_count", "max_macro_steps_target", "step_accept_rate_target", "step_learning_rate",
+              "step_gradient_decay", "step_sq_gradient_decay", "step_stabilization", "step_learn_rate_decay")
+
+
+def model_params(model: str, D: int):
+    if model != "diag_normal":
+        return None
+    return np.array([(1.0 + (d % 16)) ** 2 for d in range(D)])  # sigma_d = 1 + (d mod 16), SURVEY.md §8d cfg4
+
+
+def make_pair(model: str, D: int, C: int, lib_path=None, geometry=None, **cfg_over):
+    """-> (device engine, oracle engine) with identical configuration."""
+    dm, om = MODELS[model]
+    geo = {}
+    if geometry is not None:
+        geo = dict(waves_per_chain=geometry[0], elems_per_lane=geometry[1])
+    extra = {k: cfg_over.pop(k) for k in ("workgroups_per_cu", "lds_vectors") if k in cfg_over}
+    dcfg = wa.default_config(lib_path, **cfg_over, **geo, **extra)
+    params = model_params(model, D)
+    dev = wa.DeviceEngine(dm, D, C, dcfg, params=params, lib_path=lib_path)
+    ocfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_PORTABLE, reduce_lanes=dev.lanes,
+                              **cfg_over)
+    orc = wno.Engine(om, D, C, ocfg, params=params)
+    return dev, orc
+
+
+def assert_same_state(dev, orc, where: str, warm: bool):
+    dev.synchronize()
+    checks = [("positions", dev.positions(), orc.positions()), ("logp", dev.logp(), orc.logp()),
+              ("depths", dev.depths(), orc.depths()), ("grad_evals", dev.grad_evals(), orc.grad_evals()),
+              ("rng_draws", dev.rng_draws(), orc.rng_draws())]
+    if warm:
+        checks.append(("adam", dev.adam(), orc.adam()))
+        de, oe = dev.estimator(), orc.estimator()
+        for k in ("draw_mean", "draw_ssd", "score_mean", "score_ssd", "weights"):
+            checks.append(("estimator." + k, de[k], oe[k]))
+        checks.append(("min_micro", dev.min_micro(), orc.min_micro()))
+        checks.append(("step_sizes", dev.step_sizes(), orc.step_sizes()))
+    for name, a, b in checks:
+        a, b = np.asarray(a), np.asarray(b)
+        if not np.array_equal(a, b.astype(a.dtype) if a.dtype != b.dtype else b):
+            bad = np.argwhere(a != b)
+            raise AssertionError(f"{where}: {name} differs at {bad[:4].tolist()} "
+                                 f"device={a[tuple(bad[0])]!r} oracle={b[tuple(bad[0])]!r} ({len(bad)} entries)")
+    assert np.all(dev.depths() >= 1), f"{where}: device reported span-pool exhaustion"
+
+
+def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path=None, geometry=None, seed=1234,
+             init="random", step=None, check_every=1, **cfg_over):
+    """InitConfigBuilder -> warmup -> freeze -> sampling on both sides, bit-compared along the way."""
+    dev, orc = make_pair(model, D, C, lib_path, geometry, **cfg_over)
+    rng = np.random.default_rng(seed)
+    if init == "random":
+        pos = rng.normal(0.0, 2.0, size=(C, D))  # init_radius 2.0, pyfunc.py:57
+        for x in (dev, orc):
+            x.set_positions(pos)
+    elif init == "device":
+        dev.init_positions(seed, 7, 2.0)
+        orc.init_positions(seed, 7, 2.0)
+        dev.synchronize()
+        assert np.array_equal(dev.positions(), orc.positions()), "init positions differ"
+    dev.init_masses_from_grad(1e-5)
+    orc.init_masses_from_grad(1e-5)
+    for x in (dev, orc):
+        x.set_step_sizes(1.0 if step is None else step)
+    if step is None:
+        dev.adapt_step(seed, 11)
+        orc.adapt_step(seed, 11)
+        dev.synchronize()
+        assert np.array_equal(dev.step_sizes(), orc.step_sizes()), \
+            f"adapt_step differs: {dev.step_sizes()[:4]} vs {orc.step_sizes()[:4]}"
+    for x in (dev, orc):
+        x.seed_chains(seed + 1, 3)
+    for it in range(warmup):
+        dev.warmup_step()
+        orc.warmup_step(8)
+        if (it + 1) % check_every == 0 or it == warmup - 1:
+            assert_same_state(dev, orc, f"{model} D={D} warmup it={it}", warm=True)
+    dev.freeze()
+    orc.freeze()
+    dev.synchronize()
+    assert np.array_equal(dev.step_sizes(), orc.step_sizes()), "frozen step sizes differ"
+    assert np.array_equal(dev.inv_mass(), orc.inv_mass()), "frozen inverse mass differs"
+    assert np.array_equal(dev.min_micro(), orc.min_micro().astype(np.int32)), "frozen min micro steps differ"
+    for it in range(sampling):
+        dev.sample_step()
+        orc.sample_step(8)
+        if (it + 1) % check_every == 0 or it == sampling - 1:
+            assert_same_state(dev, orc, f"{model} D={D} sampling it={it}", warm=False)
+    return dev, orc

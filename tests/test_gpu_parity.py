@@ -1,0 +1,201 @@
+"""GPU tier (-m gpu): the HIP path through the C ABI against the oracle, bit for bit, on seeded inputs
+sized so that the oracle finishes in seconds, plus size-independent properties at BASELINE.json's full
+sizes.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+import parity
+import walnuts_amd as wa
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_variates_case(lib_path, D=96, C=8):
+    dev, orc = parity.make_pair("std_normal", D, C, lib_path)
+    rng = np.random.default_rng(5)
+    pos = rng.normal(size=(C, D))
+    for x in (dev, orc):
+        x.set_positions(pos)
+        x.set_step_sizes(0.4)
+        x.seed_chains(1, 0)
+    for it in range(3):
+        z, u = rng.normal(size=(C, D)), rng.uniform(size=(C, 64))
+        for x in (dev, orc):
+            x.set_variates(z, u)
+            x.warmup_step()
+        parity.assert_same_state(dev, orc, f"variates warmup {it}", warm=True)
+    dev.freeze()
+    orc.freeze()
+    for it in range(3):
+        z, u = rng.normal(size=(C, D)), rng.uniform(size=(C, 64))
+        for x in (dev, orc):
+            x.set_variates(z, u)
+            x.sample_step()
+        parity.assert_same_state(dev, orc, f"variates sampling {it}", warm=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(oracle):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tier needs a GPU"
+    wa.load_library()  # the in-tree HIP extension, or raise
+
+
+# ---- leapfrog + tree + adaptation, every launch geometry -----------------------------------------------
+@pytest.mark.parametrize("model,D,C,geometry", [
+    ("std_normal", 100, 64, None),          # BASELINE config #1 shape: (1,2)
+    ("std_normal", 3, 16, None),            # odd tiny D, heavy padding
+    ("std_normal", 256, 64, (1, 4)),
+    ("std_normal", 500, 48, (1, 8)),
+    ("std_normal", 1024, 128, (4, 4)),      # headline geometry
+    ("std_normal", 1024, 64, (1, 16)),      # one wavefront per chain
+    ("std_normal", 1024, 64, (2, 8)),
+    ("std_normal", 1000, 32, (4, 8)),
+    ("std_normal", 2048, 32, (8, 4)),
+    ("std_normal", 4096, 24, (8, 8)),
+    ("std_normal", 4000, 16, (16, 4)),
+    ("std_normal", 8192, 12, (16, 8)),      # restart state parked in the span pool
+    ("diag_normal", 1024, 96, None),        # config #2/#4 family
+    ("diag_normal", 130, 64, (1, 4)),
+    ("funnel", 128, 128, None),             # config #3
+    ("funnel", 1000, 32, (4, 4)),           # cross-wavefront reductions inside the model
+])
+def test_engine_matches_oracle_bitwise(model, D, C, geometry):
+    parity.run_case(model, D, C, warmup=12, sampling=8, geometry=geometry, check_every=2)
+
+
+def test_device_side_initialisation_matches_oracle():
+    parity.run_case("std_normal", 777, 40, warmup=3, sampling=2, init="device")
+    parity.run_case("funnel", 64, 40, warmup=3, sampling=2, init="device")
+
+
+def test_ill_conditioned_config2_long_warmup():
+    # sigma_d = d+1 (examples/examples.cpp:20-31), D=1024: the config #2 model on a chain subset
+    D, C = 1024, 32
+    s2 = np.array([(d + 1.0) ** 2 for d in range(D)])
+    parity.MODELS  # noqa
+    old = parity.model_params
+    parity.model_params = lambda m, d: s2 if m == "diag_normal" else None
+    try:
+        parity.run_case("diag_normal", D, C, warmup=40, sampling=10, check_every=10)
+    finally:
+        parity.model_params = old
+
+
+def test_span_pool_in_lds_or_hbm_gives_identical_chains():
+    outs = []
+    for lds in (-1, 4, 0):
+        dev, _ = parity.run_case("std_normal", 512, 32, warmup=6, sampling=6, lds_vectors=lds, check_every=6)
+        outs.append(dev.positions())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_deep_trees_and_halvings():
+    parity.run_case("std_normal", 64, 64, warmup=0, sampling=6, step=0.02, max_trajectory_doublings=9,
+                    check_every=3)  # tiny step: trees reach depth 9 (511 leaves)
+    parity.run_case("std_normal", 64, 64, warmup=0, sampling=6, step=2.9, max_trajectory_doublings=4,
+                    check_every=3)  # huge step: halving levels + reversibility checks
+    parity.run_case("funnel", 32, 64, warmup=10, sampling=10, step=1.5, max_step_halvings=8, check_every=5)
+
+
+def test_host_supplied_variates_path():
+    """kRngBuffer: normals and canonical uniforms supplied by the host (the hook for exact libstdc++-stream
+    runs), compared with the oracle fed the same variates."""
+    _host_variates_case(None)
+
+
+# ---- size-independent properties at full BASELINE sizes --------------------------------------------------
+def _logp_std_normal(x):
+    return -0.5 * np.einsum("ij,ij->i", x, x)
+
+
+def test_full_size_headline_properties():
+    """65 536 chains x 1 024 dims (BASELINE headline): determinism, chain independence (a chain's result is
+    a function of (seed, chain id, state) only, however chains are batched) and reported logp == logp(theta)."""
+    D, C = 1024, 65536
+    rng = np.random.default_rng(9)
+    pos = rng.normal(0, 1, size=(C, D))
+
+    def run(chains, offset):
+        e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, len(chains))
+        e.set_positions(pos[chains])
+        e.set_step_sizes(0.35)
+        e.seed_chains(77, offset)
+        e.freeze()
+        for _ in range(3):
+            e.sample_step()
+        e.synchronize()
+        return e.positions(), e.logp(), e.grad_evals(), e.depths()
+
+    full = run(np.arange(C), 0)
+    again = run(np.arange(C), 0)
+    for a, b in zip(full, again):
+        assert np.array_equal(a, b)
+    sub = np.arange(1000, 1000 + 512)
+    part = run(sub, 1000)
+    for a, b in zip(full, part):
+        assert np.array_equal(a[sub], b)
+    lp = _logp_std_normal(full[0])
+    assert np.allclose(full[1], lp, rtol=1e-12, atol=0)
+    assert full[2].min() >= 3 * 2 and full[3].min() >= 1 and full[3].max() <= 6
+
+
+def test_full_size_high_dim_properties():
+    """8 192 chains x 8 192 dims, diagonal Gaussian (the register-resident kernels' largest D)."""
+    D, C = 8192, 8192
+    s2 = np.array([(1.0 + (d % 16)) ** 2 for d in range(D)])
+    e = wa.DeviceEngine(wa.MODEL_DIAG_NORMAL, D, C, params=s2)
+    e.init_positions(3, 0, 2.0)
+    e.init_masses_from_grad(1e-5)
+    e.set_step_sizes(1.0)
+    e.adapt_step(3, 0)
+    e.seed_chains(4, 0)
+    for _ in range(3):
+        e.warmup_step()
+    e.freeze()
+    e.sample_step()
+    e.synchronize()
+    x = e.positions()
+    lp = np.zeros(C)
+    for lo in range(0, C, 1024):
+        xs = x[lo:lo + 1024]
+        lp[lo:lo + 1024] = np.sum(-0.5 * xs * xs / s2, axis=1)
+    assert np.allclose(e.logp(), lp, rtol=1e-11, atol=0)
+    assert np.all(np.isfinite(x)) and e.depths().min() >= 1
+    assert np.all(e.step_sizes() > 0) and np.all(np.isfinite(e.inv_mass()))
+
+
+def test_sample_device_contract_on_gpu():
+    # python/tests/test_pyfunc.py:38-125 for the device entry point
+    kw = dict(num_params=100, num_chains=4, seed=1234, min_warmup_iter=30, max_warmup_iter=30, min_sampling_iter=20,
+              max_sampling_iter=20, save_inv_metric=True)
+    a = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    b = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    c = wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "seed": 99})
+    assert len(a) == 4 and all(x.shape == (20, 100) for x in a)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y) and x.warmup.stepsize == y.warmup.stepsize
+        assert np.array_equal(x.warmup.inv_metric, y.warmup.inv_metric)
+    assert not np.array_equal(a[0], c[0])
+    with pytest.raises(ValueError, match="min_iter must be"):
+        wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "min_sampling_iter": 100, "max_sampling_iter": 10})
+
+
+def test_sampler_statistics_are_sane():
+    """Not a parity test: the chains actually sample the target (std normal, D=100, many chains)."""
+    D, C = 100, 4096
+    e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, C)
+    e.init_positions(1, 0, 2.0)
+    e.init_masses_from_grad(1e-5)
+    e.set_step_sizes(1.0)
+    e.adapt_step(1, 0)
+    e.seed_chains(2, 0)
+    for _ in range(150):
+        e.warmup_step()
+    e.freeze()
+    for _ in range(20):
+        e.sample_step()
+    x = e.positions()
+    assert abs(x.mean()) < 0.01 and abs(x.var() - 1.0) < 0.02
+    assert 0.2 < np.median(e.step_sizes()) < 1.5

@@ -1,0 +1,98 @@
+"""CPU tier: the product's device maths header (walnuts_amd/csrc/wn_devmath.h), compiled for the host,
+against the oracle's independently written copy (bit for bit), libm (few ulp) and the Random123 known-answer
+vectors for Philox4x32-10."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHIM = r'''
+#include "wn_devmath.h"
+extern "C" {
+double p_exp(double x) { return wnd::dexp(x); }
+double p_log(double x) { return wnd::dlog(x); }
+double p_pow(double x, double y) { return wnd::dpow_pos(x, y); }
+void p_sincospi(double a, double* s, double* c) { wnd::dsincospi(a, *s, *c); }
+void p_philox(const unsigned* c, const unsigned* k, unsigned* o) {
+  wnd::U4 r = wnd::philox(c[0], c[1], c[2], c[3], k[0], k[1]); o[0]=r.x; o[1]=r.y; o[2]=r.z; o[3]=r.w; }
+double p_uniform(unsigned long long seed, unsigned chain, unsigned t, unsigned stream, unsigned idx) {
+  return wnd::stream_uniform(seed, chain, t, stream, idx); }
+void p_normal_pair(unsigned long long seed, unsigned chain, unsigned t, unsigned stream, unsigned pair, double* z) {
+  wnd::stream_normal_pair(seed, chain, t, stream, pair, z[0], z[1]); }
+}
+'''
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    d = tmp_path_factory.mktemp("devmath")
+    src = d / "shim.cpp"
+    src.write_text(SHIM)
+    so = d / "libshim.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I",
+                           os.path.join(ROOT, "walnuts_amd", "csrc"), str(src), "-o", str(so)])
+    L = C.CDLL(str(so))
+    for f in ("p_exp", "p_log"):
+        getattr(L, f).restype = C.c_double
+        getattr(L, f).argtypes = [C.c_double]
+    L.p_pow.restype = C.c_double
+    L.p_pow.argtypes = [C.c_double, C.c_double]
+    L.p_uniform.restype = C.c_double
+    L.p_uniform.argtypes = [C.c_uint64, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    return L
+
+
+def test_philox_known_answers(shim):
+    # Random123 kat_vectors, philox4x32 10 rounds
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        c, k, o = (C.c_uint * 4)(*ctr), (C.c_uint * 2)(*key), (C.c_uint * 4)()
+        shim.p_philox(c, k, o)
+        assert tuple(o) == want
+
+
+def test_exp_log_bitwise_equal_to_oracle_copy_and_close_to_libm(shim, oracle):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-745, 709, 20000), rng.normal(0, 3, 20000), [0.0, -0.0, 1.0, -1.0, 709.7, -745.0]])
+    L = oracle.lib()
+    for x in xs:
+        a, b = shim.p_exp(x), L.wno_math_exp(x)
+        assert a == b or (np.isnan(a) and np.isnan(b))
+        ref = np.exp(x)
+        assert abs(a - ref) <= 1.0 * np.spacing(ref) or ref == 0.0
+    ys = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0.5, 2.0, 20000), [1.0, 5e-324, 1e308]])
+    for y in ys:
+        a, b = shim.p_log(y), L.wno_math_log(y)
+        assert a == b
+        ref = np.log(y)
+        assert abs(a - ref) <= 1.0 * np.spacing(abs(ref)) + 1e-320
+    assert shim.p_exp(0.0) == 1.0 and shim.p_log(1.0) == 0.0
+    assert shim.p_log(0.0) == -np.inf and np.isnan(shim.p_log(-1.0)) and shim.p_exp(1000.0) == np.inf
+    assert shim.p_pow(49.0, 0.5) == 7.0 and shim.p_pow(3.0, 0.0) == 1.0
+
+
+def test_streams_bitwise_equal_to_oracle_copy(shim, oracle):
+    for seed, chain, t in ((1, 0, 0), (2**40 + 17, 65535, 1234), (2**63 + 5, 2**31, 2**31 + 1)):
+        for idx in range(50):
+            assert shim.p_uniform(seed, chain, t, 1, idx) == oracle.stream_uniform(seed, chain, t, 1, idx)
+        zs = oracle.stream_normals(seed, chain, t, 0, 101)
+        for p in range(51):
+            z = (C.c_double * 2)()
+            shim.p_normal_pair(C.c_uint64(seed), chain, t, 0, p, z)
+            assert z[0] == zs[2 * p]
+            if 2 * p + 1 < 101:
+                assert z[1] == zs[2 * p + 1]
+
+
+def test_stream_moments(oracle):
+    z = np.concatenate([oracle.stream_normals(9, c, 3, 0, 4096) for c in range(64)])
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1) < 0.01 and abs((z**4).mean() - 3) < 0.08
+    u = np.array([oracle.stream_uniform(9, 1, 2, 1, i) for i in range(20000)])
+    assert 0 < u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01

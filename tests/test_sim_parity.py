@@ -1,0 +1,95 @@
+"""CPU tier: the product's HOST logic and kernel control flow under the test-only workgroup emulation
+(tests/cpusim) against the oracle.  Small on purpose: the emulation runs one OS thread per lane.
+Device parity proper is tests/test_gpu_parity.py (-m gpu)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpusim"))
+import build as simbuild  # noqa: E402
+import parity  # noqa: E402
+import walnuts_amd as wa  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return simbuild.build()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("model,D,geometry", [
+    ("std_normal", 10, None),          # (1,2): D < one pair per lane, heavy padding
+    ("diag_normal", 130, (1, 4)),      # (1,4): restart state parked in the span pool
+    ("funnel", 9, (2, 2)),             # two wavefronts: cross-wave reductions, broadcasts, barriers
+])
+def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry):
+    parity.run_case(model, D, 3, warmup=6, sampling=4, lib_path=sim, geometry=geometry)
+
+
+@pytest.mark.timeout(600)
+def test_emulated_engine_lds_pool_and_arena_paths(sim, oracle):
+    # same chains with the whole pool in "LDS", half of it, none of it: identical results
+    outs = []
+    for lds in (-1, 6, 0):
+        dev, orc = parity.run_case("std_normal", 12, 2, warmup=3, sampling=3, lib_path=sim, lds_vectors=lds,
+                                   max_trajectory_doublings=4)
+        outs.append(dev.positions())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.timeout(600)
+def test_emulated_engine_halving_and_reversibility(sim, oracle):
+    # an oversized fixed step forces step halvings and reversibility re-integrations (walnuts.hpp:254-279)
+    dev, orc = parity.run_case("std_normal", 6, 2, warmup=0, sampling=4, lib_path=sim, step=3.5,
+                               max_trajectory_doublings=3)
+    assert dev.grad_evals().sum() > 4 * 2 * 8  # more than the no-halving count
+
+
+@pytest.mark.timeout(600)
+def test_emulated_engine_host_variates(sim, oracle):
+    import test_gpu_parity
+
+    test_gpu_parity._host_variates_case(sim, D=10, C=2)
+
+
+def test_emulated_sample_device_contract(sim):
+    # python/tests/test_pyfunc.py:38-125 restated for the device entry point
+    kw = dict(num_params=5, num_chains=2, seed=1234, min_warmup_iter=4, max_warmup_iter=4, min_sampling_iter=3,
+              max_sampling_iter=3, save_inv_metric=True, lib_path=sim)
+    a = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    b = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    c = wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "seed": 4321})
+    assert len(a) == 2 and a[0].shape == (3, 5)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+        assert x.warmup.stepsize == y.warmup.stepsize
+        assert np.array_equal(x.warmup.inv_metric, y.warmup.inv_metric)
+    assert not np.array_equal(a[0], c[0])
+    w = wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "save_warmup": True})
+    assert w[0].warmup.warmup_draws.shape == (4, 5) and w[0].shape == (3, 5)
+    with pytest.raises(ValueError, match="min_iter must be"):
+        wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "min_sampling_iter": 100, "max_sampling_iter": 10})
+    with pytest.raises(ValueError, match="min_iter cannot be greater"):
+        wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "min_warmup_iter": 100, "max_warmup_iter": 10})
+    with pytest.raises(ValueError, match="refresh must be non-negative"):
+        wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "refresh": -1})
+
+
+def test_emulated_sample_device_output_buffer_check(sim):
+    lib = wa.load_library(sim)
+    out = np.zeros(10)
+    lens = np.zeros(4, dtype=np.intc)
+    err = C.c_void_p()
+    dp = C.POINTER(C.c_double)
+    rc = lib.walnutpie_sample_device(0, None, 5, None, 2, 1, 1, 2.0, None, 2, 2, 2, 2, 5, 5, 1, 0.5, 0.1, 1.0, 1.01, 4.0,
+                                     1e-5, 15.0, 1.0, 0.8, 0.05, 0.8, 0.9, 1e-4, 0.5, False, out.ctypes.data_as(dp),
+                                     out.size, lens.ctypes.data_as(C.POINTER(C.c_int)), None, None, 0,
+                                     C.cast(None, wa._ffi.PRINT_CALLBACK), C.byref(err))
+    assert rc == -1
+    msg = lib.walnutpie_get_error_message(err).decode()
+    assert msg.startswith("Output buffer too small. Expected at least 2 chains of 10 doubles, got 10")
+    assert lib.walnutpie_get_error_type(err) == 0  # generic (std::runtime_error), walnutpy.cpp:153-160
+    lib.walnutpie_destroy_error(err)

@@ -9,6 +9,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/walnuts_hip.h"
@@ -97,13 +98,27 @@ struct wn_engine {
   bool variates_pending = false;
   int u_stride = 0;
 
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
+  // one HIP event pair per transition launch since the last timing reset
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  bool own_stream = true;
 
   ~wn_engine() {
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (stream) (void)hipStreamDestroy(stream);
+    for (auto& ev : events) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    if (stream && own_stream) (void)hipStreamDestroy(stream);
+  }
+
+  std::pair<hipEvent_t, hipEvent_t>& next_events() {
+    if (events_used == events.size()) {
+      hipEvent_t a, b;
+      HIP_OK(hipEventCreate(&a));
+      HIP_OK(hipEventCreate(&b));
+      events.emplace_back(a, b);
+    }
+    return events[events_used++];
   }
 
   void use_device() { HIP_OK(hipSetDevice(device)); }
@@ -207,11 +222,11 @@ struct wn_engine {
     use_device();
     wn::Params P = make_params(warm, draws_dev, draws_stride);
     HIP_OK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), stream));
-    HIP_OK(hipEventRecord(ev0, stream));
+    auto& ev = next_events();
+    HIP_OK(hipEventRecord(ev.first, stream));
     wn::launch_transition(model, geo, grid, smem, stream, P);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipEventRecord(ev1, stream));
-    timed = true;
+    HIP_OK(hipEventRecord(ev.second, stream));
     variates_pending = false;
     ++transition;
     ++iteration;
@@ -256,8 +271,6 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   HIP_OK(hipGetDeviceProperties(&prop, e.device));
   e.num_cus = prop.multiProcessorCount;
   HIP_OK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
-  HIP_OK(hipEventCreate(&e.ev0));
-  HIP_OK(hipEventCreate(&e.ev1));
 
   // residency: how many chains (workgroups) share a CU, and how much of the span pool sits in LDS
   const size_t lds_per_cu = 160 * 1024;
@@ -570,10 +583,34 @@ void* wn_engine_stream(const wn_engine* e) { return reinterpret_cast<void*>(e->s
 double* wn_engine_positions_device(const wn_engine* e) { return e->theta.p; }
 int wn_engine_last_kernel_ms(wn_engine* e, float* ms, WalnutpyError** err) {
   return guarded(err, [&] {
-    if (!e->timed) throw std::runtime_error("no transition has been launched");
+    if (e->events_used == 0) throw std::runtime_error("no transition has been launched");
     e->use_device();
-    HIP_OK(hipEventSynchronize(e->ev1));
-    HIP_OK(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    auto& ev = e->events[e->events_used - 1];
+    HIP_OK(hipEventSynchronize(ev.second));
+    HIP_OK(hipEventElapsedTime(ms, ev.first, ev.second));
+  });
+}
+int wn_engine_timing_reset(wn_engine* e, WalnutpyError** err) {
+  return guarded(err, [&] { e->events_used = 0; });
+}
+int wn_engine_kernel_times(wn_engine* e, float* ms_out, int max_launches, int* num_launches, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    const int n = static_cast<int>(e->events_used);
+    if (num_launches) *num_launches = n;
+    for (int i = 0; i < n && i < max_launches; ++i) {
+      HIP_OK(hipEventSynchronize(e->events[i].second));
+      HIP_OK(hipEventElapsedTime(&ms_out[i], e->events[i].first, e->events[i].second));
+    }
+  });
+}
+int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) HIP_OK(hipStreamDestroy(e->stream));
+    e->stream = reinterpret_cast<hipStream_t>(stream);
+    e->own_stream = false;
   });
 }
 int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane) {

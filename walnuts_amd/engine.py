@@ -158,6 +158,19 @@ class DeviceEngine:
         self._call(self.lib.wn_engine_last_kernel_ms, C.byref(v))
         return v.value
 
+    def timing_reset(self):
+        self._call(self.lib.wn_engine_timing_reset)
+
+    def kernel_times_ms(self, max_launches: int = 1 << 16) -> np.ndarray:
+        buf = np.zeros(max_launches, dtype=np.float32)
+        n = C.c_int()
+        self._call(self.lib.wn_engine_kernel_times, buf.ctypes.data_as(C.POINTER(C.c_float)), max_launches,
+                   C.byref(n))
+        return buf[: min(n.value, max_launches)].astype(np.float64)
+
+    def set_stream(self, stream_handle: int):
+        self._call(self.lib.wn_engine_set_stream, C.c_void_p(stream_handle))
+
     @property
     def lanes(self) -> int:
         return self.lib.wn_engine_lanes(self.h)

@@ -1,0 +1,49 @@
+"""Turns rocprofv3 rocpd databases (gpurun_out/<dir>/*_results.db) into the small text summaries committed
+under profiles/.  Usage: python profiles/summarize.py <round-tag> <trace_db> [<fetch_db> <write_db>]"""
+import sqlite3
+import sys
+
+
+def kernel_stats(db):
+    cur = sqlite3.connect(db).cursor()
+    lines = ["name | calls | total_us | avg_us | pct"]
+    for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        lines.append(f"{name} | {calls} | {total:.1f} | {avg:.1f} | {pct:.2f}")
+    rows = cur.execute("select name,(end-start)/1e3,grid_x,workgroup_x,lds_size,vgpr_count,sgpr_count from kernels "
+                       "where name like '%transition_kernel%' order by start").fetchall()
+    lines.append("")
+    lines.append("transition_kernel dispatches (us, grid threads, block, LDS bytes, VGPRs, SGPRs):")
+    for r in rows:
+        lines.append(f"  {r[1]:.1f} us  grid={r[2]} block={r[3]} lds={r[4]} vgpr={r[5]} sgpr={r[6]}")
+    return lines, rows
+
+
+def counter(db, kernel_like="%transition_kernel%"):
+    cur = sqlite3.connect(db).cursor()
+    return cur.execute("select counter_name,value,duration from counters_collection where kernel_name like ? order by start",
+                       (kernel_like,)).fetchall()
+
+
+def main():
+    tag, trace = sys.argv[1], sys.argv[2]
+    out = [f"# rocprofv3 summary {tag}", "", "## --kernel-trace --stats", ""]
+    lines, rows = kernel_stats(trace)
+    out += lines
+    if len(sys.argv) >= 5:
+        f, w = counter(sys.argv[3]), counter(sys.argv[4])
+        out += ["", "## PMC (separate passes; KB per dispatch of transition_kernel; kernels run serialised and slower under PMC)", ""]
+        for name, val, dur in f + w:
+            out.append(f"  {name} = {val:.1f} KB   (dispatch {dur/1e3:.1f} us)")
+        fs = [v for _, v, _ in f][-2:]
+        ws = [v for _, v, _ in w][-2:]
+        if fs and ws:
+            fetch, write = sum(fs) / len(fs), sum(ws) / len(ws)
+            out += ["",
+                    f"steady-state sampling launches: FETCH_SIZE {fetch:.0f} KB, WRITE_SIZE {write:.0f} KB",
+                    "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts wide coalesced reads at 1/2 ->",
+                    f"HBM traffic per launch ~= (2*FETCH_SIZE + WRITE_SIZE) * 1024 = {(2 * fetch + write) * 1024 / 1e9:.2f} GB"]
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -25,8 +25,9 @@ struct Geometry {
 #define WN_FOR_EACH_GEOMETRY(X) X(1, 2, true) X(4, 4, true) X(2, 8, true)
 #else
 #define WN_FOR_EACH_GEOMETRY(X)                                                                     \
-  X(1, 2, true) X(1, 4, true) X(1, 8, true) X(1, 16, true) X(2, 4, true) X(2, 8, true) X(4, 4, true) \
-  X(4, 8, true) X(8, 4, true) X(8, 8, true) X(16, 4, true) X(16, 8, false)
+  X(1, 2, true) X(1, 4, true) X(1, 8, true) X(1, 16, true) X(2, 2, true) X(2, 4, true) X(2, 8, true)   \
+  X(4, 2, true) X(4, 4, true) X(4, 8, true) X(8, 2, true) X(8, 4, true) X(8, 8, true) X(16, 4, true)     \
+  X(16, 8, false)
 #endif
 
 inline bool geometry_exists(int nw, int epl, bool* start_regs) {

@@ -50,18 +50,68 @@ __device__ __forceinline__ double uni(double v) {
   return wnd::as_f64((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
+// xor-butterfly sum over the 64 lanes, offsets 1,2,4,8,16,32: every lane ends with the same bits
+// (a+b == b+a), and the CPU oracle replays exactly this association order.
+#if defined(WN_CPU_SIM) || defined(WN_DISABLE_DPP)
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
   for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
   return v;
 }
+__device__ __forceinline__ double lane_value(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+#else
+// gfx950: offsets 1,2 are quad permutes, 4 and 8 are row_half_mirror / row_mirror (the groups are already
+// uniform there, so the mirrored lane holds the xor partner's value), 16 and 32 are v_permlane{16,32}_swap.
+// All VALU: no LDS crossbar traffic (ds_bpermute) on the reduction path.
+template <int CTRL>
+__device__ __forceinline__ double dpp_partner(double v) {
+  const uint64_t u = wnd::as_u64(v);
+  const int lo = static_cast<int>(u), hi = static_cast<int>(u >> 32);
+  const int plo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  const int phi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return wnd::as_f64((static_cast<uint64_t>(static_cast<uint32_t>(phi)) << 32) | static_cast<uint32_t>(plo));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v = v + dpp_partner<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+  v = v + dpp_partner<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+  v = v + dpp_partner<0x141>(v);  // row_half_mirror      : partner quad  (lane ^ 4)
+  v = v + dpp_partner<0x140>(v);  // row_mirror           : partner octet (lane ^ 8)
+  {
+    const uint64_t u = wnd::as_u64(v);
+    const uint32_t lo = static_cast<uint32_t>(u), hi = static_cast<uint32_t>(u >> 32);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = wnd::as_f64((static_cast<uint64_t>(b[0]) << 32) | a[0]) + wnd::as_f64((static_cast<uint64_t>(b[1]) << 32) | a[1]);
+  }
+  {
+    const uint64_t u = wnd::as_u64(v);
+    const uint32_t lo = static_cast<uint32_t>(u), hi = static_cast<uint32_t>(u >> 32);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = wnd::as_f64((static_cast<uint64_t>(b[0]) << 32) | a[0]) + wnd::as_f64((static_cast<uint64_t>(b[1]) << 32) | a[1]);
+  }
+  return v;
+}
+// value held by lane `src_lane` (wave-uniform index) as a scalar
+__device__ __forceinline__ double lane_value(double v, int src_lane) {
+  const uint64_t u = wnd::as_u64(v);
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(u), src_lane);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(u >> 32), src_lane);
+  return wnd::as_f64((static_cast<uint64_t>(hi) << 32) | lo);
+}
+#endif
 
-// util.hpp:174-183
+// util.hpp:174-183.  One of exp(x1-m), exp(x2-m) is exp(0) == 1 exactly, so only the other one is
+// evaluated; the sum is commutative, hence the same bits as the two-exp form.
 __device__ __forceinline__ double log_sum_exp(double x1, double x2) {
   const double m = fmax(x1, x2);
   if (x1 != x1 || x2 != x2) return __builtin_nan("");
   if (__builtin_isinf(m) || (x1 + x2) != (x1 + x2)) return fmax(x1, x2);
+#if defined(WN_VARIANT_LSE2)
   return m + wnd::dlog(wnd::dexp(x1 - m) + wnd::dexp(x2 - m));
+#else
+  const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
+  return m + wnd::dlog(1.0 + wnd::dexp(d));
+#endif
 }
 
 // ---- target densities (device form of the LogpGrad contract, concepts.hpp:258-262) ----
@@ -154,6 +204,8 @@ struct Traj {
     int in_th[kMaxLevels];
     int in_rh[kMaxLevels];
     int sel[kMaxLevels];
+    double u[64];   // tree draws draw_base .. draw_base+63 of this transition
+    double lu[64];  // their logarithms
   };
   static_assert(sizeof(Meta) <= kMetaDoubles * sizeof(double), "meta scratch too small");
 
@@ -174,6 +226,7 @@ struct Traj {
   int red_parity;
   long long n_grad;
   int n_draw;
+  int draw_base;        // first tree-draw index held in meta->u / meta->lu (-1: none)
   int err;
   double step, max_error;
   double w_draw0, w_score0;  // estimator weights at entry (read once: another wave's lane 0 rewrites them at exit)
@@ -292,6 +345,17 @@ struct Traj {
     free_mask &= free_mask - 1ull;
     return b;
   }
+  // long-lived vectors (accumulated span ends, parked states) take the highest free buffer so that the
+  // LDS-resident low indices stay available for the short-lived span-stack entries
+  __device__ __forceinline__ int alloc_cold() {
+    if (free_mask == 0ull) {
+      err = 1;
+      return 0;
+    }
+    const int b = uni(63 - __builtin_clzll(free_mask));
+    free_mask &= ~(1ull << b);
+    return b;
+  }
   __device__ __forceinline__ void release(int b) {
     if (b >= 0) free_mask |= (1ull << b);
   }
@@ -300,12 +364,41 @@ struct Traj {
   }
 
   // ---- randomness (util.hpp:102,112 order; counter-based stream or host-fed variates) ----
+  // The tree consumes wave-uniform scalars one at a time.  They are produced 64 at a time, lane j
+  // computing draw number draw_base + j and its logarithm into the wave's LDS scratch, and handed out with
+  // a broadcast LDS read.  (A v_readlane hand-out from registers was miscompiled by ROCm 7.2's backend:
+  // after a refill the read used the stale register pair; caught by the bit-exact parity tests.)
+  __device__ __forceinline__ void refill_draws(int base) {
+    draw_base = base;
+    const int j = base + lane;
+    double u;
+    if (P.rng_mode == kRngBuffer) {
+      u = j < P.u_stride ? P.u_buf[static_cast<long long>(chain) * P.u_stride + j] : 0.5;
+    } else {
+      u = wnd::stream_uniform(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamTree,
+                              static_cast<uint32_t>(j));
+    }
+    meta->u[lane] = u;
+    meta->lu[lane] = wnd::dlog(u);
+  }
+  __device__ __forceinline__ int next_draw_slot() {
+    const int j = uni(n_draw);
+    ++n_draw;
+    if (draw_base < 0 || j - draw_base >= 64) refill_draws(j & ~63);
+    return j - draw_base;
+  }
+#if defined(WN_VARIANT_NOCACHE)
   __device__ __forceinline__ double uniform01() {
     const int j = n_draw++;
     if (P.rng_mode == kRngBuffer) return uni(P.u_buf[static_cast<long long>(chain) * P.u_stride + j]);
     return uni(wnd::stream_uniform(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamTree,
                                    static_cast<uint32_t>(j)));
   }
+  __device__ __forceinline__ double log_uniform01() { return wnd::dlog(uniform01()); }
+#else
+  __device__ __forceinline__ double uniform01() { return uni(meta->u[next_draw_slot()]); }
+  __device__ __forceinline__ double log_uniform01() { return uni(meta->lu[next_draw_slot()]); }
+#endif
 
   // ---- Hamiltonian pieces ------------------------------------------------------------
   __device__ __forceinline__ double model_eval() {
@@ -370,7 +463,7 @@ struct Traj {
   // while coarser reverse paths are tried from (theta', -rho', grad').
   __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
     if (n == 1) return true;
-    const int k0 = alloc(), k1 = alloc(), k2 = alloc();
+    const int k0 = alloc_cold(), k1 = alloc_cold(), k2 = alloc_cold();
     pool_store(k0, th);
     pool_store(k1, rh);
     pool_store(k2, g);
@@ -477,6 +570,7 @@ struct Traj {
     err = 0;
     n_grad = 0;
     n_draw = 0;
+    draw_base = -1;
     max_error = P.max_error;
     free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
     const long long row = static_cast<long long>(chain) * Dp;
@@ -535,9 +629,9 @@ struct Traj {
     }
 
     if (!START_REGS) {
-      start_buf[0] = alloc();
-      start_buf[1] = alloc();
-      start_buf[2] = alloc();
+      start_buf[0] = alloc_cold();
+      start_buf[1] = alloc_cold();
+      start_buf[2] = alloc_cold();
     }
 
     // initial point (walnuts.hpp:532-535)
@@ -547,9 +641,9 @@ struct Traj {
       energy(part, lp_pos, lj);
     }
     int a_bk[3], a_fw[3];
-    a_bk[0] = a_fw[0] = alloc();
-    a_bk[1] = a_fw[1] = alloc();
-    a_bk[2] = a_fw[2] = alloc();
+    a_bk[0] = a_fw[0] = alloc_cold();
+    a_bk[1] = a_fw[1] = alloc_cold();
+    a_bk[2] = a_fw[2] = alloc_cold();
     pool_store(a_bk[0], th);
     pool_store(a_bk[1], rh);
     pool_store(a_bk[2], g);
@@ -605,7 +699,7 @@ struct Traj {
           }
           // combine<Barker> (walnuts.hpp:370-386): old = s, new = c
           const double total = log_sum_exp(s_logsum, c_logsum);
-          const bool update = wnd::dlog(uniform01()) < c_logsum - total;
+          const bool update = log_uniform01() < c_logsum - total;
           const int n_sel = update ? c_sel : s_sel;
           const double n_lpsel = update ? c_lpsel : s_lpsel;
           release_unless(s_sel, s_in_th, s_in_rh, n_sel);
@@ -645,7 +739,7 @@ struct Traj {
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
       const bool turned = fwd ? uturn_against(a_bk[0], a_bk[1], true) : uturn_against(a_fw[0], a_fw[1], false);
       const double total = log_sum_exp(a_logsum, c_logsum);
-      const bool update = wnd::dlog(uniform01()) < c_logsum - a_logsum;  // Metropolis
+      const bool update = log_uniform01() < c_logsum - a_logsum;  // Metropolis
       // the new span's inner end is never read again
       release_unless(c_in_th, c_sel, -2, -2);
       release_unless(c_in_rh, -2, -2, -2);
@@ -662,7 +756,7 @@ struct Traj {
       const int* other = fwd ? a_bk : a_fw;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        if (endp[r] == other[r] || endp[r] == a_sel) endp[r] = alloc();
+        if (endp[r] == other[r] || endp[r] == a_sel) endp[r] = alloc_cold();
       }
       pool_store(endp[0], th);
       pool_store(endp[1], rh);

@@ -142,32 +142,22 @@ def main():
     eng.adapt_step(args.seed, chain0)
     eng.seed_chains(args.seed + 1, chain0)
 
-    draws = [torch.empty((C, D), dtype=torch.float64, device="cuda") for _ in range(2)]
-    gathered = [torch.empty((world, C, D), dtype=torch.float64, device="cuda") for _ in range(2)] if world > 1 else None
-    pending = [None, None]
+    from walnuts_amd.distributed import DrawGather
+
+    gather = DrawGather(dist, world, C, D, "cuda", torch.float64)
 
     def one_step(i, timed_phase):
-        b = i & 1
-        if pending[b] is not None:
-            pending[b].wait()  # the collective that last read draws[b] is done
-            pending[b] = None
+        plane = gather.buffer(i)
         if timed_phase == "warmup":
-            eng.warmup_step(draws[b].data_ptr(), D)
+            eng.warmup_step(plane.data_ptr(), D)
         else:
-            eng.sample_step(draws[b].data_ptr(), D)
-        if world > 1:
-            # the path's only exchange: all-gather of this iteration's draws over xGMI, overlapped with the
-            # next transition
-            pending[b] = dist.all_gather_into_tensor(gathered[b].view(world * C, D), draws[b], async_op=True)
-
-    def drain():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+            eng.sample_step(plane.data_ptr(), D)
+        # the path's only exchange: all-gather of this iteration's draws over xGMI, overlapped with the next
+        # transition (no-op on one GPU)
+        gather.launch(i)
 
     def fence():
-        drain()
+        gather.drain()
         if world > 1:
             dist.barrier()
         eng.synchronize()

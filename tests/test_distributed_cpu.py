@@ -1,0 +1,92 @@
+"""CPU tier, world_size 2 over gloo: the N>1 driver logic (chain sharding + double-buffered all-gather of draws)
+run on the test-only workgroup emulation gives exactly the chains of a single-rank run."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+ROOT = sys.argv[1]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "cpusim")]
+import build as simbuild
+import walnuts_amd as wa
+from walnuts_amd.distributed import DrawGather, shard_chains
+
+SIM = simbuild.build()
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+D, TOTAL, ITERS = 6, 4, 3
+first, count = shard_chains(TOTAL, rank, world)
+pos = np.random.default_rng(3).normal(size=(TOTAL, D))
+
+def make(first, count):
+    e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, count, wa.default_config(SIM), lib_path=SIM)
+    e.set_positions(pos[first:first + count]); e.set_step_sizes(0.6); e.seed_chains(99, first)
+    return e
+
+eng = make(first, count)
+gather = DrawGather(dist, world, count, D, "cpu", torch.float64)
+seen = []
+for it in range(ITERS):
+    plane = gather.buffer(it)
+    eng.warmup_step(plane.data_ptr(), D) if it < 2 else (eng.freeze() if it == 2 else None, eng.sample_step(plane.data_ptr(), D))
+    eng.synchronize()
+    gather.launch(it)
+    seen.append(gather.result(it).clone().numpy())
+gather.drain()
+if rank == 0:
+    ref = make(0, TOTAL)
+    for it in range(ITERS):
+        buf = np.empty((TOTAL, D))
+        ptr = buf.ctypes.data
+        ref.warmup_step(ptr, D) if it < 2 else (ref.freeze() if it == 2 else None, ref.sample_step(ptr, D))
+        ref.synchronize()
+        assert np.array_equal(buf, seen[it]), (it, buf, seen[it])
+    print("DISTRIBUTED_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_chains_partition():
+    sys.path.insert(0, ROOT)
+    from walnuts_amd.distributed import shard_chains
+
+    for total, world in ((65536, 8), (10, 3), (7, 8), (262144, 8)):
+        parts = [shard_chains(total, r, world) for r in range(world)]
+        assert sum(c for _, c in parts) == total
+        nxt = 0
+        for first, count in parts:
+            assert first == nxt
+            nxt += count
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gloo_run_matches_single_rank(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=800)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "DISTRIBUTED_OK" in outs[0]

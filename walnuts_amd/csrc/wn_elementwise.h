@@ -37,14 +37,16 @@ static __global__ void begin_warmup_kernel(int C, int Dp, double count, const do
 // AdaptiveWalnuts::sampler() (adaptive_walnuts.hpp:263-271)
 static __global__ void freeze_kernel(int C, int Dp, const double* draw_ssd, const double* score_ssd,
                               const double* est_weight, const double* adam, const double* mm_state,
-                              double macro_target, int cfg_min_micro, double* inv_mass, double* step_size,
-                              int* min_micro) {
+                              double macro_target, int cfg_min_micro, double* inv_mass, double* chol_mass,
+                              double* step_size, int* min_micro) {
   const long long n = static_cast<long long>(C) * Dp;
   for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
     const long long c = i / Dp;
     const double wd = est_weight[2 * c], ws = est_weight[2 * c + 1];
-    inv_mass[i] = __builtin_sqrt((draw_ssd[i] / wd) / (score_ssd[i] / ws));
+    const double im = __builtin_sqrt((draw_ssd[i] / wd) / (score_ssd[i] / ws));
+    inv_mass[i] = im;
+    chol_mass[i] = 1.0 / __builtin_sqrt(im);  // walnuts.hpp:647
     if (i < C) {
       step_size[i] = wnd::dexp(adam[6 * i]);
       const double mean_micro = mm_state[2 * i] / mm_state[2 * i + 1];

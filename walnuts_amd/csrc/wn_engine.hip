@@ -81,7 +81,7 @@ struct wn_engine {
   size_t smem = 0;
   hipStream_t stream = nullptr;
 
-  DevBuf<double> theta, mass, inv_mass, draw_mean, draw_ssd, score_mean, score_ssd;
+  DevBuf<double> theta, mass, inv_mass, chol_mass, draw_mean, draw_ssd, score_mean, score_ssd;
   DevBuf<double> step_init, step_size, adam, est_weight, mm_state, logp, model_params, arena, z_buf, u_buf;
   DevBuf<int32_t> min_micro, depth, rng_draws;
   DevBuf<int64_t> grad_evals;
@@ -174,6 +174,7 @@ struct wn_engine {
     P.warmup = warm ? 1 : 0;
     P.theta = theta.p;
     P.inv_mass = inv_mass.p;
+    P.chol_mass = chol_mass.p;
     P.est_draw_mean = draw_mean.p;
     P.est_draw_ssd = draw_ssd.p;
     P.est_score_mean = score_mean.p;
@@ -287,7 +288,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(e.num_cus) * wg_per_cu));
 
   const size_t plane = num_chains * static_cast<size_t>(e.Dp);
-  for (DevBuf<double>* b : {&e.theta, &e.mass, &e.inv_mass, &e.draw_mean, &e.draw_ssd, &e.score_mean, &e.score_ssd})
+  for (DevBuf<double>* b : {&e.theta, &e.mass, &e.inv_mass, &e.chol_mass, &e.draw_mean, &e.draw_ssd, &e.score_mean, &e.score_ssd})
     b->alloc(plane);
   e.step_init.alloc(num_chains);
   e.step_size.alloc(num_chains);
@@ -480,8 +481,8 @@ int wn_engine_freeze(wn_engine* e, WalnutpyError** err) {
     const int blocks = static_cast<int>(std::min<size_t>((e->C * e->Dp + 255) / 256, 4096));
     hipLaunchKernelGGL(wn::freeze_kernel, dim3(blocks), dim3(256), 0, e->stream, static_cast<int>(e->C), e->Dp,
                        e->draw_ssd.p, e->score_ssd.p, e->est_weight.p, e->adam.p, e->mm_state.p,
-                       e->cfg.max_macro_steps_target, e->cfg.min_micro_steps, e->inv_mass.p, e->step_size.p,
-                       e->min_micro.p);
+                       e->cfg.max_macro_steps_target, e->cfg.min_micro_steps, e->inv_mass.p, e->chol_mass.p,
+                       e->step_size.p, e->min_micro.p);
     HIP_OK(hipGetLastError());
     e->frozen = true;
   });

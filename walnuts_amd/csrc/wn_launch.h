@@ -50,7 +50,9 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
     g.epl = epl_req;
     return g;
   }
-  static const int pref[][2] = {{1, 2}, {1, 4}, {2, 4}, {4, 4}, {4, 8}, {8, 8}, {16, 8}};
+  // measured on MI355X (profiles/): wave-uniform tree logic is replicated per wavefront, so few waves with
+  // many elements per lane win until VGPR pressure caps residency
+  static const int pref[][2] = {{1, 2}, {1, 4}, {1, 8}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
   for (const auto& p : pref) {
     if (64 * p[0] * p[1] >= dim && geometry_exists(p[0], p[1], &g.start_regs)) {
       g.nw = p[0];

@@ -7,7 +7,7 @@ namespace wn {
 
 constexpr int kMaxLevels = 16;   // span-stack levels => max_trajectory_doublings <= 17
 constexpr int kMaxPool = 64;     // vector buffers per resident chain (free mask is 64 bits)
-constexpr int kMetaDoubles = 224; // per-wave scalar scratch kept in LDS (see Traj::Meta)
+constexpr int kMetaDoubles = 248; // per-wave scalar scratch kept in LDS (see Traj::Meta)
 
 enum ModelKind : int32_t { kStdNormal = 0, kDiagNormal = 1, kFunnel = 2 };
 enum RngMode : int32_t { kRngPhilox = 0, kRngBuffer = 1 };
@@ -24,6 +24,7 @@ struct Params {
   // per-chain planes [C][Dp]
   double* theta;
   double* inv_mass;        // sampling phase: frozen inverse mass diagonal
+  double* chol_mass;       // sampling phase: 1/sqrt(inv_mass) (WalnutsSampler::cholesky_mass_, walnuts.hpp:647)
   double* est_draw_mean;   // MassEstimator state (adaptive_walnuts.hpp:25-105)
   double* est_draw_ssd;
   double* est_score_mean;

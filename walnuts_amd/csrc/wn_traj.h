@@ -188,7 +188,20 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
   }
 };
 
-constexpr int kHot = -1;  // "this vector currently lives in the VGPR trajectory end"
+// ---- optional phase profiler (tests/gpu_probes only; compiled out of the product build) -------------
+#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+enum { kPhIdle = 0, kPhPrologue, kPhLeapfrog, kPhEnergy, kPhRestart, kPhReversible, kPhUturn, kPhCombine, kPhPush,
+       kPhTopMerge, kPhDoublingStart, kPhEpilogue, kPhCount };
+__device__ unsigned long long wn_phase_cycles[kPhCount];
+#define WN_PHASE(k) this->phase_mark(k)
+#define WN_PHASE_OUTER(k) t.phase_mark(k)
+#else
+#define WN_PHASE(k) ((void)0)
+#define WN_PHASE_OUTER(k) ((void)0)
+#endif
+
+constexpr int kHot = -1;    // "this vector currently lives in the VGPR trajectory end"
+constexpr int kStart = -2;  // "this vector is the macro step's restart state (= the previous leaf), in VGPRs"
 
 template <class Model, int NW, int EPL, bool START_REGS>
 struct Traj {
@@ -206,7 +219,34 @@ struct Traj {
     int sel[kMaxLevels];
     double u[64];   // tree draws draw_base .. draw_base+63 of this transition
     double lu[64];  // their logarithms
+#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+    unsigned long long prof[16];
+    unsigned long long prof_last;
+    int prof_cur;
+#endif
   };
+#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+  __device__ __forceinline__ void phase_mark(int k) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      meta->prof[meta->prof_cur] += t - meta->prof_last;
+      meta->prof_last = t;
+      meta->prof_cur = k;
+    }
+  }
+  __device__ __forceinline__ void phase_begin() {
+    if (lane == 0) {
+      for (int i = 0; i < 16; ++i) meta->prof[i] = 0;
+      meta->prof_last = __builtin_amdgcn_s_memtime();
+      meta->prof_cur = kPhIdle;
+    }
+  }
+  __device__ __forceinline__ void phase_end() {
+    phase_mark(kPhIdle);
+    if (lane == 0)
+      for (int i = 0; i < kPhCount; ++i) atomicAdd(&wn_phase_cycles[i], meta->prof[i]);
+  }
+#endif
   static_assert(sizeof(Meta) <= kMetaDoubles * sizeof(double), "meta scratch too small");
 
   const Params& P;
@@ -411,8 +451,9 @@ struct Traj {
 #pragma unroll
     for (int j = 0; j < EPL; ++j) ke += im[j] * (rh[j] * rh[j]);
     sum2(lp_partial, ke);
-    logp_pos = Model::finish(lp_partial, aux, P.dim);
-    logp_joint = logp_pos + (-0.5 * ke);
+    // wave-uniform results go back to scalar registers: they live long and would otherwise hold VGPR pairs
+    logp_pos = uni(Model::finish(lp_partial, aux, P.dim));
+    logp_joint = uni(logp_pos + (-0.5 * ke));
   }
   // n leapfrog micro steps on the VGPR state (walnuts.hpp:328-333); returns the
   // last evaluation's log-density partial
@@ -463,7 +504,7 @@ struct Traj {
   // while coarser reverse paths are tried from (theta', -rho', grad').
   __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
     if (n == 1) return true;
-    const int k0 = alloc_cold(), k1 = alloc_cold(), k2 = alloc_cold();
+    const int k0 = alloc(), k1 = alloc(), k2 = alloc();  // short-lived: LDS first
     pool_store(k0, th);
     pool_store(k1, rh);
     pool_store(k2, g);
@@ -498,6 +539,7 @@ struct Traj {
   // walnuts.hpp:307-345.  In: VGPR state = span end, logp_start = its joint log
   // density.  Out (on success): VGPR state = new leaf.
   __device__ __forceinline__ bool macro_step(bool fwd, double logp_start, double& logp_pos, double& logp_joint) {
+    WN_PHASE(kPhRestart);
     if (START_REGS) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
@@ -527,22 +569,25 @@ struct Traj {
           pool_load(start_buf[2], g);
         }
       }
+      WN_PHASE(kPhLeapfrog);
       const double part = leapfrog(h, n);
+      WN_PHASE(kPhEnergy);
       energy(part, logp_pos, logp_joint);
       if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
         if (P.warmup) adam_observe(wnd::dexp(-fabs(logp_start - logp_joint)));
       }
-      if (fabs(logp_start - logp_joint) <= max_error) return reversible(h, n, logp_joint);
+      if (fabs(logp_start - logp_joint) <= max_error) {
+        WN_PHASE(kPhReversible);
+        return reversible(h, n, logp_joint);
+      }
+      WN_PHASE(kPhRestart);
     }
     return false;
   }
 
-  // walnuts.hpp:192-201: the VGPR state is the outer end of the newer span; (bth, brh)
-  // is the far end it is tested against.
-  __device__ __forceinline__ bool uturn_against(int bth, int brh, bool fwd) {
-    double a[EPL], b[EPL];
-    pool_load(bth, a);
-    pool_load(brh, b);
+  // walnuts.hpp:192-201: the VGPR state is the outer end of the newer span; (a, b) = (theta, rho) of
+  // the far end it is tested against.
+  __device__ __forceinline__ bool uturn_vectors(const double (&a)[EPL], const double (&b)[EPL], bool fwd) {
     double p_hot = 0.0, p_far = 0.0;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
@@ -554,10 +599,28 @@ struct Traj {
     sum2(p_hot, p_far);
     return p_hot < 0 || p_far < 0;
   }
+  __device__ __forceinline__ bool uturn_against(int bth, int brh, bool fwd) {
+    if (START_REGS && bth == kStart) return uturn_vectors(th0, rh0, fwd);  // the previous leaf, still in VGPRs
+    double a[EPL], b[EPL];
+    pool_load(bth, a);
+    pool_load(brh, b);
+    return uturn_vectors(a, b, fwd);
+  }
 
   __device__ __forceinline__ int materialize_theta() {
     const int b = alloc();
     pool_store(b, th);
+    return b;
+  }
+  // give a symbolic vector (kHot = moving end, kStart = restart registers) a pool buffer
+  __device__ __forceinline__ int materialize(int ref, bool rho) {
+    if (ref >= 0) return ref;
+    const int b = alloc();
+    if (ref == kHot) {
+      pool_store(b, rho ? rh : th);
+    } else {
+      pool_store(b, rho ? rh0 : th0);
+    }
     return b;
   }
 
@@ -566,6 +629,7 @@ struct Traj {
   // walnuts.hpp:682-692)
   // ------------------------------------------------------------------------------------
   __device__ void run(int chain_id) {
+    WN_PHASE(kPhPrologue);
     chain = chain_id;
     err = 0;
     n_grad = 0;
@@ -605,8 +669,7 @@ struct Traj {
       min_micro = uni(static_cast<int>(est > P.cfg_min_micro ? est : P.cfg_min_micro));
     } else {
       vload(P.inv_mass + row, im);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) chol[j] = 1.0 / __builtin_sqrt(im[j]);  // walnuts.hpp:647
+      vload(P.chol_mass + row, chol);  // 1/sqrt(inv_mass), walnuts.hpp:647, computed once at freeze
       step = uni(P.step_size[chain]);
       min_micro = uni(P.min_micro[chain]);
     }
@@ -649,27 +712,34 @@ struct Traj {
     pool_store(a_bk[2], g);
     int a_sel = a_bk[0];
     double a_lj_bk = lj, a_lj_fw = lj, a_logsum = lj, a_lpsel = lp_pos;
-    bool hot_is_fw = true, hot_is_bk = true;  // which accumulated end the VGPR state equals
+    // The VGPR state equals one (initially both) of the accumulated span's ends.  An extended end is
+    // written back to its pool buffers only when the walk turns around (`dirty`), not after every doubling.
+    bool hot_is_fw = true, hot_is_bk = true, dirty = false;
+    auto flush_hot_end = [&]() {
+      int* endp = hot_is_fw ? a_fw : a_bk;
+      const int* other = hot_is_fw ? a_bk : a_fw;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (endp[r] == other[r] || endp[r] == a_sel) endp[r] = alloc_cold();
+      }
+      pool_store(endp[0], th);
+      pool_store(endp[1], rh);
+      pool_store(endp[2], g);
+      dirty = false;
+    };
 
     int depth = 1;
     for (; depth <= P.max_depth; ++depth) {
+      WN_PHASE(kPhDoublingStart);
       const bool fwd = uniform01() < 0.5;  // bernoulli(0.5), walnuts.hpp:552
-      double h_cur;
-      if (fwd) {
-        if (!hot_is_fw) {
-          pool_load(a_fw[0], th);
-          pool_load(a_fw[1], rh);
-          pool_load(a_fw[2], g);
-        }
-        h_cur = a_lj_fw;
-      } else {
-        if (!hot_is_bk) {
-          pool_load(a_bk[0], th);
-          pool_load(a_bk[1], rh);
-          pool_load(a_bk[2], g);
-        }
-        h_cur = a_lj_bk;
+      if (fwd ? !hot_is_fw : !hot_is_bk) {
+        if (dirty) flush_hot_end();
+        const int* e = fwd ? a_fw : a_bk;
+        pool_load(e[0], th);
+        pool_load(e[1], rh);
+        pool_load(e[2], g);
       }
+      double h_cur = fwd ? a_lj_fw : a_lj_bk;
 
       // ---- build_span(depth-1) as a post-order walk over 2^(depth-1) leaves ----
       const int nleaf = 1 << (depth - 1);
@@ -693,12 +763,14 @@ struct Traj {
           --sp;
           const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
           const double s_logsum = uni(meta->logsum[sp]), s_lpsel = uni(meta->lpsel[sp]);
+          WN_PHASE(kPhUturn);
           if (uturn_against(s_in_th, s_in_rh, fwd)) {  // walnuts.hpp:490-492
             ok = false;
             break;
           }
+          WN_PHASE(kPhCombine);
           // combine<Barker> (walnuts.hpp:370-386): old = s, new = c
-          const double total = log_sum_exp(s_logsum, c_logsum);
+          const double total = uni(log_sum_exp(s_logsum, c_logsum));
           const bool update = log_uniform01() < c_logsum - total;
           const int n_sel = update ? c_sel : s_sel;
           const double n_lpsel = update ? c_lpsel : s_lpsel;
@@ -713,17 +785,21 @@ struct Traj {
           c_logsum = total;
         }
         if (!ok) break;
+        WN_PHASE(kPhPush);
         if (i + 1 < nleaf) {
-          // the VGPR state is about to move on: give the span's hot parts a home
-          if (c_in_th == kHot) {
-            c_in_th = materialize_theta();
-            if (c_sel == kHot) c_sel = c_in_th;
+          // the VGPR state is about to move on.  A lone leaf (even i) becomes the next macro step's
+          // restart state, which is exactly where the next leaf's level-0 merge looks for it: nothing to
+          // store.  Anything else gets pool buffers for its symbolic parts.
+          if (START_REGS && c_in_th == kHot) {
+            c_in_th = kStart;
+            c_in_rh = kStart;
+            c_sel = kStart;
+          } else {
+            const bool sel_is_inner = (c_sel == c_in_th);
+            c_in_th = materialize(c_in_th, false);
+            c_in_rh = materialize(c_in_rh, true);
+            c_sel = sel_is_inner ? c_in_th : materialize(c_sel, false);
           }
-          if (c_in_rh == kHot) {
-            c_in_rh = alloc();
-            pool_store(c_in_rh, rh);
-          }
-          if (c_sel == kHot) c_sel = materialize_theta();
           if (lane == 0) {
             meta->in_th[sp] = c_in_th;
             meta->in_rh[sp] = c_in_rh;
@@ -736,31 +812,23 @@ struct Traj {
       }
       if (!ok) break;  // walnuts.hpp:543-545
 
+      WN_PHASE(kPhTopMerge);
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
       const bool turned = fwd ? uturn_against(a_bk[0], a_bk[1], true) : uturn_against(a_fw[0], a_fw[1], false);
-      const double total = log_sum_exp(a_logsum, c_logsum);
+      const double total = uni(log_sum_exp(a_logsum, c_logsum));
       const bool update = log_uniform01() < c_logsum - a_logsum;  // Metropolis
       // the new span's inner end is never read again
-      release_unless(c_in_th, c_sel, -2, -2);
-      release_unless(c_in_rh, -2, -2, -2);
+      release_unless(c_in_th, c_sel, -3, -3);
+      release_unless(c_in_rh, -3, -3, -3);
       if (update) {
-        if (c_sel == kHot) c_sel = materialize_theta();
+        c_sel = materialize(c_sel, false);
         release_unless(a_sel, a_bk[0], a_fw[0], c_sel);
         a_sel = c_sel;
         a_lpsel = c_lpsel;
       } else {
         release(c_sel);
       }
-      // the extended end becomes the VGPR state
-      int* endp = fwd ? a_fw : a_bk;
-      const int* other = fwd ? a_bk : a_fw;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (endp[r] == other[r] || endp[r] == a_sel) endp[r] = alloc_cold();
-      }
-      pool_store(endp[0], th);
-      pool_store(endp[1], rh);
-      pool_store(endp[2], g);
+      // the extended end is now the VGPR state; it reaches the pool only if the walk turns around
       if (fwd) {
         a_lj_fw = h_cur;
         hot_is_fw = true;
@@ -770,10 +838,12 @@ struct Traj {
         hot_is_bk = true;
         hot_is_fw = false;
       }
+      dirty = true;
       a_logsum = total;
       if (turned) break;  // walnuts.hpp:549,556-558
     }
 
+    WN_PHASE(kPhEpilogue);
     // ---- selected state out (walnuts.hpp:560-562) ----
     pool_load(a_sel, th);
     vstore(P.theta + row, th);
@@ -848,7 +918,11 @@ __global__ __launch_bounds__(64 * NW) void transition_kernel(const Params P) {
   double* arena = P.arena + static_cast<long long>(blockIdx.x) * P.arena_stride;
 
   T t(P, pool, meta, red, bcast, arena);
+#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+  t.phase_begin();
+#endif
   for (;;) {
+    WN_PHASE_OUTER(kPhIdle);
     int c;
     if (NW == 1) {
       int mine = 0;
@@ -863,6 +937,9 @@ __global__ __launch_bounds__(64 * NW) void transition_kernel(const Params P) {
     if (c >= P.num_chains) break;
     t.run(c);
   }
+#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+  t.phase_end();
+#endif
 }
 
 inline size_t transition_smem_bytes(int nw, int pool_lds, int dim_padded) {

@@ -89,7 +89,8 @@ typedef struct wn_config {
   double step_stabilization;        /* 1e-4 */
   double step_learn_rate_decay;     /* 0.5 */
   int32_t waves_per_chain;          /* NW: wavefronts cooperating on one chain */
-  int32_t elems_per_lane;           /* EPL: vector elements held per lane */
+  int32_t elems_per_lane;           /* EPL: vector elements held per lane; -1 = streaming kernels (vectors in HBM,
+                                       the default above 8192 parameters) */
   int32_t workgroups_per_cu;        /* resident chains per compute unit */
   int32_t lds_vectors;              /* span-pool vectors kept in LDS (-1: as many as fit) */
 } wn_config;
@@ -153,6 +154,7 @@ WALNUTS_HIP_EXPORT int wn_engine_total_grad_evals(wn_engine* e, int64_t* out, Wa
 /* introspection */
 WALNUTS_HIP_EXPORT int wn_engine_lanes(const wn_engine* e);        /* L = 64*NW: the reduction width   */
 WALNUTS_HIP_EXPORT int wn_engine_dim_padded(const wn_engine* e);   /* Dp                                */
+WALNUTS_HIP_EXPORT int wn_engine_is_streaming(const wn_engine* e); /* 1: vectors streamed from HBM      */
 WALNUTS_HIP_EXPORT int wn_engine_workgroups(const wn_engine* e);   /* persistent grid size              */
 WALNUTS_HIP_EXPORT int wn_engine_lds_vectors(const wn_engine* e);  /* pool vectors resident in LDS      */
 WALNUTS_HIP_EXPORT int64_t wn_engine_iteration(const wn_engine* e);

@@ -24,6 +24,7 @@ def sim():
     ("std_normal", 10, None),          # (1,2): D < one pair per lane, heavy padding
     ("diag_normal", 130, (1, 4)),      # (1,4): restart state parked in the span pool
     ("funnel", 9, (2, 2)),             # two wavefronts: cross-wave reductions, broadcasts, barriers
+    ("diag_normal", 300, (1, -1)),     # streaming backend (vectors in HBM scratch), 3 tiles per lane
 ])
 def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry):
     parity.run_case(model, D, 3, warmup=6, sampling=4, lib_path=sim, geometry=geometry)

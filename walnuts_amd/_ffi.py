@@ -79,6 +79,7 @@ SYMBOLS = [
     ("wn_engine_total_grad_evals", _i32, [_vp, _i64p, _errpp]),
     ("wn_engine_lanes", _i32, [_vp]),
     ("wn_engine_dim_padded", _i32, [_vp]),
+    ("wn_engine_is_streaming", _i32, [_vp]),
     ("wn_engine_workgroups", _i32, [_vp]),
     ("wn_engine_lds_vectors", _i32, [_vp]),
     ("wn_engine_iteration", _i64, [_vp]),

@@ -78,6 +78,7 @@ struct wn_engine {
   int num_cus = 256;
   int grid = 0;
   int pool_lds = 0, pool_total = 0;
+  int64_t arena_stride = 0;  // doubles per persistent workgroup: HBM part of the span pool (+ streaming scratch)
   size_t smem = 0;
   hipStream_t stream = nullptr;
 
@@ -212,7 +213,7 @@ struct wn_engine {
     P.u_buf = u_buf.p;
     P.warmup_iter = warmup_iter;
     P.arena = arena.p;
-    P.arena_stride = static_cast<int64_t>(pool_total - pool_lds) * Dp;
+    P.arena_stride = arena_stride;
     P.pool_lds = pool_lds;
     P.pool_total = pool_total;
     P.work_counter = counter.p;
@@ -266,7 +267,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.cfg = cfg;
   e.device = cfg.device;
   e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane);
-  e.Dp = 64 * e.geo.nw * e.geo.epl;
+  e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, e.device));
@@ -283,6 +284,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   const size_t vec_bytes = sizeof(double) * e.Dp;
   int lds_vecs = budget > fixed + 1024 ? static_cast<int>((budget - fixed - 1024) / vec_bytes) : 0;
   if (cfg.lds_vectors >= 0 && cfg.lds_vectors < lds_vecs) lds_vecs = cfg.lds_vectors;
+  if (e.geo.mem) lds_vecs = 0;  // streaming backend: vectors are far larger than LDS
   e.pool_lds = std::min(lds_vecs, e.pool_total);
   e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds, e.Dp);
   e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(e.num_cus) * wg_per_cu));
@@ -302,7 +304,9 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.grad_evals.alloc(num_chains);
   e.counter.alloc(1);
   e.scratch64.alloc(1);
-  const size_t arena_vecs = static_cast<size_t>(e.pool_total - e.pool_lds);
+  const size_t arena_vecs =
+      static_cast<size_t>(e.pool_total - e.pool_lds) + (e.geo.mem ? wn::kMemScratchVectors : 0);
+  e.arena_stride = static_cast<int64_t>(arena_vecs) * e.Dp;
   e.arena.alloc(std::max<size_t>(1, static_cast<size_t>(e.grid) * arena_vecs * e.Dp));
   e.model_params.alloc(e.Dp);
 
@@ -340,13 +344,15 @@ void run_init(wn_engine& e, bool pos, bool masses, bool step, double scale, doub
   Q.grad_evals = e.grad_evals.p;
   Q.model_params = e.model_params.p;
   Q.z_buf = z_dev;
+  Q.scratch = e.arena.p;
+  Q.scratch_stride = e.arena_stride;
   Q.scale = scale;
   Q.smoothing = smoothing;
   Q.pos_seed = pos_seed;
   Q.step_seed = step_seed;
   Q.pos_chain_offset = pos_off;
   Q.step_chain_offset = step_off;
-  const int grid = static_cast<int>(std::min<size_t>(e.C, static_cast<size_t>(e.num_cus) * 8));
+  const int grid = e.geo.mem ? e.grid : static_cast<int>(std::min<size_t>(e.C, static_cast<size_t>(e.num_cus) * 8));
   wn::launch_init(e.model, e.geo, grid, wn::transition_smem_bytes(e.geo.nw, 0, e.Dp), e.stream, Q);
   HIP_OK(hipGetLastError());
   e.adapters_ready = false;
@@ -576,6 +582,7 @@ int wn_engine_total_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err) 
 }
 
 int wn_engine_lanes(const wn_engine* e) { return 64 * e->geo.nw; }
+int wn_engine_is_streaming(const wn_engine* e) { return e->geo.mem ? 1 : 0; }
 int wn_engine_dim_padded(const wn_engine* e) { return e->Dp; }
 int wn_engine_workgroups(const wn_engine* e) { return e->grid; }
 int wn_engine_lds_vectors(const wn_engine* e) { return e->pool_lds; }

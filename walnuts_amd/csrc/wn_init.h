@@ -19,6 +19,8 @@ struct InitParams {
   int64_t* grad_evals;
   const double* model_params;
   const double* z_buf;  // nullable [C][Dp]: host-generated normals for the step search (exact libstdc++ stream)
+  double* scratch;      // streaming kernels: one Dp-vector per workgroup at scratch + blockIdx*scratch_stride
+  int64_t scratch_stride;
   double scale, smoothing;
   uint64_t pos_seed, step_seed;
   uint32_t pos_chain_offset, step_chain_offset;
@@ -116,6 +118,127 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
       if (t.tid == 0) Q.step_init[chain] = step;
     }
     if (t.tid == 0) Q.grad_evals[chain] += t.n_grad;
+  }
+}
+
+// The same three InitConfigBuilder steps for the streaming backend (vectors in HBM).  leapfrog_error
+// (util.hpp:242-259) is one fused pass per probe: both energies of the probe come out of the same sweep.
+template <class Model, int NW>
+__global__ __launch_bounds__(64 * NW) void init_kernel_mem(const InitParams Q) {
+  WN_DYN_SMEM(smem);
+  using T = TrajMem<Model, NW>;
+  Params P{};
+  P.num_chains = Q.num_chains;
+  P.dim = Q.dim;
+  P.dim_padded = Q.dim_padded;
+  P.model_params = Q.model_params;
+  WN_LDS double* base = (WN_LDS double*)smem;
+  WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(base + (threadIdx.x >> 6) * kMetaDoubles);
+  WN_LDS double* red = base + NW * kMetaDoubles;
+  WN_LDS double* bcast = red + 4 * NW;
+  double* rho0 = Q.scratch + static_cast<long long>(blockIdx.x) * Q.scratch_stride;
+  T t(P, base, meta, red, bcast, rho0);
+  constexpr int L = T::L;
+  const int tiles = Q.dim_padded / (2 * L);
+  typename Model::Aux aux;
+
+  auto load_mp = [&](int o, double (&mp2)[2]) {
+    mp2[0] = mp2[1] = 1.0;
+    if (Model::kUsesParams) {
+      const v2f64 p0 = T::ld(Q.model_params + o);
+      mp2[0] = p0[0];
+      mp2[1] = p0[1];
+    }
+  };
+
+  for (int chain = blockIdx.x; chain < Q.num_chains; chain += gridDim.x) {
+    const long long row = static_cast<long long>(chain) * Q.dim_padded;
+    long long n_grad = 0;
+    if (Q.do_positions) {
+      for (int k = 0; k < tiles; ++k) {
+        const int o = t.pair_offset(k);
+        double z0, z1;
+        wnd::stream_normal_pair(Q.pos_seed, Q.pos_chain_offset + chain, 0u, wnd::kStreamInitPos,
+                                static_cast<uint32_t>(k * L + t.tid), z0, z1);
+        T::st(Q.theta + row + o, o < Q.dim ? z0 * Q.scale : 0.0, o + 1 < Q.dim ? z1 * Q.scale : 0.0);
+      }
+    }
+    if (Q.do_masses) {
+      for (int k = 0; k < tiles; ++k) {
+        const int o = t.pair_offset(k);
+        const v2f64 t0 = T::ld(Q.theta + row + o);
+        double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2];
+        load_mp(o, mp2);
+        typename T::TileCx cx{o, Q.dim};
+        double unused = 0.0;
+        Model::eval(cx, th2, g2, mp2, aux, unused);
+        T::st(Q.mass + row + o, o < Q.dim ? (1 - Q.smoothing) * fabs(g2[0]) + Q.smoothing : 1.0,
+              o + 1 < Q.dim ? (1 - Q.smoothing) * fabs(g2[1]) + Q.smoothing : 1.0);
+      }
+      ++n_grad;
+    }
+    if (Q.do_step) {
+      // momentum rho0 = z .* sqrt(mass) and the energy at the start point (util.hpp:248-249, 289-293)
+      double lp0 = 0.0, ke0 = 0.0;
+      for (int k = 0; k < tiles; ++k) {
+        const int o = t.pair_offset(k);
+        const v2f64 t0 = T::ld(Q.theta + row + o), m0 = T::ld(Q.mass + row + o);
+        double z2[2];
+        if (Q.z_buf != nullptr) {
+          const v2f64 zz = T::ld(Q.z_buf + row + o);
+          z2[0] = zz[0];
+          z2[1] = zz[1];
+        } else {
+          wnd::stream_normal_pair(Q.step_seed, Q.step_chain_offset + chain, 0u, wnd::kStreamInitStep,
+                                  static_cast<uint32_t>(k * L + t.tid), z2[0], z2[1]);
+        }
+        double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2], r2[2];
+        load_mp(o, mp2);
+        typename T::TileCx cx{o, Q.dim};
+        Model::eval(cx, th2, g2, mp2, aux, lp0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          r2[j] = (o + j < Q.dim) ? z2[j] * __builtin_sqrt(m0[j]) : 0.0;
+          ke0 += (1.0 / m0[j]) * (r2[j] * r2[j]);
+        }
+        T::st(rho0 + o, r2[0], r2[1]);
+      }
+      t.sum2(lp0, ke0);
+      const double lj0 = Model::finish(lp0, aux, Q.dim) + (-0.5 * ke0);
+      double step = uni(Q.step_init[chain]);
+      const double log09 = wnd::dlog(0.9), log06 = wnd::dlog(0.6), rt = __builtin_sqrt(0.5);
+      auto leapfrog_error = [&](double h) -> double {
+        double lp1 = 0.0, ke1 = 0.0;
+        for (int k = 0; k < tiles; ++k) {
+          const int o = t.pair_offset(k);
+          const v2f64 t0 = T::ld(Q.theta + row + o), m0 = T::ld(Q.mass + row + o), r0 = T::ld(rho0 + o);
+          double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2], r2[2] = {r0[0], r0[1]}, im2[2];
+          load_mp(o, mp2);
+          typename T::TileCx cx{o, Q.dim};
+          double unused = 0.0;
+          Model::eval(cx, th2, g2, mp2, aux, unused);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            im2[j] = 1.0 / m0[j];
+            r2[j] = r2[j] + 0.5 * h * g2[j];
+            th2[j] = th2[j] + h * (im2[j] * r2[j]);
+          }
+          Model::eval(cx, th2, g2, mp2, aux, lp1);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            r2[j] = r2[j] + 0.5 * h * g2[j];
+            ke1 += im2[j] * (r2[j] * r2[j]);
+          }
+        }
+        n_grad += 2;
+        t.sum2(lp1, ke1);
+        return (Model::finish(lp1, aux, Q.dim) + (-0.5 * ke1)) - lj0;
+      };
+      while (leapfrog_error(step) > log09) step *= 2;
+      while (leapfrog_error(step) < log06) step *= rt;
+      if (t.tid == 0) Q.step_init[chain] = step;
+    }
+    if (t.tid == 0) Q.grad_evals[chain] += n_grad;
   }
 }
 

@@ -13,10 +13,37 @@ struct InitParams;
 
 // NW wavefronts cooperate on one chain, each lane holds EPL elements of every vector:
 // padded dimension Dp = 64*NW*EPL.  START_REGS: the macro step's restart state stays in VGPRs.
+// `mem`: the streaming backend (TrajMem) -- vectors in HBM, any dimension; epl is 0 then.
 struct Geometry {
   int nw, epl;
   bool start_regs;
+  bool mem;
 };
+
+// X(NW) -- wavefronts per chain of the streaming kernels
+#if defined(WN_SIM_GEOMETRIES)
+#define WN_FOR_EACH_MEM_GEOMETRY(X) X(1)
+#elif defined(WN_FAST_BUILD)
+#define WN_FOR_EACH_MEM_GEOMETRY(X) X(4)
+#else
+#define WN_FOR_EACH_MEM_GEOMETRY(X) X(2) X(4) X(8) X(16)
+#endif
+inline bool mem_geometry_exists(int nw) {
+#define WN_X(NW) \
+  if (nw == NW) return true;
+  WN_FOR_EACH_MEM_GEOMETRY(WN_X)
+#undef WN_X
+  return false;
+}
+inline int default_mem_waves() {
+  int best = 0;
+#define WN_X(NW) \
+  if (best == 0 || NW == 16) best = NW; /* measured: 16 waves per chain stream fastest (profiles/) */
+  WN_FOR_EACH_MEM_GEOMETRY(WN_X)
+#undef WN_X
+  return best;
+}
+constexpr int kMaxRegisterDim = 8192;
 
 // X(NW, EPL, START_REGS)
 #if defined(WN_SIM_GEOMETRIES)  // tests/cpusim: small workgroups only; (1,4) exercises the pool-resident restart state
@@ -41,8 +68,15 @@ inline bool geometry_exists(int nw, int epl, bool* start_regs) {
   return false;
 }
 
+// elems_per_lane == -1 requests the streaming backend explicitly (it is the default above kMaxRegisterDim)
 inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
-  Geometry g{0, 0, true};
+  Geometry g{0, 0, true, false};
+  if (epl_req < 0 || (dim > kMaxRegisterDim && epl_req == 0)) {
+    g.mem = true;
+    g.nw = nw_req > 0 ? nw_req : default_mem_waves();
+    if (!mem_geometry_exists(g.nw)) throw std::invalid_argument("unsupported waves_per_chain for the streaming kernels");
+    return g;
+  }
   if (nw_req > 0 && epl_req > 0) {
     if (!geometry_exists(nw_req, epl_req, &g.start_regs) || 64 * nw_req * epl_req < dim)
       throw std::invalid_argument("unsupported waves_per_chain / elems_per_lane for this num_params");
@@ -65,7 +99,7 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
 #define WN_X(NW, EPL, SR)                                  \
   if (64 * NW * EPL >= dim && 64 * NW * EPL < best) {      \
     best = 64 * NW * EPL;                                  \
-    g = Geometry{NW, EPL, SR};                             \
+    g = Geometry{NW, EPL, SR, false};                      \
   }
   WN_FOR_EACH_GEOMETRY(WN_X)
 #undef WN_X
@@ -73,7 +107,15 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
   return g;
 }
 
-inline int default_workgroups_per_cu(const Geometry& g) { return g.nw >= 8 ? 1 : 8 / g.nw; }
+inline int default_workgroups_per_cu(const Geometry& g) {
+  if (g.mem) return g.nw >= 16 ? 1 : 16 / g.nw;  // streaming: latency is hidden by resident waves
+  return g.nw >= 8 ? 1 : 8 / g.nw;
+}
+inline int padded_dim(const Geometry& g, int dim) {
+  const int lanes = 64 * g.nw;
+  if (!g.mem) return lanes * g.epl;
+  return ((dim + 2 * lanes - 1) / (2 * lanes)) * 2 * lanes;
+}
 
 // defined once per model in wn_kernels_<model>.hip
 #define WN_DECLARE_MODEL(tag)                                                                              \

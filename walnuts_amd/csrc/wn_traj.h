@@ -1,5 +1,8 @@
 // wn_traj.h -- the GPU-resident Walnuts transition for one chain per workgroup (gfx950).
 //
+// Layout of this file: device models; TrajBase (the tree logic, shared); TrajReg (vectors in VGPRs, D <= 8192);
+// TrajMem (vectors streamed from HBM, any D); the two persistent kernels.
+//
 // One workgroup of NW wavefronts owns one chain at a time.  Lane l of the
 // workgroup (L = 64*NW lanes) owns the 16-byte element pairs (k*L + l),
 // k = 0..EPL/2-1, of every D-vector of that chain; the moving trajectory end
@@ -115,23 +118,22 @@ __device__ __forceinline__ double log_sum_exp(double x1, double x2) {
 }
 
 // ---- target densities (device form of the LogpGrad contract, concepts.hpp:258-262) ----
-// eval():   writes grad for the lane's elements and returns the lane's partial of
-//           the log-density sum; may reduce internally through cx.
+// eval():   writes grad for the lane's elements and ADDS the lane's log-density terms, in index order,
+//           to `acc` (the running per-lane partial); may reduce internally through cx.
 // finish(): turns the reduced sum into logp.
 struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
   static constexpr int kKind = kStdNormal;
   static constexpr bool kUsesParams = false;
+  static constexpr bool kElementwise = true;
   struct Aux {};
   template <int EPL, class Cx>
-  __device__ __forceinline__ static double eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
-                                                const double (&)[EPL], Aux&) {
-    double p = 0.0;
+  __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
+                                              const double (&)[EPL], Aux&, double& acc) {
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       g[j] = -th[j];
-      p += th[j] * th[j];
+      acc += th[j] * th[j];
     }
-    return p;
   }
   __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return -0.5 * sum; }
 };
@@ -139,17 +141,16 @@ struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
 struct DiagNormalModel {  // examples/examples.cpp:20-31, params = sigma_sq
   static constexpr int kKind = kDiagNormal;
   static constexpr bool kUsesParams = true;
+  static constexpr bool kElementwise = true;
   struct Aux {};
   template <int EPL, class Cx>
-  __device__ __forceinline__ static double eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
-                                                const double (&s2)[EPL], Aux&) {
-    double p = 0.0;
+  __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
+                                              const double (&s2)[EPL], Aux&, double& acc) {
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       g[j] = -th[j] / s2[j];
-      p += -0.5 * th[j] * th[j] / s2[j];
+      acc += -0.5 * th[j] * th[j] / s2[j];
     }
-    return p;
   }
   __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return sum; }
 };
@@ -157,12 +158,13 @@ struct DiagNormalModel {  // examples/examples.cpp:20-31, params = sigma_sq
 struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the reference)
   static constexpr int kKind = kFunnel;
   static constexpr bool kUsesParams = false;
+  static constexpr bool kElementwise = false;  // the gradient needs sum(x^2): register backend only
   struct Aux {
     double v, S, hev;
   };
   template <int EPL, class Cx>
-  __device__ __forceinline__ static double eval(Cx& cx, const double (&th)[EPL], double (&g)[EPL],
-                                                const double (&)[EPL], Aux& aux) {
+  __device__ __forceinline__ static void eval(Cx& cx, const double (&th)[EPL], double (&g)[EPL],
+                                              const double (&)[EPL], Aux& aux, double&) {
     const double v = cx.element0(th[0]);
     double sp = 0.0;
 #pragma unroll
@@ -180,7 +182,6 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
     aux.v = v;
     aux.S = S;
     aux.hev = hev;
-    return 0.0;
   }
   __device__ __forceinline__ static double finish(double, const Aux& a, int D) {
     const double hd = 0.5 * static_cast<double>(D - 1);
@@ -200,14 +201,23 @@ __device__ unsigned long long wn_phase_cycles[kPhCount];
 #define WN_PHASE_OUTER(k) ((void)0)
 #endif
 
-constexpr int kHot = -1;    // "this vector currently lives in the VGPR trajectory end"
-constexpr int kStart = -2;  // "this vector is the macro step's restart state (= the previous leaf), in VGPRs"
+constexpr int kHot = -1;    // "this vector is the moving trajectory end"
+constexpr int kStart = -2;  // "this vector is the macro step's restart state (= the previous leaf)"
 
-template <class Model, int NW, int EPL, bool START_REGS>
-struct Traj {
+// components of the moving end / restart state that can be copied to and from pool buffers
+enum Comp : int { kTh = 0, kRh = 1, kG = 2, kTh0 = 3, kRh0 = 4 };
+
+// ---------------------------------------------------------------------------------------------------
+// TrajBase: everything about a transition that does not touch vector elements -- span bookkeeping, the
+// random-number order, step halving control, Adam, reductions.  `Self` supplies the vector operations:
+//   begin_transition(row, warm) -> first log-density partial     finish_transition(a_sel, row, warm, depth)
+//   leapfrog(h, n) -> partial      energy(partial, lp, lj)        reversible(h, n, lj)
+//   macro_begin() / macro_retry() / macro_commit()
+//   put(b, Comp) / get(b, Comp)    uturn_pool(bth, brh, fwd)      uturn_start(fwd)
+// ---------------------------------------------------------------------------------------------------
+template <class Self, class Model, int NW>
+struct TrajBase {
   static constexpr int L = 64 * NW;
-  static constexpr int NP = EPL / 2;
-  static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   // per-wave scalar scratch in LDS
   struct Meta {
@@ -225,6 +235,40 @@ struct Traj {
     int prof_cur;
 #endif
   };
+  static_assert(sizeof(Meta) <= kMetaDoubles * sizeof(double), "meta scratch too small");
+
+  const Params& P;
+  WN_LDS double* lds_pool;
+  WN_LDS Meta* meta;
+  WN_LDS double* red;  // [2][NW][2] cross-wave reduction scratch
+  WN_LDS double* bcast;
+  double* arena;
+  int tid, lane, wave;
+  int chain;
+  int Dp;
+  unsigned long long free_mask;
+  int red_parity;
+  long long n_grad;
+  int n_draw;
+  int draw_base;  // first tree-draw index held in meta->u / meta->lu (-1: none)
+  int err;
+  double step, max_error;
+  double w_draw0, w_score0;  // estimator weights at entry (read once: another wave's lane 0 rewrites them at exit)
+  int min_micro;
+  typename Model::Aux aux;
+
+  __device__ __forceinline__ Self& self() { return *static_cast<Self*>(this); }
+
+  __device__ __forceinline__ TrajBase(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
+                                      WN_LDS double* bc, double* ar)
+      : P(p), lds_pool(pool), meta(m), red(r), bcast(bc), arena(ar) {
+    tid = threadIdx.x;
+    lane = tid & 63;
+    wave = tid >> 6;
+    Dp = p.dim_padded;
+    red_parity = 0;
+  }
+
 #if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
   __device__ __forceinline__ void phase_mark(int k) {
     const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -247,45 +291,7 @@ struct Traj {
       for (int i = 0; i < kPhCount; ++i) atomicAdd(&wn_phase_cycles[i], meta->prof[i]);
   }
 #endif
-  static_assert(sizeof(Meta) <= kMetaDoubles * sizeof(double), "meta scratch too small");
 
-  const Params& P;
-  WN_LDS double* lds_pool;
-  WN_LDS Meta* meta;
-  WN_LDS double* red;  // [2][NW][2] cross-wave reduction scratch
-  WN_LDS double* bcast;
-  double* arena;
-  int tid, lane, wave;
-  int chain;
-  int Dp;
-
-  double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
-  double th0[EPL], rh0[EPL], g0[EPL];
-  int start_buf[3];
-  unsigned long long free_mask;
-  int red_parity;
-  long long n_grad;
-  int n_draw;
-  int draw_base;        // first tree-draw index held in meta->u / meta->lu (-1: none)
-  int err;
-  double step, max_error;
-  double w_draw0, w_score0;  // estimator weights at entry (read once: another wave's lane 0 rewrites them at exit)
-  int min_micro;
-  typename Model::Aux aux;
-
-  __device__ __forceinline__ Traj(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
-                                  WN_LDS double* bc, double* ar)
-      : P(p), lds_pool(pool), meta(m), red(r), bcast(bc), arena(ar) {
-    tid = threadIdx.x;
-    lane = tid & 63;
-    wave = tid >> 6;
-    Dp = p.dim_padded;
-    red_parity = 0;
-  }
-
-  // ---- model context -----------------------------------------------------------
-  __device__ __forceinline__ int index(int j) const { return ((j >> 1) * L + tid) * 2 + (j & 1); }
-  __device__ __forceinline__ bool valid(int j) const { return index(j) < P.dim; }
   __device__ __forceinline__ int dim() const { return P.dim; }
   __device__ __forceinline__ double element0(double mine) {
     // element 0 is slot 0 of thread 0
@@ -326,6 +332,360 @@ struct Traj {
     sum2(a, b);
     return a;
   }
+
+  // ---- span pool: wave-uniform buffer indices over a 64-bit free mask ---------------------
+  __device__ __forceinline__ int alloc() {
+    if (free_mask == 0ull) {
+      err = 1;
+      return 0;
+    }
+    const int b = uni(__builtin_ctzll(free_mask));
+    free_mask &= free_mask - 1ull;
+    return b;
+  }
+  // long-lived vectors (accumulated span ends) take the highest free buffer so that the LDS-resident low
+  // indices stay available for the short-lived span-stack entries
+  __device__ __forceinline__ int alloc_cold() {
+    if (free_mask == 0ull) {
+      err = 1;
+      return 0;
+    }
+    const int b = uni(63 - __builtin_clzll(free_mask));
+    free_mask &= ~(1ull << b);
+    return b;
+  }
+  __device__ __forceinline__ void release(int b) {
+    if (b >= 0) free_mask |= (1ull << b);
+  }
+  __device__ __forceinline__ void release_unless(int b, int k0, int k1, int k2) {
+    if (b >= 0 && b != k0 && b != k1 && b != k2) free_mask |= (1ull << b);
+  }
+  // give a symbolic vector (kHot = moving end, kStart = restart state) a pool buffer
+  __device__ __forceinline__ int materialize(int ref, bool rho) {
+    if (ref >= 0) return ref;
+    const int b = alloc();
+    if (ref == kHot) {
+      self().put(b, rho ? kRh : kTh);
+    } else {
+      self().put(b, rho ? kRh0 : kTh0);
+    }
+    return b;
+  }
+
+  // ---- randomness (util.hpp:102,112 order; counter-based stream or host-fed variates) ----
+  // The tree consumes wave-uniform scalars one at a time.  They are produced 64 at a time, lane j
+  // computing draw number draw_base + j and its logarithm into the wave's LDS scratch, and handed out with
+  // a broadcast LDS read.  (A v_readlane hand-out from registers was miscompiled by ROCm 7.2's backend:
+  // after a refill the read used the stale register pair; caught by the bit-exact parity tests.)
+  __device__ __forceinline__ void refill_draws(int base) {
+    draw_base = base;
+    const int j = base + lane;
+    double u;
+    if (P.rng_mode == kRngBuffer) {
+      u = j < P.u_stride ? P.u_buf[static_cast<long long>(chain) * P.u_stride + j] : 0.5;
+    } else {
+      u = wnd::stream_uniform(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamTree,
+                              static_cast<uint32_t>(j));
+    }
+    meta->u[lane] = u;
+    meta->lu[lane] = wnd::dlog(u);
+  }
+  __device__ __forceinline__ int next_draw_slot() {
+    const int j = uni(n_draw);
+    ++n_draw;
+    if (draw_base < 0 || j - draw_base >= 64) refill_draws(j & ~63);
+    return j - draw_base;
+  }
+  __device__ __forceinline__ double uniform01() { return uni(meta->u[next_draw_slot()]); }
+  __device__ __forceinline__ double log_uniform01() { return uni(meta->lu[next_draw_slot()]); }
+
+  // adam.hpp:70-86
+  __device__ __forceinline__ void adam_observe(double alpha) {
+    WN_LDS double* a = meta->adam;
+    double theta = a[0], m = a[1], v = a[2], t = a[3], b1p = a[4], b2p = a[5];
+    t += 1;
+    b1p *= P.adam_b1;
+    b2p *= P.adam_b2;
+    const double grad = P.adam_target - alpha;
+    m = P.adam_b1 * m + (1 - P.adam_b1) * grad;
+    v = P.adam_b2 * v + (1 - P.adam_b2) * grad * grad;
+    const double m_hat = m / (1 - b1p);
+    const double v_hat = v / (1 - b2p);
+    const double lr_t = P.adam_lr / wnd::dpow_pos(t, P.adam_decay);
+    const double denom = __builtin_sqrt(v_hat) + P.adam_eps;
+    theta -= lr_t * m_hat / denom;
+    if (lane == 0) {
+      a[0] = theta; a[1] = m; a[2] = v; a[3] = t; a[4] = b1p; a[5] = b2p;
+    }
+  }
+
+  // per-chain tuning parameters of this transition (adaptive_walnuts.hpp:235-245 / walnuts.hpp:686-689)
+  __device__ __forceinline__ void load_tuning(bool warm) {
+    if (warm) {
+      w_draw0 = uni(P.est_weight[2 * chain]);
+      w_score0 = uni(P.est_weight[2 * chain + 1]);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) meta->adam[i] = P.adam[6 * chain + i];
+      }
+      step = uni(wnd::dexp(P.adam[6 * chain]));  // adam.hpp:93
+      // adaptive_walnuts.hpp:152-157
+      const double mean_micro = P.mm_state[2 * chain] / P.mm_state[2 * chain + 1];
+      const long long est = static_cast<long long>(__builtin_round(mean_micro / P.macro_target));
+      min_micro = uni(static_cast<int>(est > P.cfg_min_micro ? est : P.cfg_min_micro));
+    } else {
+      step = uni(P.step_size[chain]);
+      min_micro = uni(P.min_micro[chain]);
+    }
+  }
+  // per-chain scalar results of this transition
+  __device__ __forceinline__ void store_scalars(bool warm, int depth, double lpsel) {
+    if (tid == 0) {
+      if (warm) {
+        const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(P.warmup_iter));
+        P.est_weight[2 * chain] = discount * w_draw0 + 1;
+        P.est_weight[2 * chain + 1] = discount * w_score0 + 1;
+        P.mm_state[2 * chain] += static_cast<double>(1ll << depth);  // observe(1 << depth)
+        P.mm_state[2 * chain + 1] += 1.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) P.adam[6 * chain + i] = meta->adam[i];
+      }
+      P.logp_out[chain] = lpsel;
+      P.depth_out[chain] = err ? -1 : depth;
+      P.grad_evals[chain] += n_grad;
+      P.rng_draws[chain] = n_draw;
+    }
+  }
+
+  // walnuts.hpp:307-345.  In: moving end = span end, logp_start = its joint log density.
+  // Out (on success): moving end = new leaf, restart state = previous leaf.
+  __device__ __forceinline__ bool macro_step(bool fwd, double logp_start, double& logp_pos, double& logp_joint) {
+    WN_PHASE(kPhRestart);
+    self().macro_begin();
+    double h = fwd ? step : -step;
+    int n = min_micro;
+    for (int halvings = 0; halvings < P.max_halvings; ++halvings, n *= 2, h *= 0.5) {
+      if (halvings > 0) self().macro_retry();
+      WN_PHASE(kPhLeapfrog);
+      const double part = self().leapfrog(h, n);
+      WN_PHASE(kPhEnergy);
+      self().energy(part, logp_pos, logp_joint);
+      if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
+        if (P.warmup) adam_observe(wnd::dexp(-fabs(logp_start - logp_joint)));
+      }
+      if (fabs(logp_start - logp_joint) <= max_error) {
+        WN_PHASE(kPhReversible);
+        const bool rev = self().reversible(h, n, logp_joint);
+        if (rev) self().macro_commit();
+        return rev;
+      }
+      WN_PHASE(kPhRestart);
+    }
+    return false;
+  }
+
+  __device__ __forceinline__ bool uturn_against(int bth, int brh, bool fwd) {
+    if (Self::kHasStartState && bth == kStart) return self().uturn_start(fwd);  // the previous leaf
+    return self().uturn_pool(bth, brh, fwd);
+  }
+
+  // ------------------------------------------------------------------------------------
+  // one MCMC transition (walnuts.hpp:520-563 wrapped as adaptive_walnuts.hpp:234-251 or
+  // walnuts.hpp:682-692)
+  // ------------------------------------------------------------------------------------
+  __device__ void run(int chain_id) {
+    WN_PHASE(kPhPrologue);
+    chain = chain_id;
+    err = 0;
+    n_grad = 0;
+    n_draw = 0;
+    draw_base = -1;
+    max_error = P.max_error;
+    free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
+    const long long row = static_cast<long long>(chain) * Dp;
+    const bool warm = P.warmup != 0;
+    load_tuning(warm);
+
+    // momentum refresh + initial point (walnuts.hpp:528-535)
+    double lp_pos, lj;
+    {
+      const double part = self().begin_transition(row, warm);
+      self().energy(part, lp_pos, lj);
+    }
+    int a_bk[3], a_fw[3];
+    a_bk[0] = a_fw[0] = alloc_cold();
+    a_bk[1] = a_fw[1] = alloc_cold();
+    a_bk[2] = a_fw[2] = alloc_cold();
+    self().put(a_bk[0], kTh);
+    self().put(a_bk[1], kRh);
+    self().put(a_bk[2], kG);
+    int a_sel = a_bk[0];
+    double a_lj_bk = lj, a_lj_fw = lj, a_logsum = lj, a_lpsel = lp_pos;
+    // The moving end equals one (initially both) of the accumulated span's ends.  An extended end is
+    // written back to its pool buffers only when the walk turns around (`dirty`), not after every doubling.
+    bool hot_is_fw = true, hot_is_bk = true, dirty = false;
+    auto flush_hot_end = [&]() {
+      int* endp = hot_is_fw ? a_fw : a_bk;
+      const int* other = hot_is_fw ? a_bk : a_fw;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (endp[r] == other[r] || endp[r] == a_sel) endp[r] = alloc_cold();
+      }
+      self().put(endp[0], kTh);
+      self().put(endp[1], kRh);
+      self().put(endp[2], kG);
+      dirty = false;
+    };
+
+    int depth = 1;
+    for (; depth <= P.max_depth; ++depth) {
+      WN_PHASE(kPhDoublingStart);
+      const bool fwd = uniform01() < 0.5;  // bernoulli(0.5), walnuts.hpp:552
+      if (fwd ? !hot_is_fw : !hot_is_bk) {
+        if (dirty) flush_hot_end();
+        const int* e = fwd ? a_fw : a_bk;
+        self().get(e[0], kTh);
+        self().get(e[1], kRh);
+        self().get(e[2], kG);
+      }
+      double h_cur = fwd ? a_lj_fw : a_lj_bk;
+
+      // ---- build_span(depth-1) as a post-order walk over 2^(depth-1) leaves ----
+      const int nleaf = 1 << (depth - 1);
+      int sp = 0;
+      bool ok = true;
+      int c_in_th = kHot, c_in_rh = kHot, c_sel = kHot;
+      double c_logsum = 0.0, c_lpsel = 0.0;
+      for (int i = 0; i < nleaf; ++i) {
+        double leaf_lp, leaf_lj;
+        if (!macro_step(fwd, h_cur, leaf_lp, leaf_lj)) {  // build_leaf, walnuts.hpp:420-442
+          ok = false;
+          break;
+        }
+        h_cur = leaf_lj;
+        c_in_th = kHot;
+        c_in_rh = kHot;
+        c_sel = kHot;
+        c_logsum = leaf_lj;
+        c_lpsel = leaf_lp;
+        for (int l = 0; (i >> l) & 1; ++l) {
+          --sp;
+          const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
+          const double s_logsum = uni(meta->logsum[sp]), s_lpsel = uni(meta->lpsel[sp]);
+          WN_PHASE(kPhUturn);
+          if (uturn_against(s_in_th, s_in_rh, fwd)) {  // walnuts.hpp:490-492
+            ok = false;
+            break;
+          }
+          WN_PHASE(kPhCombine);
+          // combine<Barker> (walnuts.hpp:370-386): old = s, new = c
+          const double total = uni(log_sum_exp(s_logsum, c_logsum));
+          const bool update = log_uniform01() < c_logsum - total;
+          const int n_sel = update ? c_sel : s_sel;
+          const double n_lpsel = update ? c_lpsel : s_lpsel;
+          release_unless(s_sel, s_in_th, s_in_rh, n_sel);
+          release_unless(c_in_th, s_in_th, s_in_rh, n_sel);
+          release_unless(c_in_rh, s_in_th, s_in_rh, n_sel);
+          release_unless(c_sel, s_in_th, s_in_rh, n_sel);
+          c_in_th = s_in_th;
+          c_in_rh = s_in_rh;
+          c_sel = n_sel;
+          c_lpsel = n_lpsel;
+          c_logsum = total;
+        }
+        if (!ok) break;
+        WN_PHASE(kPhPush);
+        if (i + 1 < nleaf) {
+          // the moving end is about to move on.  A lone leaf (even i) becomes the next macro step's
+          // restart state, which is exactly where the next leaf's level-0 merge looks for it: nothing to
+          // store.  Anything else gets pool buffers for its symbolic parts.
+          if (Self::kHasStartState && c_in_th == kHot) {
+            c_in_th = kStart;
+            c_in_rh = kStart;
+            c_sel = kStart;
+          } else {
+            const bool sel_is_inner = (c_sel == c_in_th);
+            c_in_th = materialize(c_in_th, false);
+            c_in_rh = materialize(c_in_rh, true);
+            c_sel = sel_is_inner ? c_in_th : materialize(c_sel, false);
+          }
+          if (lane == 0) {
+            meta->in_th[sp] = c_in_th;
+            meta->in_rh[sp] = c_in_rh;
+            meta->sel[sp] = c_sel;
+            meta->logsum[sp] = c_logsum;
+            meta->lpsel[sp] = c_lpsel;
+          }
+          ++sp;
+        }
+      }
+      if (!ok) break;  // walnuts.hpp:543-545
+
+      WN_PHASE(kPhTopMerge);
+      // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
+      const bool turned = fwd ? uturn_against(a_bk[0], a_bk[1], true) : uturn_against(a_fw[0], a_fw[1], false);
+      const double total = uni(log_sum_exp(a_logsum, c_logsum));
+      const bool update = log_uniform01() < c_logsum - a_logsum;  // Metropolis
+      // the new span's inner end is never read again
+      release_unless(c_in_th, c_sel, -3, -3);
+      release_unless(c_in_rh, -3, -3, -3);
+      if (update) {
+        c_sel = materialize(c_sel, false);
+        release_unless(a_sel, a_bk[0], a_fw[0], c_sel);
+        a_sel = c_sel;
+        a_lpsel = c_lpsel;
+      } else {
+        release(c_sel);
+      }
+      // the extended end is now the moving end; it reaches the pool only if the walk turns around
+      if (fwd) {
+        a_lj_fw = h_cur;
+        hot_is_fw = true;
+        hot_is_bk = false;
+      } else {
+        a_lj_bk = h_cur;
+        hot_is_bk = true;
+        hot_is_fw = false;
+      }
+      dirty = true;
+      a_logsum = total;
+      if (turned) break;  // walnuts.hpp:549,556-558
+    }
+
+    WN_PHASE(kPhEpilogue);
+    // ---- selected state out (walnuts.hpp:560-562), estimator update (adaptive_walnuts.hpp:247-248) ----
+    self().finish_transition(a_sel, row, warm);
+    store_scalars(warm, depth, a_lpsel);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// TrajReg: every vector of the moving end lives in VGPRs (EPL elements per lane), the span pool in LDS +
+// an HBM arena.  A leapfrog micro step touches no memory.
+// ---------------------------------------------------------------------------------------------------
+template <class Model, int NW, int EPL, bool START_REGS>
+struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
+  using Base = TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW>;
+  using typename Base::Meta;
+  using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::chain;
+  using Base::Dp; using Base::aux; using Base::n_grad; using Base::max_error; using Base::min_micro;
+  using Base::w_draw0; using Base::w_score0; using Base::meta;
+  static constexpr int L = Base::L;
+  static constexpr int NP = EPL / 2;
+  static constexpr bool kHasStartState = START_REGS;
+  static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
+
+  double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
+  double th0[EPL], rh0[EPL], g0[EPL];
+  int start_buf[3];
+
+  __device__ __forceinline__ TrajReg(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
+                                     WN_LDS double* bc, double* ar)
+      : Base(p, pool, m, r, bc, ar) {}
+
+  // ---- model context -----------------------------------------------------------
+  __device__ __forceinline__ int index(int j) const { return ((j >> 1) * L + tid) * 2 + (j & 1); }
+  __device__ __forceinline__ bool valid(int j) const { return index(j) < P.dim; }
 
   // ---- vector buffers -------------------------------------------------------------
   __device__ __forceinline__ void vload(const double* base, double (&v)[EPL]) const {
@@ -376,81 +736,36 @@ struct Traj {
       vstore(arena + static_cast<long long>(b - P.pool_lds) * Dp, v);
     }
   }
-  __device__ __forceinline__ int alloc() {
-    if (free_mask == 0ull) {
-      err = 1;
-      return 0;
+  __device__ __forceinline__ void put(int b, Comp c) {
+    switch (c) {
+      case kTh: pool_store(b, th); break;
+      case kRh: pool_store(b, rh); break;
+      case kG: pool_store(b, g); break;
+      case kTh0: pool_store(b, th0); break;
+      default: pool_store(b, rh0); break;
     }
-    const int b = uni(__builtin_ctzll(free_mask));
-    free_mask &= free_mask - 1ull;
-    return b;
   }
-  // long-lived vectors (accumulated span ends, parked states) take the highest free buffer so that the
-  // LDS-resident low indices stay available for the short-lived span-stack entries
-  __device__ __forceinline__ int alloc_cold() {
-    if (free_mask == 0ull) {
-      err = 1;
-      return 0;
+  __device__ __forceinline__ void get(int b, Comp c) {
+    switch (c) {
+      case kTh: pool_load(b, th); break;
+      case kRh: pool_load(b, rh); break;
+      default: pool_load(b, g); break;
     }
-    const int b = uni(63 - __builtin_clzll(free_mask));
-    free_mask &= ~(1ull << b);
-    return b;
   }
-  __device__ __forceinline__ void release(int b) {
-    if (b >= 0) free_mask |= (1ull << b);
-  }
-  __device__ __forceinline__ void release_unless(int b, int k0, int k1, int k2) {
-    if (b >= 0 && b != k0 && b != k1 && b != k2) free_mask |= (1ull << b);
-  }
-
-  // ---- randomness (util.hpp:102,112 order; counter-based stream or host-fed variates) ----
-  // The tree consumes wave-uniform scalars one at a time.  They are produced 64 at a time, lane j
-  // computing draw number draw_base + j and its logarithm into the wave's LDS scratch, and handed out with
-  // a broadcast LDS read.  (A v_readlane hand-out from registers was miscompiled by ROCm 7.2's backend:
-  // after a refill the read used the stale register pair; caught by the bit-exact parity tests.)
-  __device__ __forceinline__ void refill_draws(int base) {
-    draw_base = base;
-    const int j = base + lane;
-    double u;
-    if (P.rng_mode == kRngBuffer) {
-      u = j < P.u_stride ? P.u_buf[static_cast<long long>(chain) * P.u_stride + j] : 0.5;
-    } else {
-      u = wnd::stream_uniform(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamTree,
-                              static_cast<uint32_t>(j));
-    }
-    meta->u[lane] = u;
-    meta->lu[lane] = wnd::dlog(u);
-  }
-  __device__ __forceinline__ int next_draw_slot() {
-    const int j = uni(n_draw);
-    ++n_draw;
-    if (draw_base < 0 || j - draw_base >= 64) refill_draws(j & ~63);
-    return j - draw_base;
-  }
-#if defined(WN_VARIANT_NOCACHE)
-  __device__ __forceinline__ double uniform01() {
-    const int j = n_draw++;
-    if (P.rng_mode == kRngBuffer) return uni(P.u_buf[static_cast<long long>(chain) * P.u_stride + j]);
-    return uni(wnd::stream_uniform(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamTree,
-                                   static_cast<uint32_t>(j)));
-  }
-  __device__ __forceinline__ double log_uniform01() { return wnd::dlog(uniform01()); }
-#else
-  __device__ __forceinline__ double uniform01() { return uni(meta->u[next_draw_slot()]); }
-  __device__ __forceinline__ double log_uniform01() { return uni(meta->lu[next_draw_slot()]); }
-#endif
 
   // ---- Hamiltonian pieces ------------------------------------------------------------
   __device__ __forceinline__ double model_eval() {
     ++n_grad;
-    return Model::eval(*this, th, g, mp, aux);
+    double part = 0.0;
+    Model::eval(*this, th, g, mp, aux, part);
+    return part;
   }
   // joint log density of the moving end: logp_pos + logp_momentum (util.hpp:220-223)
   __device__ __forceinline__ void energy(double lp_partial, double& logp_pos, double& logp_joint) {
     double ke = 0.0;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) ke += im[j] * (rh[j] * rh[j]);
-    sum2(lp_partial, ke);
+    this->sum2(lp_partial, ke);
     // wave-uniform results go back to scalar registers: they live long and would otherwise hold VGPR pairs
     logp_pos = uni(Model::finish(lp_partial, aux, P.dim));
     logp_joint = uni(logp_pos + (-0.5 * ke));
@@ -472,26 +787,6 @@ struct Traj {
     return part;
   }
 
-  // adam.hpp:70-86
-  __device__ __forceinline__ void adam_observe(double alpha) {
-    WN_LDS double* a = meta->adam;
-    double theta = a[0], m = a[1], v = a[2], t = a[3], b1p = a[4], b2p = a[5];
-    t += 1;
-    b1p *= P.adam_b1;
-    b2p *= P.adam_b2;
-    const double grad = P.adam_target - alpha;
-    m = P.adam_b1 * m + (1 - P.adam_b1) * grad;
-    v = P.adam_b2 * v + (1 - P.adam_b2) * grad * grad;
-    const double m_hat = m / (1 - b1p);
-    const double v_hat = v / (1 - b2p);
-    const double lr_t = P.adam_lr / wnd::dpow_pos(t, P.adam_decay);
-    const double denom = __builtin_sqrt(v_hat) + P.adam_eps;
-    theta -= lr_t * m_hat / denom;
-    if (lane == 0) {
-      a[0] = theta; a[1] = m; a[2] = v; a[3] = t; a[4] = b1p; a[5] = b2p;
-    }
-  }
-
   // walnuts.hpp:218-235 on the VGPR state
   __device__ __forceinline__ bool within_tolerance(double h, int n, double logp_entry) {
     const double part = leapfrog(h, n);
@@ -504,7 +799,7 @@ struct Traj {
   // while coarser reverse paths are tried from (theta', -rho', grad').
   __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
     if (n == 1) return true;
-    const int k0 = alloc(), k1 = alloc(), k2 = alloc();  // short-lived: LDS first
+    const int k0 = this->alloc(), k1 = this->alloc(), k2 = this->alloc();  // short-lived: LDS first
     pool_store(k0, th);
     pool_store(k1, rh);
     pool_store(k2, g);
@@ -530,16 +825,14 @@ struct Traj {
     pool_load(k0, th);
     pool_load(k1, rh);
     pool_load(k2, g);
-    release(k0);
-    release(k1);
-    release(k2);
+    this->release(k0);
+    this->release(k1);
+    this->release(k2);
     return result;
   }
 
-  // walnuts.hpp:307-345.  In: VGPR state = span end, logp_start = its joint log
-  // density.  Out (on success): VGPR state = new leaf.
-  __device__ __forceinline__ bool macro_step(bool fwd, double logp_start, double& logp_pos, double& logp_joint) {
-    WN_PHASE(kPhRestart);
+  // the macro step's restart state (walnuts.hpp:324-326)
+  __device__ __forceinline__ void macro_begin() {
     if (START_REGS) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
@@ -552,38 +845,22 @@ struct Traj {
       pool_store(start_buf[1], rh);
       pool_store(start_buf[2], g);
     }
-    double h = fwd ? step : -step;
-    int n = min_micro;
-    for (int halvings = 0; halvings < P.max_halvings; ++halvings, n *= 2, h *= 0.5) {
-      if (halvings > 0) {
-        if (START_REGS) {
-#pragma unroll
-          for (int j = 0; j < EPL; ++j) {
-            th[j] = th0[j];
-            rh[j] = rh0[j];
-            g[j] = g0[j];
-          }
-        } else {
-          pool_load(start_buf[0], th);
-          pool_load(start_buf[1], rh);
-          pool_load(start_buf[2], g);
-        }
-      }
-      WN_PHASE(kPhLeapfrog);
-      const double part = leapfrog(h, n);
-      WN_PHASE(kPhEnergy);
-      energy(part, logp_pos, logp_joint);
-      if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
-        if (P.warmup) adam_observe(wnd::dexp(-fabs(logp_start - logp_joint)));
-      }
-      if (fabs(logp_start - logp_joint) <= max_error) {
-        WN_PHASE(kPhReversible);
-        return reversible(h, n, logp_joint);
-      }
-      WN_PHASE(kPhRestart);
-    }
-    return false;
   }
+  __device__ __forceinline__ void macro_retry() {
+    if (START_REGS) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        th[j] = th0[j];
+        rh[j] = rh0[j];
+        g[j] = g0[j];
+      }
+    } else {
+      pool_load(start_buf[0], th);
+      pool_load(start_buf[1], rh);
+      pool_load(start_buf[2], g);
+    }
+  }
+  __device__ __forceinline__ void macro_commit() {}
 
   // walnuts.hpp:192-201: the VGPR state is the outer end of the newer span; (a, b) = (theta, rho) of
   // the far end it is tested against.
@@ -596,59 +873,24 @@ struct Traj {
       p_hot += rh[j] * sd;
       p_far += b[j] * sd;
     }
-    sum2(p_hot, p_far);
+    this->sum2(p_hot, p_far);
     return p_hot < 0 || p_far < 0;
   }
-  __device__ __forceinline__ bool uturn_against(int bth, int brh, bool fwd) {
-    if (START_REGS && bth == kStart) return uturn_vectors(th0, rh0, fwd);  // the previous leaf, still in VGPRs
+  __device__ __forceinline__ bool uturn_start(bool fwd) { return uturn_vectors(th0, rh0, fwd); }
+  __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
     double a[EPL], b[EPL];
     pool_load(bth, a);
     pool_load(brh, b);
     return uturn_vectors(a, b, fwd);
   }
 
-  __device__ __forceinline__ int materialize_theta() {
-    const int b = alloc();
-    pool_store(b, th);
-    return b;
-  }
-  // give a symbolic vector (kHot = moving end, kStart = restart registers) a pool buffer
-  __device__ __forceinline__ int materialize(int ref, bool rho) {
-    if (ref >= 0) return ref;
-    const int b = alloc();
-    if (ref == kHot) {
-      pool_store(b, rho ? rh : th);
-    } else {
-      pool_store(b, rho ? rh0 : th0);
-    }
-    return b;
-  }
-
-  // ------------------------------------------------------------------------------------
-  // one MCMC transition (walnuts.hpp:520-563 wrapped as adaptive_walnuts.hpp:234-251 or
-  // walnuts.hpp:682-692)
-  // ------------------------------------------------------------------------------------
-  __device__ void run(int chain_id) {
-    WN_PHASE(kPhPrologue);
-    chain = chain_id;
-    err = 0;
-    n_grad = 0;
-    n_draw = 0;
-    draw_base = -1;
-    max_error = P.max_error;
-    free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
-    const long long row = static_cast<long long>(chain) * Dp;
-    const bool warm = P.warmup != 0;
-
+  // load the chain, refresh the momentum (walnuts.hpp:528-529), evaluate the initial point (:532)
+  __device__ __forceinline__ double begin_transition(long long row, bool warm) {
     vload(P.theta + row, th);
     if (Model::kUsesParams) vload(P.model_params, mp);
-
-    // tuning parameters of this transition
     double chol[EPL];
     if (warm) {
       // adaptive_walnuts.hpp:235-236 with MassEstimator::inv_mass_estimate :89-94
-      w_draw0 = uni(P.est_weight[2 * chain]);
-      w_score0 = uni(P.est_weight[2 * chain + 1]);
       const double wd = w_draw0, ws = w_score0;
       double ds[EPL], ss[EPL];
       vload(P.est_draw_ssd + row, ds);
@@ -658,23 +900,10 @@ struct Traj {
         im[j] = __builtin_sqrt((ds[j] / wd) / (ss[j] / ws));
         chol[j] = __builtin_sqrt(1.0 / im[j]);
       }
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) meta->adam[i] = P.adam[6 * chain + i];
-      }
-      step = uni(wnd::dexp(P.adam[6 * chain]));  // adam.hpp:93
-      // adaptive_walnuts.hpp:152-157
-      const double mean_micro = P.mm_state[2 * chain] / P.mm_state[2 * chain + 1];
-      const long long est = static_cast<long long>(__builtin_round(mean_micro / P.macro_target));
-      min_micro = uni(static_cast<int>(est > P.cfg_min_micro ? est : P.cfg_min_micro));
     } else {
       vload(P.inv_mass + row, im);
       vload(P.chol_mass + row, chol);  // 1/sqrt(inv_mass), walnuts.hpp:647, computed once at freeze
-      step = uni(P.step_size[chain]);
-      min_micro = uni(P.min_micro[chain]);
     }
-
-    // momentum refresh rho = chol .* z (walnuts.hpp:528-529)
     if (P.rng_mode == kRngBuffer) {
       double z[EPL];
       vload(P.z_buf + row, z);
@@ -690,161 +919,15 @@ struct Traj {
         rh[2 * k + 1] = valid(2 * k + 1) ? chol[2 * k + 1] * z1 : 0.0;
       }
     }
-
     if (!START_REGS) {
-      start_buf[0] = alloc_cold();
-      start_buf[1] = alloc_cold();
-      start_buf[2] = alloc_cold();
+      start_buf[0] = this->alloc_cold();
+      start_buf[1] = this->alloc_cold();
+      start_buf[2] = this->alloc_cold();
     }
+    return model_eval();
+  }
 
-    // initial point (walnuts.hpp:532-535)
-    double lp_pos, lj;
-    {
-      const double part = model_eval();
-      energy(part, lp_pos, lj);
-    }
-    int a_bk[3], a_fw[3];
-    a_bk[0] = a_fw[0] = alloc_cold();
-    a_bk[1] = a_fw[1] = alloc_cold();
-    a_bk[2] = a_fw[2] = alloc_cold();
-    pool_store(a_bk[0], th);
-    pool_store(a_bk[1], rh);
-    pool_store(a_bk[2], g);
-    int a_sel = a_bk[0];
-    double a_lj_bk = lj, a_lj_fw = lj, a_logsum = lj, a_lpsel = lp_pos;
-    // The VGPR state equals one (initially both) of the accumulated span's ends.  An extended end is
-    // written back to its pool buffers only when the walk turns around (`dirty`), not after every doubling.
-    bool hot_is_fw = true, hot_is_bk = true, dirty = false;
-    auto flush_hot_end = [&]() {
-      int* endp = hot_is_fw ? a_fw : a_bk;
-      const int* other = hot_is_fw ? a_bk : a_fw;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (endp[r] == other[r] || endp[r] == a_sel) endp[r] = alloc_cold();
-      }
-      pool_store(endp[0], th);
-      pool_store(endp[1], rh);
-      pool_store(endp[2], g);
-      dirty = false;
-    };
-
-    int depth = 1;
-    for (; depth <= P.max_depth; ++depth) {
-      WN_PHASE(kPhDoublingStart);
-      const bool fwd = uniform01() < 0.5;  // bernoulli(0.5), walnuts.hpp:552
-      if (fwd ? !hot_is_fw : !hot_is_bk) {
-        if (dirty) flush_hot_end();
-        const int* e = fwd ? a_fw : a_bk;
-        pool_load(e[0], th);
-        pool_load(e[1], rh);
-        pool_load(e[2], g);
-      }
-      double h_cur = fwd ? a_lj_fw : a_lj_bk;
-
-      // ---- build_span(depth-1) as a post-order walk over 2^(depth-1) leaves ----
-      const int nleaf = 1 << (depth - 1);
-      int sp = 0;
-      bool ok = true;
-      int c_in_th = kHot, c_in_rh = kHot, c_sel = kHot;
-      double c_logsum = 0.0, c_lpsel = 0.0;
-      for (int i = 0; i < nleaf; ++i) {
-        double leaf_lp, leaf_lj;
-        if (!macro_step(fwd, h_cur, leaf_lp, leaf_lj)) {  // build_leaf, walnuts.hpp:420-442
-          ok = false;
-          break;
-        }
-        h_cur = leaf_lj;
-        c_in_th = kHot;
-        c_in_rh = kHot;
-        c_sel = kHot;
-        c_logsum = leaf_lj;
-        c_lpsel = leaf_lp;
-        for (int l = 0; (i >> l) & 1; ++l) {
-          --sp;
-          const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
-          const double s_logsum = uni(meta->logsum[sp]), s_lpsel = uni(meta->lpsel[sp]);
-          WN_PHASE(kPhUturn);
-          if (uturn_against(s_in_th, s_in_rh, fwd)) {  // walnuts.hpp:490-492
-            ok = false;
-            break;
-          }
-          WN_PHASE(kPhCombine);
-          // combine<Barker> (walnuts.hpp:370-386): old = s, new = c
-          const double total = uni(log_sum_exp(s_logsum, c_logsum));
-          const bool update = log_uniform01() < c_logsum - total;
-          const int n_sel = update ? c_sel : s_sel;
-          const double n_lpsel = update ? c_lpsel : s_lpsel;
-          release_unless(s_sel, s_in_th, s_in_rh, n_sel);
-          release_unless(c_in_th, s_in_th, s_in_rh, n_sel);
-          release_unless(c_in_rh, s_in_th, s_in_rh, n_sel);
-          release_unless(c_sel, s_in_th, s_in_rh, n_sel);
-          c_in_th = s_in_th;
-          c_in_rh = s_in_rh;
-          c_sel = n_sel;
-          c_lpsel = n_lpsel;
-          c_logsum = total;
-        }
-        if (!ok) break;
-        WN_PHASE(kPhPush);
-        if (i + 1 < nleaf) {
-          // the VGPR state is about to move on.  A lone leaf (even i) becomes the next macro step's
-          // restart state, which is exactly where the next leaf's level-0 merge looks for it: nothing to
-          // store.  Anything else gets pool buffers for its symbolic parts.
-          if (START_REGS && c_in_th == kHot) {
-            c_in_th = kStart;
-            c_in_rh = kStart;
-            c_sel = kStart;
-          } else {
-            const bool sel_is_inner = (c_sel == c_in_th);
-            c_in_th = materialize(c_in_th, false);
-            c_in_rh = materialize(c_in_rh, true);
-            c_sel = sel_is_inner ? c_in_th : materialize(c_sel, false);
-          }
-          if (lane == 0) {
-            meta->in_th[sp] = c_in_th;
-            meta->in_rh[sp] = c_in_rh;
-            meta->sel[sp] = c_sel;
-            meta->logsum[sp] = c_logsum;
-            meta->lpsel[sp] = c_lpsel;
-          }
-          ++sp;
-        }
-      }
-      if (!ok) break;  // walnuts.hpp:543-545
-
-      WN_PHASE(kPhTopMerge);
-      // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
-      const bool turned = fwd ? uturn_against(a_bk[0], a_bk[1], true) : uturn_against(a_fw[0], a_fw[1], false);
-      const double total = uni(log_sum_exp(a_logsum, c_logsum));
-      const bool update = log_uniform01() < c_logsum - a_logsum;  // Metropolis
-      // the new span's inner end is never read again
-      release_unless(c_in_th, c_sel, -3, -3);
-      release_unless(c_in_rh, -3, -3, -3);
-      if (update) {
-        c_sel = materialize(c_sel, false);
-        release_unless(a_sel, a_bk[0], a_fw[0], c_sel);
-        a_sel = c_sel;
-        a_lpsel = c_lpsel;
-      } else {
-        release(c_sel);
-      }
-      // the extended end is now the VGPR state; it reaches the pool only if the walk turns around
-      if (fwd) {
-        a_lj_fw = h_cur;
-        hot_is_fw = true;
-        hot_is_bk = false;
-      } else {
-        a_lj_bk = h_cur;
-        hot_is_bk = true;
-        hot_is_fw = false;
-      }
-      dirty = true;
-      a_logsum = total;
-      if (turned) break;  // walnuts.hpp:549,556-558
-    }
-
-    WN_PHASE(kPhEpilogue);
-    // ---- selected state out (walnuts.hpp:560-562) ----
+  __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
     pool_load(a_sel, th);
     vstore(P.theta + row, th);
     if (P.draws_out != nullptr) {
@@ -882,32 +965,278 @@ struct Traj {
       }
       vstore(P.est_score_mean + row, mean);
       vstore(P.est_score_ssd + row, ssd);
-      if (tid == 0) {
-        P.est_weight[2 * chain] = wd;
-        P.est_weight[2 * chain + 1] = ws;
-        P.mm_state[2 * chain] += static_cast<double>(1ll << depth);  // observe(1 << depth)
-        P.mm_state[2 * chain + 1] += 1.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) P.adam[6 * chain + i] = meta->adam[i];
-      }
-    }
-    if (tid == 0) {
-      P.logp_out[chain] = a_lpsel;
-      P.depth_out[chain] = err ? -1 : depth;
-      P.grad_evals[chain] += n_grad;
-      P.rng_draws[chain] = n_draw;
     }
   }
 };
 
+// ---------------------------------------------------------------------------------------------------
+// TrajMem: the large-D backend.  Vectors do not fit on chip, so the moving end lives in a per-workgroup
+// HBM scratch and every operation is a coalesced streaming pass over 16-byte pairs.  Two state sets
+// (cur, alt) ping-pong: the first micro step of a macro step reads `cur` and writes `alt`, so the restart
+// state (walnuts.hpp:324-326) is never copied and a halving retry costs nothing extra; a micro step is
+// one fused pass reading theta, rho, grad, inv_mass and writing theta, rho, grad -- exactly the
+// algorithmic 56*D bytes.  Only models whose gradient is element-wise are supported here.
+// ---------------------------------------------------------------------------------------------------
+template <class Model, int NW>
+struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
+  using Base = TrajBase<TrajMem<Model, NW>, Model, NW>;
+  using typename Base::Meta;
+  using Base::P; using Base::arena; using Base::tid; using Base::chain; using Base::Dp; using Base::aux;
+  using Base::n_grad; using Base::max_error; using Base::min_micro; using Base::w_draw0; using Base::w_score0;
+  static constexpr int L = Base::L;
+  static constexpr bool kHasStartState = true;
+  static_assert(Model::kElementwise, "the streaming backend needs an element-wise gradient");
+
+  double* cur[3];   // theta, rho, grad of the moving end
+  double* alt[3];   // the other set: output of the running macro step / the previous leaf after commit
+  double* work[3];  // reversibility re-integration (the reference's scratch vectors, walnuts.hpp:264-266)
+  double* im_buf;   // warmup: this transition's inverse mass
+  const double* im; // inverse mass row in force
+  double ke_part;   // kinetic partial of the state produced by the last pass
+  int tiles;        // pairs per lane
+
+  __device__ __forceinline__ TrajMem(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
+                                     WN_LDS double* bc, double* ar)
+      : Base(p, pool, m, r, bc, ar) {
+    // scratch follows the pool buffers in this workgroup's arena slice
+    double* s = ar + static_cast<long long>(p.pool_total - p.pool_lds) * p.dim_padded;
+    for (int i = 0; i < 3; ++i) {
+      cur[i] = s + static_cast<long long>(i) * p.dim_padded;
+      alt[i] = s + static_cast<long long>(3 + i) * p.dim_padded;
+      work[i] = s + static_cast<long long>(6 + i) * p.dim_padded;
+    }
+    im_buf = s + 9ll * p.dim_padded;
+    im = im_buf;
+    ke_part = 0.0;
+    tiles = p.dim_padded / (2 * L);
+  }
+
+  struct TileCx {  // model context of one 2-element tile
+    int base, D;
+    __device__ __forceinline__ int index(int j) const { return base + j; }
+    __device__ __forceinline__ bool valid(int j) const { return base + j < D; }
+    __device__ __forceinline__ int dim() const { return D; }
+  };
+  __device__ __forceinline__ int pair_offset(int k) const { return (k * L + tid) * 2; }
+  __device__ __forceinline__ static v2f64 ld(const double* p) { return *reinterpret_cast<const v2f64*>(p); }
+  __device__ __forceinline__ static void st(double* p, double a, double b) {
+    v2f64 t;
+    t[0] = a;
+    t[1] = b;
+    *reinterpret_cast<v2f64*>(p) = t;
+  }
+  __device__ __forceinline__ double* pool_ptr(int b) const { return arena + static_cast<long long>(b) * Dp; }
+  __device__ __forceinline__ void copy(double* dst, const double* src) const {
+    for (int k = 0; k < tiles; ++k) {
+      const int o = pair_offset(k);
+      const v2f64 t = ld(src + o);
+      st(dst + o, t[0], t[1]);
+    }
+  }
+  __device__ __forceinline__ void put(int b, Comp c) {
+    const double* src = c == kTh ? cur[0] : c == kRh ? cur[1] : c == kG ? cur[2] : c == kTh0 ? alt[0] : alt[1];
+    copy(pool_ptr(b), src);
+  }
+  __device__ __forceinline__ void get(int b, Comp c) { copy(cur[c == kTh ? 0 : c == kRh ? 1 : 2], pool_ptr(b)); }
+
+  // n micro steps (walnuts.hpp:328-333): the first reads `src` (rho negated for the reversibility check)
+  // and writes `dst`, the rest run in place on `dst`.  Returns the log-density partial and leaves the kinetic
+  // partial of the final state in ke_part.
+  __device__ __forceinline__ double leapfrog_sets(double* const* src, double* const* dst, bool negate, double h,
+                                                  int n) {
+    const double half = 0.5 * h;
+    double part = 0.0, ke = 0.0;
+    for (int s = 0; s < n; ++s) {
+      double* const* in = (s == 0) ? src : dst;
+      const bool neg = negate && s == 0;
+      part = 0.0;
+      ke = 0.0;
+      for (int k = 0; k < tiles; ++k) {
+        const int o = pair_offset(k);
+        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), g0 = ld(in[2] + o), m0 = ld(im + o);
+        double th2[2] = {t0[0], t0[1]}, rh2[2] = {neg ? -r0[0] : r0[0], neg ? -r0[1] : r0[1]};
+        double g2[2] = {g0[0], g0[1]}, mp2[2] = {1.0, 1.0};
+        if (Model::kUsesParams) {
+          const v2f64 p0 = ld(P.model_params + o);
+          mp2[0] = p0[0];
+          mp2[1] = p0[1];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rh2[j] += half * g2[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) th2[j] += h * m0[j] * rh2[j];
+        TileCx cx{o, P.dim};
+        Model::eval(cx, th2, g2, mp2, aux, part);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rh2[j] += half * g2[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ke += m0[j] * (rh2[j] * rh2[j]);
+        st(dst[0] + o, th2[0], th2[1]);
+        st(dst[1] + o, rh2[0], rh2[1]);
+        st(dst[2] + o, g2[0], g2[1]);
+      }
+      ++n_grad;
+    }
+    ke_part = ke;
+    return part;
+  }
+  __device__ __forceinline__ double leapfrog(double h, int n) { return leapfrog_sets(cur, alt, false, h, n); }
+  __device__ __forceinline__ void energy(double lp_partial, double& logp_pos, double& logp_joint) {
+    double ke = ke_part;
+    this->sum2(lp_partial, ke);
+    logp_pos = uni(Model::finish(lp_partial, aux, P.dim));
+    logp_joint = uni(logp_pos + (-0.5 * ke));
+  }
+  __device__ __forceinline__ void macro_begin() {}
+  __device__ __forceinline__ void macro_retry() {}
+  __device__ __forceinline__ void macro_commit() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double* t = cur[i];
+      cur[i] = alt[i];
+      alt[i] = t;
+    }
+  }
+  // walnuts.hpp:254-279: coarser reverse paths from (theta', -rho', grad') = the candidate in `alt`
+  __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
+    if (n == 1) return true;
+    while (n >= 2 * min_micro) {
+      n /= 2;
+      h *= 2;
+      const double part = leapfrog_sets(alt, work, true, h, n);
+      double lp, lj;
+      energy(part, lp, lj);
+      if (fabs(lj - logp_joint) <= max_error) return false;
+    }
+    return true;
+  }
+
+  // walnuts.hpp:192-201 against the far end (a, b) = (theta, rho)
+  __device__ __forceinline__ bool uturn_ptrs(const double* a, const double* b, bool fwd) {
+    double p_hot = 0.0, p_far = 0.0;
+    for (int k = 0; k < tiles; ++k) {
+      const int o = pair_offset(k);
+      const v2f64 t = ld(cur[0] + o), r = ld(cur[1] + o), m = ld(im + o), av = ld(a + o), bv = ld(b + o);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const double diff = fwd ? (t[j] - av[j]) : (av[j] - t[j]);
+        const double sd = m[j] * diff;
+        p_hot += r[j] * sd;
+        p_far += bv[j] * sd;
+      }
+    }
+    this->sum2(p_hot, p_far);
+    return p_hot < 0 || p_far < 0;
+  }
+  __device__ __forceinline__ bool uturn_start(bool fwd) { return uturn_ptrs(alt[0], alt[1], fwd); }
+  __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
+    return uturn_ptrs(pool_ptr(bth), pool_ptr(brh), fwd);
+  }
+
+  __device__ __forceinline__ double begin_transition(long long row, bool warm) {
+    const double wd = w_draw0, ws = w_score0;
+    im = warm ? im_buf : P.inv_mass + row;
+    double part = 0.0, ke = 0.0;
+    for (int k = 0; k < tiles; ++k) {
+      const int o = pair_offset(k);
+      const v2f64 t0 = ld(P.theta + row + o);
+      double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2] = {1.0, 1.0}, m2[2], ch2[2], z2[2];
+      if (Model::kUsesParams) {
+        const v2f64 p0 = ld(P.model_params + o);
+        mp2[0] = p0[0];
+        mp2[1] = p0[1];
+      }
+      if (warm) {  // adaptive_walnuts.hpp:235-236, :89-94
+        const v2f64 ds = ld(P.est_draw_ssd + row + o), ss = ld(P.est_score_ssd + row + o);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          m2[j] = __builtin_sqrt((ds[j] / wd) / (ss[j] / ws));
+          ch2[j] = __builtin_sqrt(1.0 / m2[j]);
+        }
+        st(im_buf + o, m2[0], m2[1]);
+      } else {
+        const v2f64 m0 = ld(P.inv_mass + row + o), c0 = ld(P.chol_mass + row + o);
+        m2[0] = m0[0]; m2[1] = m0[1];
+        ch2[0] = c0[0]; ch2[1] = c0[1];
+      }
+      if (P.rng_mode == kRngBuffer) {
+        const v2f64 z0 = ld(P.z_buf + row + o);
+        z2[0] = z0[0];
+        z2[1] = z0[1];
+      } else {
+        wnd::stream_normal_pair(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamMomentum,
+                                static_cast<uint32_t>(k * L + tid), z2[0], z2[1]);
+      }
+      double rh2[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rh2[j] = (o + j < P.dim) ? ch2[j] * z2[j] : 0.0;
+      TileCx cx{o, P.dim};
+      Model::eval(cx, th2, g2, mp2, aux, part);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ke += m2[j] * (rh2[j] * rh2[j]);
+      st(cur[0] + o, th2[0], th2[1]);
+      st(cur[1] + o, rh2[0], rh2[1]);
+      st(cur[2] + o, g2[0], g2[1]);
+    }
+    ++n_grad;
+    ke_part = ke;
+    return part;
+  }
+
+  __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
+    const double* sel = pool_ptr(a_sel);
+    const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(P.warmup_iter));
+    const double wd = discount * w_draw0 + 1, ws = discount * w_score0 + 1;
+    for (int k = 0; k < tiles; ++k) {
+      const int o = pair_offset(k);
+      const v2f64 t0 = ld(sel + o);
+      st(P.theta + row + o, t0[0], t0[1]);
+      if (P.draws_out != nullptr) {
+        double* out = P.draws_out + static_cast<long long>(chain) * P.draws_stride;
+        if (o < P.dim) out[o] = t0[0];
+        if (o + 1 < P.dim) out[o + 1] = t0[1];
+      }
+      if (warm) {  // adaptive_walnuts.hpp:247-248, online_moments.hpp:184-191
+        double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2] = {1.0, 1.0};
+        if (Model::kUsesParams) {
+          const v2f64 p0 = ld(P.model_params + o);
+          mp2[0] = p0[0];
+          mp2[1] = p0[1];
+        }
+        TileCx cx{o, P.dim};
+        double unused = 0.0;
+        Model::eval(cx, th2, g2, mp2, aux, unused);
+        v2f64 mean = ld(P.est_draw_mean + row + o), ssd = ld(P.est_draw_ssd + row + o);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          mean[j] += (th2[j] - mean[j]) / wd;
+          ssd[j] = discount * ssd[j] + (th2[j] - mean[j]) * (th2[j] - mean[j]);
+        }
+        st(P.est_draw_mean + row + o, mean[0], mean[1]);
+        st(P.est_draw_ssd + row + o, ssd[0], ssd[1]);
+        mean = ld(P.est_score_mean + row + o);
+        ssd = ld(P.est_score_ssd + row + o);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          mean[j] += (g2[j] - mean[j]) / ws;
+          ssd[j] = discount * ssd[j] + (g2[j] - mean[j]) * (g2[j] - mean[j]);
+        }
+        st(P.est_score_mean + row + o, mean[0], mean[1]);
+        st(P.est_score_ssd + row + o, ssd[0], ssd[1]);
+      }
+    }
+  }
+};
+
+constexpr int kMemScratchVectors = 10;  // TrajMem: cur 3 + alt 3 + work 3 + inverse mass 1
+
 // ---------------------------------------------------------------------------------------
-// persistent kernel: workgroups pull chains from a shared counter (work per transition
+// persistent kernels: workgroups pull chains from a shared counter (work per transition
 // varies 5..200+ gradient evaluations)
 // ---------------------------------------------------------------------------------------
-template <class Model, int NW, int EPL, bool START_REGS>
-__global__ __launch_bounds__(64 * NW) void transition_kernel(const Params P) {
+template <class T, int NW>
+__device__ __forceinline__ void persistent_loop(const Params& P) {
   WN_DYN_SMEM(smem);
-  using T = Traj<Model, NW, EPL, START_REGS>;
   // layout: [pool_lds * Dp] vectors | per-wave Meta | reduction scratch | broadcast word
   WN_LDS double* pool = (WN_LDS double*)smem;
   WN_LDS double* tail = pool + P.pool_lds * P.dim_padded;
@@ -941,6 +1270,20 @@ __global__ __launch_bounds__(64 * NW) void transition_kernel(const Params P) {
   t.phase_end();
 #endif
 }
+
+template <class Model, int NW, int EPL, bool START_REGS>
+__global__ __launch_bounds__(64 * NW) void transition_kernel(const Params P) {
+  persistent_loop<TrajReg<Model, NW, EPL, START_REGS>, NW>(P);
+}
+
+template <class Model, int NW>
+__global__ __launch_bounds__(64 * NW) void transition_kernel_mem(const Params P) {
+  persistent_loop<TrajMem<Model, NW>, NW>(P);
+}
+
+// kept as an alias: the init kernels build on the register backend
+template <class Model, int NW, int EPL, bool START_REGS>
+using Traj = TrajReg<Model, NW, EPL, START_REGS>;
 
 inline size_t transition_smem_bytes(int nw, int pool_lds, int dim_padded) {
   return (static_cast<size_t>(pool_lds) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + 4 * nw + 2) *

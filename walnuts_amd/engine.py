@@ -180,6 +180,10 @@ class DeviceEngine:
         return self.lib.wn_engine_dim_padded(self.h)
 
     @property
+    def streaming(self) -> bool:
+        return bool(self.lib.wn_engine_is_streaming(self.h))
+
+    @property
     def workgroups(self) -> int:
         return self.lib.wn_engine_workgroups(self.h)
 

@@ -151,6 +151,18 @@ WALNUTS_HIP_EXPORT int wn_engine_get_estimator(wn_engine* e, double* draw_mean, 
 /* sum over chains of gradient evaluations so far (device-side reduction) */
 WALNUTS_HIP_EXPORT int wn_engine_total_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err);
 
+/* cross-chain monitors = the reference's controller loops, evaluated on the device.
+ * wn_engine_rhat: sqrt(1 + var(chain lp means) / mean(chain lp sample variances)) over the sampling draws so far
+ *   (sampler.hpp:132-145, WelfordAccumulator online_moments.hpp:22-86); _lp_sums/_lp_sq_dev are its two
+ *   reduction stages for callers that all-reduce across GPUs in between.
+ * wn_engine_warmup_spread: max over chains of the relative distance of the step size / of the mass vector from
+ *   their geometric means over chains (adapt.hpp:193-221). */
+WALNUTS_HIP_EXPORT int wn_engine_rhat(wn_engine* e, double* rhat, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_lp_sums(wn_engine* e, double* out3, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_lp_sq_dev(wn_engine* e, double mean_of_means, double* out1, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_warmup_spread(wn_engine* e, double* max_rel_diff_step, double* max_rel_diff_mass,
+                                               WalnutpyError** err);
+
 /* introspection */
 WALNUTS_HIP_EXPORT int wn_engine_lanes(const wn_engine* e);        /* L = 64*NW: the reduction width   */
 WALNUTS_HIP_EXPORT int wn_engine_dim_padded(const wn_engine* e);   /* Dp                                */

@@ -567,6 +567,17 @@ struct Chain {
   std::mt19937_64 eng64;
   std::mt19937 eng32;
   std::vector<TraceRec> trace;
+  // WelfordAccumulator of the sampling log densities (online_moments.hpp:22-86, sampler.hpp:87-88)
+  double lp_n = 0, lp_mean = 0, lp_m2 = 0;
+  void observe_lp(double x) {
+    lp_n += 1;
+    const double delta = x - lp_mean;
+    lp_mean += delta / lp_n;
+    lp_m2 += delta * (x - lp_mean);
+  }
+  double lp_sample_variance() const {
+    return lp_n > 1 ? lp_m2 / (lp_n - 1) : std::numeric_limits<double>::quiet_NaN();
+  }
 };
 
 }  // namespace
@@ -666,6 +677,7 @@ struct wno_engine {
                ch.grad_sel, ch.logp);
     ch.grad_evals += c.grad_evals;
     ch.last_scalar_draws = lease.r->scalar_draws;
+    ch.observe_lp(ch.logp);
     ++ch.transitions;
   }
 
@@ -939,6 +951,58 @@ void wno_get_adam(const wno_engine* e, double* out) {
   }
 }
 int64_t wno_iteration(const wno_engine* e) { return e->iteration; }
+
+// sampler.hpp:132-145 with util.hpp:401-404 (variance) on the per-chain Welford statistics
+double wno_rhat(const wno_engine* e) {
+  const size_t M = e->C;
+  double mean_of_means = 0, mean_of_vars = 0;
+  for (const auto& ch : e->chains) {
+    mean_of_means += ch.lp_mean;
+    mean_of_vars += ch.lp_sample_variance();
+  }
+  mean_of_means /= static_cast<double>(M);
+  mean_of_vars /= static_cast<double>(M);
+  double ss = 0;
+  for (const auto& ch : e->chains) ss += (ch.lp_mean - mean_of_means) * (ch.lp_mean - mean_of_means);
+  const double variance_of_means = ss / static_cast<double>(M - 1);
+  return std::sqrt(1 + variance_of_means / mean_of_vars);
+}
+
+// adapt.hpp:193-221: max over chains of l2_rel_diff(mass_m, geom_mean_mass) and of the step's relative distance
+void wno_warmup_spread(wno_engine* e, double* max_rel_step, double* max_rel_mass) {
+  e->ensure_adapters();
+  const size_t M = e->C, D = e->D;
+  Vec mean_log_mass(D, 0.0), im(D);
+  double mean_log_step = 0;
+  std::vector<Vec> mass(M, Vec(D));
+  std::vector<double> log_step(M);
+  for (size_t m = 0; m < M; ++m) {
+    auto& ch = e->chains[m];
+    log_step[m] = std::log(ch.adam.step_size());  // log_step_size(), adaptive_walnuts.hpp:311
+    ch.est.inv_mass(im.data());
+    for (size_t d = 0; d < D; ++d) {
+      const double lm = -std::log(im[d]);  // log_mass(), adaptive_walnuts.hpp:319-323
+      mean_log_mass[d] += lm;
+      mass[m][d] = std::exp(lm);           // adapt.hpp:141
+    }
+    mean_log_step += log_step[m];
+  }
+  mean_log_step /= static_cast<double>(M);
+  for (size_t d = 0; d < D; ++d) mean_log_mass[d] = std::exp(mean_log_mass[d] / static_cast<double>(M));
+  const double gms = std::exp(mean_log_step);
+  double rm = 0, rs = 0;
+  for (size_t m = 0; m < M; ++m) {
+    double ss = 0;
+    for (size_t d = 0; d < D; ++d) {
+      const double r = (mass[m][d] - mean_log_mass[d]) / mean_log_mass[d];
+      ss += r * r;
+    }
+    rm = std::fmax(rm, std::sqrt(ss));
+    rs = std::fmax(rs, (std::exp(log_step[m]) - gms) / gms);
+  }
+  *max_rel_step = rs;
+  *max_rel_mass = rm;
+}
 
 void wno_enable_trace(wno_engine* e, int on) { e->trace_on = on != 0; }
 size_t wno_get_trace(const wno_engine* e, size_t chain, double* out, size_t max_rec) {

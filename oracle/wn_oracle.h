@@ -108,6 +108,10 @@ void wno_get_estimator(const wno_engine* e, double* draw_mean, double* draw_ssd,
                        double* score_ssd, double* weights /*[C*2]*/);
 void wno_get_adam(const wno_engine* e, double* out /*[C*6]: theta,m,v,t,b1pow,b2pow*/);
 int64_t wno_iteration(const wno_engine* e);
+/* the reference's controller statistics: R-hat of the log density over the sampling draws so far
+ * (sampler.hpp:132-145) and the warmup spread of step size / mass across chains (adapt.hpp:193-221) */
+double wno_rhat(const wno_engine* e);
+void wno_warmup_spread(wno_engine* e, double* max_rel_step, double* max_rel_mass);
 
 /* ---- per-macro-step trace of the LAST transition of one chain ------------ */
 /* record layout (doubles): [dir, level, n_micro, step, H_start, H_end, accepted,

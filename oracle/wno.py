@@ -88,6 +88,9 @@ def lib():
     L.wno_get_estimator.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.wno_iteration.restype = i64
     L.wno_iteration.argtypes = [vp]
+    L.wno_rhat.restype = dbl
+    L.wno_rhat.argtypes = [vp]
+    L.wno_warmup_spread.argtypes = [vp, _dp, _dp]
     L.wno_enable_trace.argtypes = [vp, i32]
     L.wno_get_trace.restype = sz
     L.wno_get_trace.argtypes = [vp, sz, _dp, sz]
@@ -236,6 +239,14 @@ class Engine:
         w = np.empty((self.C, 2))
         self.L.wno_get_estimator(self.h, _p(dm), _p(ds), _p(sm), _p(ss), _p(w))
         return dict(draw_mean=dm, draw_ssd=ds, score_mean=sm, score_ssd=ss, weights=w)
+
+    def rhat(self) -> float:
+        return self.L.wno_rhat(self.h)
+
+    def warmup_spread(self):
+        a, b = C.c_double(), C.c_double()
+        self.L.wno_warmup_spread(self.h, C.cast(C.byref(a), _dp), C.cast(C.byref(b), _dp))
+        return a.value, b.value
 
     def enable_trace(self, on: bool = True):
         self.L.wno_enable_trace(self.h, int(on))

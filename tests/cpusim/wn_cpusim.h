@@ -25,6 +25,9 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(x)
+// static LDS arrays: blocks run one after another in the emulation, so function-local statics are
+// exactly "storage shared by the threads of the running block"
+#define __shared__ static
 #define WN_LDS
 typedef double v2f64 __attribute__((vector_size(16)));
 

@@ -43,6 +43,20 @@ def make_pair(model: str, D: int, C: int, lib_path=None, geometry=None, **cfg_ov
     return dev, orc
 
 
+def check_monitors(dev, orc, warm: bool, rtol=1e-9):
+    """The controller statistics (adapt.hpp:193-221, sampler.hpp:132-145): device reductions vs the oracle's
+    reference-order arithmetic.  Not bit-exact by construction (sums over chains associate differently and
+    the device uses its portable exp/log), so the tolerance is written here: 1e-9 relative."""
+    if warm:
+        ds, dm = dev.warmup_spread()
+        os_, om = orc.warmup_spread()
+        assert abs(ds - os_) <= rtol * max(abs(os_), 1e-300) + 1e-13, (ds, os_)
+        assert abs(dm - om) <= rtol * max(abs(om), 1e-300) + 1e-13, (dm, om)
+    else:
+        d, o = dev.rhat(), orc.rhat()
+        assert abs(d - o) <= rtol * o, (d, o)
+
+
 def assert_same_state(dev, orc, where: str, warm: bool):
     dev.synchronize()
     checks = [("positions", dev.positions(), orc.positions()), ("logp", dev.logp(), orc.logp()),

@@ -220,6 +220,41 @@ def test_sample_device_contract_on_gpu():
         wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "min_sampling_iter": 100, "max_sampling_iter": 10})
 
 
+def test_controller_statistics_match_oracle():
+    """adapt.hpp:193-221 / sampler.hpp:132-145 monitors: device reductions vs the oracle (rtol 1e-9, see
+    parity.check_monitors)."""
+    for model, D, C in (("std_normal", 100, 64), ("diag_normal", 1024, 48), ("diag_normal", 9000, 8)):
+        dev, orc = parity.make_pair(model, D, C)
+        pos = np.random.default_rng(1).normal(0, 2, size=(C, D))
+        for x in (dev, orc):
+            x.set_positions(pos)
+            x.set_step_sizes(0.3)
+            x.seed_chains(5, 0)
+        for _ in range(8):
+            dev.warmup_step()
+            orc.warmup_step(8)
+        parity.check_monitors(dev, orc, warm=True)
+        dev.freeze()
+        orc.freeze()
+        for _ in range(6):
+            dev.sample_step()
+            orc.sample_step(8)
+        parity.check_monitors(dev, orc, warm=False)
+
+
+def test_sample_device_early_stopping_bounds():
+    # python/tests/test_pyfunc.py:38-64
+    kw = dict(num_params=50, num_chains=8, seed=11, min_warmup_iter=20, max_warmup_iter=200, min_sampling_iter=10,
+              max_sampling_iter=300, save_warmup=True)
+    out = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    n_w, n_s = out[0].warmup.warmup_draws.shape[0], out[0].shape[0]
+    assert 20 <= n_w <= 200 and 10 <= n_s <= 300
+    assert all(x.shape[0] == n_s and x.warmup.warmup_draws.shape[0] == n_w for x in out)
+    loose = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw, step_size_converge_tol=1e6, mass_converge_tol=1e6,
+                              rhat_converge_tol=1e6)
+    assert loose[0].warmup.warmup_draws.shape[0] == 20 and loose[0].shape[0] == 10
+
+
 def test_sampler_statistics_are_sane():
     """Not a parity test: the chains actually sample the target (std normal, D=100, many chains)."""
     D, C = 100, 4096

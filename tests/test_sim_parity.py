@@ -56,6 +56,35 @@ def test_emulated_engine_host_variates(sim, oracle):
     test_gpu_parity._host_variates_case(sim, D=10, C=2)
 
 
+@pytest.mark.timeout(600)
+def test_emulated_controller_statistics(sim, oracle):
+    dev, orc = parity.run_case("std_normal", 8, 4, warmup=4, sampling=0, lib_path=sim)
+    # (run_case froze both sides: build a fresh pair for the warmup monitor)
+    dev, orc = parity.make_pair("std_normal", 8, 4, sim)
+    pos = np.random.default_rng(0).normal(size=(4, 8))
+    for x in (dev, orc):
+        x.set_positions(pos); x.set_step_sizes(0.5); x.seed_chains(3, 0)
+    for _ in range(3):
+        dev.warmup_step(); orc.warmup_step()
+    parity.check_monitors(dev, orc, warm=True)
+    dev.freeze(); orc.freeze()
+    for _ in range(3):
+        dev.sample_step(); orc.sample_step()
+    parity.check_monitors(dev, orc, warm=False)
+
+
+def test_emulated_sample_device_early_stop(sim):
+    # python/tests/test_pyfunc.py:38-64: min <= length <= max, and a loose tolerance stops at the minimum
+    kw = dict(num_params=4, num_chains=3, seed=7, min_warmup_iter=5, max_warmup_iter=12, min_sampling_iter=3,
+              max_sampling_iter=9, lib_path=sim, save_warmup=True)
+    loose = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw, step_size_converge_tol=1e6, mass_converge_tol=1e6,
+                              rhat_converge_tol=1e6)
+    assert all(x.shape[0] == 3 and x.warmup.warmup_draws.shape[0] == 5 for x in loose)
+    tight = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw, step_size_converge_tol=1e-12, mass_converge_tol=1e-12,
+                              rhat_converge_tol=1.0 + 1e-12)
+    assert all(x.shape[0] == 9 and x.warmup.warmup_draws.shape[0] == 12 for x in tight)
+
+
 def test_emulated_sample_device_contract(sim):
     # python/tests/test_pyfunc.py:38-125 restated for the device entry point
     kw = dict(num_params=5, num_chains=2, seed=1234, min_warmup_iter=4, max_warmup_iter=4, min_sampling_iter=3,

@@ -56,6 +56,120 @@ static __global__ void freeze_kernel(int C, int Dp, const double* draw_ssd, cons
   }
 }
 
+// ---- cross-chain monitors (the reference's controller loops) --------------------------------------
+// Deterministic two-stage sums: stage 1 gives every block a contiguous slice and a fixed tree inside the
+// block, stage 2 (one block) adds the block partials left to right.
+constexpr int kMonitorBlocks = 256;
+
+template <int K, class F>
+static __device__ void block_partial_sums(int n, F f, double* partial /*[gridDim][K]*/) {
+  __shared__ double sh[256][K];
+  double acc[K];
+  for (int k = 0; k < K; ++k) acc[k] = 0.0;
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) f(i, acc);
+  for (int k = 0; k < K; ++k) sh[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s)
+      for (int k = 0; k < K; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + s][k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int k = 0; k < K; ++k) partial[blockIdx.x * K + k] = sh[0][k];
+}
+template <int K>
+static __global__ void finish_sums_kernel(const double* partial, int blocks, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    for (int k = 0; k < K; ++k) {
+      double s = 0.0;
+      for (int b = 0; b < blocks; ++b) s += partial[b * K + k];
+      out[k] = s;
+    }
+  }
+}
+// sampling monitor, sampler.hpp:132-145: sums of the per-chain lp means and sample variances
+static __global__ void lp_sums_kernel(int C, const double* lp_stats, double* partial) {
+  block_partial_sums<2>(C, [&](int c, double* acc) {
+    const double n = lp_stats[3 * c], mean = lp_stats[3 * c + 1], m2 = lp_stats[3 * c + 2];
+    acc[0] += mean;
+    acc[1] += n > 1 ? m2 / (n - 1) : __builtin_nan("");  // WelfordAccumulator::sample_variance
+  }, partial);
+}
+static __global__ void lp_sqdev_kernel(int C, const double* lp_stats, double mu, double* partial) {
+  block_partial_sums<1>(C, [&](int c, double* acc) {
+    const double d = lp_stats[3 * c + 1] - mu;
+    acc[0] += d * d;
+  }, partial);
+}
+// warmup monitor, adapt.hpp:193-221.  log step per chain from Adam's theta; log mass = -log(inv_mass).
+static __global__ void log_step_sum_kernel(int C, const double* adam, double* partial) {
+  block_partial_sums<1>(C, [&](int c, double* acc) { acc[0] += wnd::dlog(wnd::dexp(adam[6 * c])); }, partial);
+}
+// column sums over chains of log mass: thread per column, chains in order (coalesced rows)
+static __global__ void log_mass_colsum_kernel(int C, int D, int Dp, const double* draw_ssd, const double* score_ssd,
+                                              const double* est_weight, double* colsum) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  double s = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const long long i = static_cast<long long>(c) * Dp + d;
+    const double im = __builtin_sqrt((draw_ssd[i] / est_weight[2 * c]) / (score_ssd[i] / est_weight[2 * c + 1]));
+    s += -wnd::dlog(im);
+  }
+  colsum[d] = s;
+}
+// per-chain l2_rel_diff(mass_m, geom_mean_mass) (util.hpp:379-382) and rel diff of the step; block per chain
+static __global__ void warmup_spread_kernel(int C, int D, int Dp, const double* draw_ssd, const double* score_ssd,
+                                            const double* est_weight, const double* adam, const double* colsum,
+                                            double mean_log_step, double* rel_mass, double* rel_step) {
+  __shared__ double sh[256];
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const long long i = static_cast<long long>(c) * Dp + d;
+    const double im = __builtin_sqrt((draw_ssd[i] / est_weight[2 * c]) / (score_ssd[i] / est_weight[2 * c + 1]));
+    const double mass = wnd::dexp(-wnd::dlog(im));                       // snap.mass, adapt.hpp:141
+    const double gm = wnd::dexp(colsum[d] / static_cast<double>(C));     // geom_mean_mass, adapt.hpp:203-205
+    const double r = (mass - gm) / gm;
+    acc += r * r;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    rel_mass[c] = __builtin_sqrt(sh[0]);
+    const double gms = wnd::dexp(mean_log_step);
+    rel_step[c] = (wnd::dexp(wnd::dlog(wnd::dexp(adam[6 * c]))) - gms) / gms;  // adapt.hpp:213-215
+  }
+}
+static __global__ void max2_kernel(int C, const double* a, const double* b, double* out) {
+  __shared__ double sa[256], sb[256];
+  double ma = 0.0, mb = 0.0;  // std::fmax from 0.0, adapt.hpp:208-216
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    ma = fmax(ma, a[i]);
+    mb = fmax(mb, b[i]);
+  }
+  sa[threadIdx.x] = ma;
+  sb[threadIdx.x] = mb;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s) {
+      sa[threadIdx.x] = fmax(sa[threadIdx.x], sa[threadIdx.x + s]);
+      sb[threadIdx.x] = fmax(sb[threadIdx.x], sb[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sa[0];
+    out[1] = sb[0];
+  }
+}
+
 static __global__ void sum_i64_kernel(const int64_t* v, int n, unsigned long long* out) {
   unsigned long long acc = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)

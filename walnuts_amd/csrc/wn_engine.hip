@@ -84,6 +84,7 @@ struct wn_engine {
 
   DevBuf<double> theta, mass, inv_mass, chol_mass, draw_mean, draw_ssd, score_mean, score_ssd;
   DevBuf<double> step_init, step_size, adam, est_weight, mm_state, logp, model_params, arena, z_buf, u_buf;
+  DevBuf<double> lp_stats, mon_partial, mon_out, mon_colsum, mon_rel_mass, mon_rel_step;
   DevBuf<int32_t> min_micro, depth, rng_draws;
   DevBuf<int64_t> grad_evals;
   DevBuf<uint32_t> counter;
@@ -189,6 +190,7 @@ struct wn_engine {
     P.depth_out = depth.p;
     P.grad_evals = grad_evals.p;
     P.rng_draws = rng_draws.p;
+    P.lp_stats = lp_stats.p;
     P.draws_out = draws_dev;
     P.draws_stride = draws_stride;
     P.model_params = model_params.p;
@@ -303,6 +305,12 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.rng_draws.alloc(num_chains);
   e.grad_evals.alloc(num_chains);
   e.counter.alloc(1);
+  e.lp_stats.alloc(3 * num_chains);
+  e.mon_partial.alloc(2 * wn::kMonitorBlocks);
+  e.mon_out.alloc(4);
+  e.mon_colsum.alloc(e.Dp);
+  e.mon_rel_mass.alloc(num_chains);
+  e.mon_rel_step.alloc(num_chains);
   e.scratch64.alloc(1);
   const size_t arena_vecs =
       static_cast<size_t>(e.pool_total - e.pool_lds) + (e.geo.mem ? wn::kMemScratchVectors : 0);
@@ -319,6 +327,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   HIP_OK(hipMemsetAsync(e.depth.p, 0, num_chains * sizeof(int32_t), e.stream));
   HIP_OK(hipMemsetAsync(e.rng_draws.p, 0, num_chains * sizeof(int32_t), e.stream));
   HIP_OK(hipMemsetAsync(e.logp.p, 0, num_chains * sizeof(double), e.stream));
+  HIP_OK(hipMemsetAsync(e.lp_stats.p, 0, 3 * num_chains * sizeof(double), e.stream));
   {
     std::vector<double> mp(e.Dp, 1.0);
     if (model_params) std::copy(model_params, model_params + num_params, mp.begin());
@@ -578,6 +587,74 @@ int wn_engine_total_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err) 
     HIP_OK(hipMemcpyAsync(&v, e->scratch64.p, sizeof(v), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));
     *out = static_cast<int64_t>(v);
+  });
+}
+
+// ---- cross-chain monitors (adapt.hpp:172-229, sampler.hpp:117-158) ---------------------------------
+int wn_engine_lp_sums(wn_engine* e, double* out /*[3]: sum of means, sum of sample variances, chains*/,
+                      WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    const int C = static_cast<int>(e->C);
+    hipLaunchKernelGGL(wn::lp_sums_kernel, dim3(wn::kMonitorBlocks), dim3(256), 0, e->stream, C, e->lp_stats.p,
+                       e->mon_partial.p);
+    hipLaunchKernelGGL(wn::finish_sums_kernel<2>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p,
+                       wn::kMonitorBlocks, e->mon_out.p);
+    HIP_OK(hipGetLastError());
+    e->download(e->mon_out, out, 2);
+    out[2] = static_cast<double>(C);
+  });
+}
+int wn_engine_lp_sq_dev(wn_engine* e, double mean_of_means, double* out, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    hipLaunchKernelGGL(wn::lp_sqdev_kernel, dim3(wn::kMonitorBlocks), dim3(256), 0, e->stream,
+                       static_cast<int>(e->C), e->lp_stats.p, mean_of_means, e->mon_partial.p);
+    hipLaunchKernelGGL(wn::finish_sums_kernel<1>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p,
+                       wn::kMonitorBlocks, e->mon_out.p);
+    HIP_OK(hipGetLastError());
+    e->download(e->mon_out, out, 1);
+  });
+}
+int wn_engine_rhat(wn_engine* e, double* rhat, WalnutpyError** err) {
+  return guarded(err, [&] {
+    double s[3], q;
+    WalnutpyError* inner = nullptr;
+    if (wn_engine_lp_sums(e, s, &inner) != 0 || wn_engine_lp_sq_dev(e, s[0] / s[2], &q, &inner) != 0) {
+      std::string msg = inner ? inner->msg : "monitor failed";
+      delete inner;
+      throw std::runtime_error(msg);
+    }
+    const double variance_of_means = q / (s[2] - 1);  // util.hpp:401-404
+    const double mean_of_variances = s[1] / s[2];
+    *rhat = std::sqrt(1 + variance_of_means / mean_of_variances);  // sampler.hpp:145
+  });
+}
+int wn_engine_warmup_spread(wn_engine* e, double* max_rel_diff_step, double* max_rel_diff_mass, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e->frozen) throw std::runtime_error("warmup monitor after freeze");
+    e->ensure_adapters();
+    e->use_device();
+    const int C = static_cast<int>(e->C);
+    hipLaunchKernelGGL(wn::log_step_sum_kernel, dim3(wn::kMonitorBlocks), dim3(256), 0, e->stream, C, e->adam.p,
+                       e->mon_partial.p);
+    hipLaunchKernelGGL(wn::finish_sums_kernel<1>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p,
+                       wn::kMonitorBlocks, e->mon_out.p);
+    double sum_log_step = 0;
+    e->download(e->mon_out, &sum_log_step, 1);
+    const double mean_log_step = sum_log_step / C;  // adapt.hpp:201-202
+    hipLaunchKernelGGL(wn::log_mass_colsum_kernel, dim3((e->D + 255) / 256), dim3(256), 0, e->stream, C, e->D, e->Dp,
+                       e->draw_ssd.p, e->score_ssd.p, e->est_weight.p, e->mon_colsum.p);
+    hipLaunchKernelGGL(wn::warmup_spread_kernel, dim3(C), dim3(256), 0, e->stream, C, e->D, e->Dp, e->draw_ssd.p,
+                       e->score_ssd.p, e->est_weight.p, e->adam.p, e->mon_colsum.p, mean_log_step,
+                       e->mon_rel_mass.p, e->mon_rel_step.p);
+    hipLaunchKernelGGL(wn::max2_kernel, dim3(1), dim3(256), 0, e->stream, C, e->mon_rel_mass.p, e->mon_rel_step.p,
+                       e->mon_out.p);
+    HIP_OK(hipGetLastError());
+    double m[2];
+    e->download(e->mon_out, m, 2);
+    *max_rel_diff_mass = m[0];
+    *max_rel_diff_step = m[1];
   });
 }
 

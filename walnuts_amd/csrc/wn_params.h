@@ -39,6 +39,7 @@ struct Params {
   int32_t* depth_out;  // [C]
   int64_t* grad_evals; // [C] running totals
   int32_t* rng_draws;  // [C] scalar draws of the last transition
+  double* lp_stats;    // [C][3] WelfordAccumulator (count, mean, M2) of the sampling log densities
   // output of this transition
   double* draws_out;   // nullable; row c at draws_out + c*draws_stride, D doubles
   int64_t draws_stride;

@@ -8,13 +8,15 @@
 // Initial positions and the step-size search consume the same libstdc++ streams as the reference
 // (seed_seq{seed,1} and seed_seq{seed,2}; walnutpy.cpp:187-189,75-76): they are generated on the host,
 // so those inputs are bit-identical to the reference's.
-// What differs (documented in INTEGRATION.md): chains advance in lock step for exactly max_*_iter
-// iterations (the reference's thread-per-chain controllers may stop any time after min_*_iter), and the
+// What differs (documented in INTEGRATION.md): chains advance in lock step, so the controllers' stopping
+// rules (adapt.hpp:172-229, sampler.hpp:117-158) are evaluated on whole iterations and every chain gets the same
+// length (the reference's thread-per-chain workers stop wherever they happen to be), and the
 // per-chain trajectory randomness comes from the counter-based generator keyed by seed+id+num_chains
 // (walnutpy.cpp:82) instead of mt19937_64.
 #include "wn_hip.h"
 
 #include <cmath>
+#include <iomanip>
 #include <random>
 #include <sstream>
 #include <stdexcept>
@@ -204,21 +206,39 @@ extern "C" int walnutpie_sample_device(
     }
     Printer printer{print, static_cast<size_t>(refresh)};
     size_t written = 0;
-    for (int it = 0; it < max_warmup_iter; ++it) {  // AdaptWorker loop, adapt.hpp:116-127
+    for (int it = 1; it <= max_warmup_iter; ++it) {  // AdaptWorker loop, adapt.hpp:116-127
       double* dst = save_warmup ? d_out + written * D : nullptr;
       WN_CALL(wn_engine_warmup_step(e, dst, static_cast<int64_t>(draws_offset), &call_err_));
       if (save_warmup) ++written;
       printer.progress(num_chains);
+      // controller_loop (adapt.hpp:172-229) on the snapshots published every publish_stride = 5 iterations
+      if (it >= min_warmup_iter && it < max_warmup_iter && it % 5 == 0) {
+        double rel_step = 0, rel_mass = 0;
+        WN_CALL(wn_engine_warmup_spread(e, &rel_step, &rel_mass, &call_err_));
+        if (rel_mass <= mass_converge_tol && rel_step <= step_size_converge_tol) break;
+      }
     }
     const size_t written_warmup = written;
     WN_CALL(wn_engine_freeze(e, &call_err_));  // on_warmup_complete, handlers.hpp:91-101
     printer.in_warmup = false;
     if (stepsize_out != nullptr) WN_CALL(wn_engine_get_step_sizes(e, stepsize_out, &call_err_));
     if (inv_metric_out != nullptr) WN_CALL(wn_engine_get_inv_mass(e, inv_metric_out, &call_err_));
-    for (int it = 0; it < max_sampling_iter; ++it) {  // ChainWorker loop, sampler.hpp:82-93
+    for (int it = 1; it <= max_sampling_iter; ++it) {  // ChainWorker loop, sampler.hpp:82-93
       WN_CALL(wn_engine_sample_step(e, d_out + written * D, static_cast<int64_t>(draws_offset), &call_err_));
       ++written;
       printer.progress(num_chains);
+      // controller_loop (sampler.hpp:117-158): R-hat of the log density once every chain has min_iter draws
+      if (it >= min_sampling_iter && it >= 2 && it < max_sampling_iter && num_chains > 1) {
+        double rhat = 0;
+        WN_CALL(wn_engine_rhat(e, &rhat, &call_err_));
+        if (print != nullptr && refresh != 0) {
+          std::stringstream ss;
+          ss << "Controller: R-hat at " << std::setprecision(10) << rhat << std::endl;  // handlers.hpp:160-176
+          const std::string msg = ss.str();
+          print(msg.c_str(), msg.length(), false);
+        }
+        if (rhat <= rhat_converge_tol) break;
+      }
     }
     WN_CALL(wn_engine_synchronize(e, &call_err_));
     if (num_chains * draws_offset > 0) {

@@ -450,6 +450,15 @@ struct TrajBase {
 #pragma unroll
         for (int i = 0; i < 6; ++i) P.adam[6 * chain + i] = meta->adam[i];
       }
+      if (!warm) {  // ChainWorker: logp_stats_.observe(lp), sampler.hpp:87-88 / online_moments.hpp:34-40
+        double* w = P.lp_stats + 3ll * chain;
+        const double n = w[0] + 1;
+        const double delta = lpsel - w[1];
+        const double mean = w[1] + delta / n;
+        w[0] = n;
+        w[1] = mean;
+        w[2] += delta * (lpsel - mean);
+      }
       P.logp_out[chain] = lpsel;
       P.depth_out[chain] = err ? -1 : depth;
       P.grad_evals[chain] += n_grad;

@@ -158,6 +158,19 @@ class DeviceEngine:
         self._call(self.lib.wn_engine_last_kernel_ms, C.byref(v))
         return v.value
 
+    def rhat(self) -> float:
+        """R-hat of the log density over the sampling draws so far (sampler.hpp:132-145)."""
+        v = C.c_double()
+        self._call(self.lib.wn_engine_rhat, C.cast(C.byref(v), _dp))
+        return v.value
+
+    def warmup_spread(self):
+        """(max rel. step-size distance, max rel. mass distance) from the chains' geometric means
+        (adapt.hpp:193-221)."""
+        a, b = C.c_double(), C.c_double()
+        self._call(self.lib.wn_engine_warmup_spread, C.cast(C.byref(a), _dp), C.cast(C.byref(b), _dp))
+        return a.value, b.value
+
     def timing_reset(self):
         self._call(self.lib.wn_engine_timing_reset)
 

@@ -875,9 +875,11 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
   // the far end it is tested against.
   __device__ __forceinline__ bool uturn_vectors(const double (&a)[EPL], const double (&b)[EPL], bool fwd) {
     double p_hot = 0.0, p_far = 0.0;
+    // a - th == -(th - a) exactly: one subtraction, then a wave-uniform sign flip on the high word
+    const uint64_t flip = fwd ? 0ull : 0x8000000000000000ull;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
-      const double diff = fwd ? (th[j] - a[j]) : (a[j] - th[j]);
+      const double diff = wnd::as_f64(wnd::as_u64(th[j] - a[j]) ^ flip);
       const double sd = im[j] * diff;
       p_hot += rh[j] * sd;
       p_far += b[j] * sd;

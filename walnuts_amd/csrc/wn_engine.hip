@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <random>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -69,6 +70,20 @@ struct DevBuf {
 
 }  // namespace
 
+// Host-side reproduction of the reference's per-chain random streams (api.hpp:46-51 + detail::Random,
+// util.hpp:78-162): engine m = mt19937_64(seed_seq{seed, m+1}); per transition D normals (libstdc++'s polar
+// method with its cached second variate), then one engine output per bernoulli / uniform.  The variates are
+// generated here and fed to the kernel (kRngBuffer); after the launch each engine is advanced by the number of
+// scalar draws its chain actually consumed.  Parity mode for small runs: one host round trip per transition.
+struct ReferenceStreams {
+  std::vector<std::mt19937_64> eng;
+  std::vector<std::normal_distribution<double>> normal;
+  std::vector<std::mt19937_64> after_normals;
+  std::vector<double> z, u;
+  std::vector<int32_t> used;
+  int pool = 0;
+};
+
 struct wn_engine {
   int model = 0, D = 0, Dp = 0;
   size_t C = 0;
@@ -99,6 +114,7 @@ struct wn_engine {
   bool frozen = false;
   bool variates_pending = false;
   int u_stride = 0;
+  std::unique_ptr<ReferenceStreams> ref_streams;
 
   // one HIP event pair per transition launch since the last timing reset
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -222,8 +238,12 @@ struct wn_engine {
     return P;
   }
 
+  void feed_reference_streams();
+  void advance_reference_streams();
+
   void step(bool warm, double* draws_dev, int64_t draws_stride) {
     use_device();
+    if (ref_streams) feed_reference_streams();
     wn::Params P = make_params(warm, draws_dev, draws_stride);
     HIP_OK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), stream));
     auto& ev = next_events();
@@ -235,8 +255,40 @@ struct wn_engine {
     ++transition;
     ++iteration;
     if (warm) ++warmup_iter;
+    if (ref_streams) advance_reference_streams();
   }
 };
+
+void wn_engine::feed_reference_streams() {
+  ReferenceStreams& r = *ref_streams;
+  const size_t Dn = static_cast<size_t>(D);
+  for (size_t m = 0; m < C; ++m) {
+    for (size_t i = 0; i < Dn; ++i) r.z[m * Dn + i] = r.normal[m](r.eng[m]);  // util.hpp:124-127, index order
+    r.after_normals[m] = r.eng[m];
+    std::mt19937_64 look = r.eng[m];
+    // uniform_real_distribution(0,1) and bernoulli_distribution(0.5) both draw one generate_canonical value
+    for (int j = 0; j < r.pool; ++j) r.u[m * r.pool + j] = std::generate_canonical<double, 53>(look);
+  }
+  if (z_buf.n == 0) z_buf.alloc(C * static_cast<size_t>(Dp));
+  if (u_buf.n < C * static_cast<size_t>(r.pool)) u_buf.alloc(C * static_cast<size_t>(r.pool));
+  HIP_OK(hipMemsetAsync(z_buf.p, 0, z_buf.n * sizeof(double), stream));
+  upload_rows(z_buf, r.z.data(), 0.0);
+  HIP_OK(hipMemcpyAsync(u_buf.p, r.u.data(), C * static_cast<size_t>(r.pool) * sizeof(double), hipMemcpyHostToDevice,
+                        stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  u_stride = r.pool;
+  variates_pending = true;
+}
+
+void wn_engine::advance_reference_streams() {
+  ReferenceStreams& r = *ref_streams;
+  download(rng_draws, r.used.data(), C);
+  for (size_t m = 0; m < C; ++m) {
+    if (r.used[m] > r.pool) throw std::runtime_error("reference-stream pool exhausted");
+    r.eng[m] = r.after_normals[m];
+    r.eng[m].discard(static_cast<unsigned long long>(r.used[m]));
+  }
+}
 
 namespace {
 
@@ -465,6 +517,29 @@ int wn_engine_seed(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyE
     e->transition = 0;
   });
 }
+int wn_engine_seed_reference_streams(wn_engine* e, uint64_t seed, WalnutpyError** err) {
+  return guarded(err, [&] {
+    auto r = std::make_unique<ReferenceStreams>();
+    r->eng.reserve(e->C);
+    for (size_t m = 0; m < e->C; ++m) {
+      std::seed_seq ss{static_cast<size_t>(seed), m + 1u};  // api.hpp:48-49
+      r->eng.emplace_back(ss);
+    }
+    r->normal.assign(e->C, std::normal_distribution<double>(0.0, 1.0));
+    r->after_normals = r->eng;
+    r->z.assign(e->C * static_cast<size_t>(e->D), 0.0);
+    // scalar draws per transition: one bernoulli + one Metropolis uniform per doubling, one Barker uniform
+    // per inner merge: at most 2^max_depth - 1 + max_depth
+    const int md = e->cfg.max_trajectory_doublings;
+    if (md > 16) throw std::invalid_argument("reference streams support max_trajectory_doublings <= 16");
+    r->pool = (1 << md) - 1 + md;
+    r->u.assign(e->C * static_cast<size_t>(r->pool), 0.0);
+    r->used.assign(e->C, 0);
+    e->ref_streams = std::move(r);
+    e->seed = seed;
+    e->transition = 0;
+  });
+}
 int wn_engine_set_variates(wn_engine* e, const double* normals, const double* uniforms, int u_per_chain,
                            WalnutpyError** err) {
   return guarded(err, [&] {
@@ -500,6 +575,8 @@ int wn_engine_freeze(wn_engine* e, WalnutpyError** err) {
                        e->step_size.p, e->min_micro.p);
     HIP_OK(hipGetLastError());
     e->frozen = true;
+    if (e->ref_streams)  // WalnutsSampler builds a new detail::Random over the same engine (walnuts.hpp:642)
+      e->ref_streams->normal.assign(e->C, std::normal_distribution<double>(0.0, 1.0));
   });
 }
 int wn_engine_sample_step(wn_engine* e, double* draws_dev, int64_t draws_stride, WalnutpyError** err) {

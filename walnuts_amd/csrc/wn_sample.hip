@@ -77,7 +77,8 @@ struct Printer {  // python/src/walnutpie/handlers.hpp:17-59
 
 }  // namespace
 
-extern "C" int walnutpie_sample_device(
+static int sample_device_impl(
+    bool reference_streams,
     int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
     unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
     int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
@@ -190,7 +191,12 @@ extern "C" int walnutpie_sample_device(
       }
       WN_CALL(wn_engine_adapt_step_with_normals(e, z.data(), &call_err_));
     }
-    WN_CALL(wn_engine_seed(e, static_cast<uint64_t>(seed) + id + num_chains, 0u, &call_err_));
+    // walnutpy.cpp:82: walnuts<mt19937_64>(seed + id + num_chains, ...)
+    if (reference_streams) {
+      WN_CALL(wn_engine_seed_reference_streams(e, static_cast<uint64_t>(seed) + id + num_chains, &call_err_));
+    } else {
+      WN_CALL(wn_engine_seed(e, static_cast<uint64_t>(seed) + id + num_chains, 0u, &call_err_));
+    }
 
     // draws stay on the device in the caller's layout and come back in one copy
     double* d_out = nullptr;
@@ -260,4 +266,28 @@ extern "C" int walnutpie_sample_device(
     if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error("Unknown error", generic));
   }
   return -1;
+}
+
+#define WN_SAMPLE_ARGS                                                                                            \
+  model, model_params, num_params, inits, num_chains, seed, id, init_radius, init_inv_metric, min_warmup_iter,   \
+      max_warmup_iter, min_sampling_iter, max_sampling_iter, max_trajectory_doublings, max_step_halvings,        \
+      min_micro_steps, max_hamiltonian_error, step_size_converge_tol, mass_converge_tol, rhat_converge_tol,      \
+      mass_init_count, mass_additive_smoothing, max_macro_steps_target, step_size_init, step_accept_rate_target, \
+      step_learning_rate, step_gradient_decay, step_sq_gradient_decay, step_stabilization, step_learn_rate_decay, \
+      save_warmup, out, out_size, final_lengths, stepsize_out, inv_metric_out, refresh, print, err
+#define WN_SAMPLE_PARAMS                                                                                          \
+  int model, const double *model_params, int num_params, const double *inits, size_t num_chains,                 \
+      unsigned int seed, unsigned int id, double init_radius, const double *init_inv_metric, int min_warmup_iter, \
+      int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,           \
+      int max_step_halvings, int min_micro_steps, double max_hamiltonian_error, double step_size_converge_tol,   \
+      double mass_converge_tol, double rhat_converge_tol, double mass_init_count,                                \
+      double mass_additive_smoothing, double max_macro_steps_target, double step_size_init,                      \
+      double step_accept_rate_target, double step_learning_rate, double step_gradient_decay,                     \
+      double step_sq_gradient_decay, double step_stabilization, double step_learn_rate_decay, bool save_warmup,  \
+      double *out, size_t out_size, int *final_lengths, double *stepsize_out, double *inv_metric_out,            \
+      int refresh, PRINT_CALLBACK print, WalnutpyError **err
+
+extern "C" int walnutpie_sample_device(WN_SAMPLE_PARAMS) { return sample_device_impl(false, WN_SAMPLE_ARGS); }
+extern "C" int walnutpie_sample_device_reference_streams(WN_SAMPLE_PARAMS) {
+  return sample_device_impl(true, WN_SAMPLE_ARGS);
 }

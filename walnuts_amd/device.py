@@ -94,6 +94,7 @@ def walnuts_device(
     step_learn_rate_decay: float = 0.5,
     save_warmup: bool = False,
     refresh: int = 0,
+    reference_streams: bool = False,
     lib_path: Optional[str] = None,
 ) -> list:
     lib = _ffi.load_library(lib_path)
@@ -129,7 +130,8 @@ def walnuts_device(
     cb = _ffi.PRINT_CALLBACK(_print)
     dp = _ffi._dp
     err = C.c_void_p()
-    rc = lib.walnutpie_sample_device(
+    entry = lib.walnutpie_sample_device_reference_streams if reference_streams else lib.walnutpie_sample_device
+    rc = entry(
         model, None if mp is None else mp.ctypes.data_as(dp), num_params,
         None if inits is None else inits.ctypes.data_as(dp), num_chains, seed, id, init_radius,
         None if inv_metric_init is None else inv_metric_init.ctypes.data_as(dp), min_warmup_iter, max_warmup_iter,

@@ -91,6 +91,11 @@ class DeviceEngine:
     def seed_chains(self, seed: int, chain_offset: int = 0):
         self._call(self.lib.wn_engine_seed, seed, chain_offset)
 
+    def seed_reference_streams(self, seed: int):
+        """Parity mode: the reference's mt19937_64(seed_seq{seed, m+1}) + libstdc++ distributions, generated on
+        the host for every following transition (api.hpp:46-51, util.hpp:78-162)."""
+        self._call(self.lib.wn_engine_seed_reference_streams, seed)
+
     def set_variates(self, normals, uniforms):
         z = _f64(normals).reshape(self.C, self.D)
         u = _f64(uniforms).reshape(self.C, -1)

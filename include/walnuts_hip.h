@@ -152,6 +152,8 @@ WALNUTS_HIP_EXPORT int wn_engine_freeze(wn_engine* e, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_sample_step(wn_engine* e, double* draws_dev, int64_t draws_stride,
                                              WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_synchronize(wn_engine* e, WalnutpyError** err);
+/* fails (generic error) if any chain's last transition could not complete on the device (span pool exhausted) */
+WALNUTS_HIP_EXPORT int wn_engine_check(wn_engine* e, WalnutpyError** err);
 
 /* state -> host buffers */
 WALNUTS_HIP_EXPORT int wn_engine_get_positions(wn_engine* e, double* out /*[C*D]*/, WalnutpyError** err);

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("wn_engine_freeze", _i32, [_vp, _errpp]),
     ("wn_engine_sample_step", _i32, [_vp, _vp, _i64, _errpp]),
     ("wn_engine_synchronize", _i32, [_vp, _errpp]),
+    ("wn_engine_check", _i32, [_vp, _errpp]),
     ("wn_engine_get_positions", _i32, [_vp, _dp, _errpp]),
     ("wn_engine_get_inv_mass", _i32, [_vp, _dp, _errpp]),
     ("wn_engine_get_step_sizes", _i32, [_vp, _dp, _errpp]),

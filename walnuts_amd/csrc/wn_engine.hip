@@ -167,9 +167,25 @@ struct wn_engine {
     HIP_OK(hipStreamSynchronize(stream));
   }
   void fill(DevBuf<double>& b, double v) {
-    std::vector<double> h(b.n, v);
-    HIP_OK(hipMemcpyAsync(b.p, h.data(), b.n * sizeof(double), hipMemcpyHostToDevice, stream));
+    const int blocks = static_cast<int>(std::min<size_t>((b.n + 255) / 256, 4096));
+    hipLaunchKernelGGL(wn::fill_kernel, dim3(blocks), dim3(256), 0, stream, b.p, static_cast<long long>(b.n), v);
+    HIP_OK(hipGetLastError());
+  }
+  // throws if any chain's last transition exhausted the span pool (reported by the kernel as depth -1)
+  void check_transitions() {
+    use_device();
+    HIP_OK(hipMemsetAsync(scratch64.p, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(wn::count_failed_kernel, dim3(256), dim3(256), 0, stream, depth.p, static_cast<int>(C),
+                       scratch64.p);
+    HIP_OK(hipGetLastError());
+    unsigned long long bad = 0;
+    HIP_OK(hipMemcpyAsync(&bad, scratch64.p, sizeof(bad), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
+    if (bad != 0) {
+      std::stringstream ss;
+      ss << bad << " chain(s) exhausted the span pool; raise max pool or lower max_trajectory_doublings";
+      throw std::runtime_error(ss.str());
+    }
   }
 
   void ensure_adapters() {
@@ -590,6 +606,9 @@ int wn_engine_synchronize(wn_engine* e, WalnutpyError** err) {
     e->use_device();
     HIP_OK(hipStreamSynchronize(e->stream));
   });
+}
+int wn_engine_check(wn_engine* e, WalnutpyError** err) {
+  return guarded(err, [&] { e->check_transitions(); });
 }
 
 int wn_engine_get_positions(wn_engine* e, double* out, WalnutpyError** err) {

@@ -246,7 +246,7 @@ static int sample_device_impl(
         if (rhat <= rhat_converge_tol) break;
       }
     }
-    WN_CALL(wn_engine_synchronize(e, &call_err_));
+    WN_CALL(wn_engine_check(e, &call_err_));
     if (num_chains * draws_offset > 0) {
       if (hipMemcpyAsync(out, d_out, num_chains * draws_offset * sizeof(double), hipMemcpyDeviceToHost,
                          reinterpret_cast<hipStream_t>(wn_engine_stream(e))) != hipSuccess ||

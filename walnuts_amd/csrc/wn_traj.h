@@ -55,7 +55,7 @@ __device__ __forceinline__ double uni(double v) {
 
 // xor-butterfly sum over the 64 lanes, offsets 1,2,4,8,16,32: every lane ends with the same bits
 // (a+b == b+a), and the CPU oracle replays exactly this association order.
-#if defined(WN_CPU_SIM) || defined(WN_DISABLE_DPP)
+#if defined(WN_CPU_SIM)
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
   return v;
@@ -111,12 +111,8 @@ __device__ __forceinline__ double log_sum_exp(double x1, double x2) {
   const double m = fmax(x1, x2);
   if (x1 != x1 || x2 != x2) return __builtin_nan("");
   if (__builtin_isinf(m) || (x1 + x2) != (x1 + x2)) return fmax(x1, x2);
-#if defined(WN_VARIANT_LSE2)
-  return m + wnd::dlog(wnd::dexp(x1 - m) + wnd::dexp(x2 - m));
-#else
   const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
   return m + wnd::dlog(1.0 + wnd::dexp(d));
-#endif
 }
 
 // ---- target densities (device form of the LogpGrad contract, concepts.hpp:258-262) ----

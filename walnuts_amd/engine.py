@@ -114,6 +114,10 @@ class DeviceEngine:
     def synchronize(self):
         self._call(self.lib.wn_engine_synchronize)
 
+    def check(self):
+        """Raise if any chain's last transition could not complete on the device."""
+        self._call(self.lib.wn_engine_check)
+
     # ---- state
     def _get(self, fn, shape, dtype=np.float64, ptr=_dp):
         out = np.empty(shape, dtype=dtype)

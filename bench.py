@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--elems-per-lane", type=int, default=0)
     ap.add_argument("--workgroups-per-cu", type=int, default=0)
     ap.add_argument("--lds-vectors", type=int, default=-1)
+    ap.add_argument("--reserved-cus", type=int, default=-1,
+                    help="CUs left free for the RCCL all-gather kernels (default: 0 on one GPU, 16 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--phase", default="sampling", choices=["sampling", "warmup"],
@@ -127,8 +129,12 @@ def main():
 
     D, C = args.dim, args.chains
     model_id, params = model_setup(args.model, D)
+    # the transition kernel is persistent and would hold every CU for the whole step; with more than one GPU a
+    # few CUs stay free so that RCCL's all-gather of the previous draws really runs underneath it
+    reserved = args.reserved_cus if args.reserved_cus >= 0 else (16 if world > 1 else 0)
     cfg = wa.default_config(device=local_rank, waves_per_chain=args.waves_per_chain, elems_per_lane=args.elems_per_lane,
-                            workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors)
+                            workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors,
+                            reserved_cus=reserved)
     eng = wa.DeviceEngine(model_id, D, C, cfg, params=params)
     if world > 1:
         # kernels on torch's current stream: RCCL collectives on the draws are then ordered after them by torch
@@ -215,7 +221,8 @@ def main():
                 "phase": args.phase, "parallelism": f"chains sharded over {world} GPU(s)"
                                                     + (", RCCL all-gather of draws each step" if world > 1 else ""),
                 "geometry": {"lanes_per_chain": eng.lanes, "dim_padded": eng.dim_padded,
-                             "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors},
+                             "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
+                             "reserved_cus": reserved},
                 "grad_evals_per_transition_per_chain": grad_evals / max(args.steps, 1) / C,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -107,6 +107,9 @@ typedef struct wn_config {
                                        the default above 8192 parameters) */
   int32_t workgroups_per_cu;        /* resident chains per compute unit */
   int32_t lds_vectors;              /* span-pool vectors kept in LDS (-1: as many as fit) */
+  int32_t reserved_cus;             /* compute units the persistent grid leaves free (e.g. for RCCL kernels that
+                                       all-gather the previous iteration's draws while this one runs); 0 */
+  int32_t reserved0;
 } wn_config;
 
 WALNUTS_HIP_EXPORT void wn_default_config(wn_config* cfg);

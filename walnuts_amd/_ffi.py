@@ -36,6 +36,8 @@ class Config(C.Structure):
         ("elems_per_lane", C.c_int32),
         ("workgroups_per_cu", C.c_int32),
         ("lds_vectors", C.c_int32),
+        ("reserved_cus", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

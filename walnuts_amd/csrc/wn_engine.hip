@@ -357,7 +357,8 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   if (e.geo.mem) lds_vecs = 0;  // streaming backend: vectors are far larger than LDS
   e.pool_lds = std::min(lds_vecs, e.pool_total);
   e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds, e.Dp);
-  e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(e.num_cus) * wg_per_cu));
+  const int usable_cus = std::max(1, e.num_cus - std::max(0, cfg.reserved_cus));
+  e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(usable_cus) * wg_per_cu));
 
   const size_t plane = num_chains * static_cast<size_t>(e.Dp);
   for (DevBuf<double>* b : {&e.theta, &e.mass, &e.inv_mass, &e.chol_mass, &e.draw_mean, &e.draw_ssd, &e.score_mean, &e.score_ssd})
@@ -464,6 +465,8 @@ void wn_default_config(wn_config* c) {
   c->elems_per_lane = 0;
   c->workgroups_per_cu = 0;
   c->lds_vectors = -1;
+  c->reserved_cus = 0;
+  c->reserved0 = 0;
 }
 
 int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params, size_t num_chains,

@@ -683,7 +683,7 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
   static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
-  double th0[EPL], rh0[EPL], g0[EPL];
+  double th0[EPL], rh0[EPL];  // restart state; its gradient is re-evaluated on a retry (a pure function of th0)
   int start_buf[3];
 
   __device__ __forceinline__ TrajReg(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
@@ -845,7 +845,6 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
       for (int j = 0; j < EPL; ++j) {
         th0[j] = th[j];
         rh0[j] = rh[j];
-        g0[j] = g[j];
       }
     } else {
       pool_store(start_buf[0], th);
@@ -859,8 +858,11 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
       for (int j = 0; j < EPL; ++j) {
         th[j] = th0[j];
         rh[j] = rh0[j];
-        g[j] = g0[j];
       }
+      // the restart gradient is a pure function of the restart position: same bits as the copy the
+      // reference keeps (walnuts.hpp:326), without holding a third vector for the rare retry
+      double unused = 0.0;
+      Model::eval(*this, th, g, mp, aux, unused);
     } else {
       pool_load(start_buf[0], th);
       pool_load(start_buf[1], rh);

@@ -24,7 +24,7 @@
 #define __global__
 #define __host__
 #define __forceinline__ inline
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 // static LDS arrays: blocks run one after another in the emulation, so function-local statics are
 // exactly "storage shared by the threads of the running block"
 #define __shared__ static

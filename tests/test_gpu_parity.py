@@ -69,6 +69,19 @@ def test_engine_matches_oracle_bitwise(model, D, C, geometry):
     parity.run_case(model, D, C, warmup=12, sampling=8, geometry=geometry, check_every=2)
 
 
+@pytest.mark.parametrize("model,D,C,geometry,wpe", [
+    ("std_normal", 1024, 96, (2, 8), 3),
+    ("std_normal", 1024, 64, (4, 4), 3),
+    ("std_normal", 1000, 64, (4, 4), 4),
+    ("diag_normal", 500, 48, (1, 8), 3),
+    ("funnel", 300, 48, (2, 4), 4),
+    ("diag_normal", 4096, 16, (8, 8), 3),
+])
+def test_lds_state_kernels_match_oracle_bitwise(model, D, C, geometry, wpe):
+    """The kernels that keep inverse mass + restart state in LDS (more resident chains per CU)."""
+    parity.run_case(model, D, C, warmup=10, sampling=6, geometry=geometry, state_in_lds=wpe, check_every=2)
+
+
 @pytest.mark.parametrize("kw", [
     dict(model="std_normal", D=1, C=5),                                   # one parameter
     dict(model="std_normal", D=2, C=1),                                   # one chain

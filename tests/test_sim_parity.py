@@ -25,9 +25,14 @@ def sim():
     ("diag_normal", 130, (1, 4)),      # (1,4): restart state parked in the span pool
     ("funnel", 9, (2, 2)),             # two wavefronts: cross-wave reductions, broadcasts, barriers
     ("diag_normal", 300, (1, -1)),     # streaming backend (vectors in HBM scratch), 3 tiles per lane
+    ("std_normal", 11, (1, 2, 3)),     # LDS-state kernels: inverse mass + restart state in LDS
 ])
 def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry):
-    parity.run_case(model, D, 2, warmup=4, sampling=3, lib_path=sim, geometry=geometry)
+    extra = {}
+    if geometry is not None and len(geometry) == 3:
+        extra["state_in_lds"] = geometry[2]
+        geometry = geometry[:2]
+    parity.run_case(model, D, 2, warmup=4, sampling=3, lib_path=sim, geometry=geometry, step=None, **extra)
 
 
 @pytest.mark.timeout(600)

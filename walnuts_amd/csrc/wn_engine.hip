@@ -92,7 +92,7 @@ struct wn_engine {
   int device = 0;
   int num_cus = 256;
   int grid = 0;
-  int pool_lds = 0, pool_total = 0;
+  int pool_lds = 0, pool_total = 0, lds_state = 0;
   int64_t arena_stride = 0;  // doubles per persistent workgroup: HBM part of the span pool (+ streaming scratch)
   size_t smem = 0;
   hipStream_t stream = nullptr;
@@ -248,6 +248,7 @@ struct wn_engine {
     P.warmup_iter = warmup_iter;
     P.arena = arena.p;
     P.arena_stride = arena_stride;
+    P.lds_state = lds_state;
     P.pool_lds = pool_lds;
     P.pool_total = pool_total;
     P.work_counter = counter.p;
@@ -337,6 +338,11 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.cfg = cfg;
   e.device = cfg.device;
   e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane);
+  if (!e.geo.mem && cfg.state_in_lds > 0) {
+    if (!wn::lds_geometry_exists(e.geo.nw, e.geo.epl, cfg.state_in_lds))
+      throw std::invalid_argument("no LDS-state kernel for this geometry / waves-per-SIMD budget");
+    e.geo.lds_wpe = cfg.state_in_lds;
+  }
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
@@ -349,14 +355,16 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.pool_total = std::min(required_pool(cfg, e.geo.start_regs), wn::kMaxPool);
   int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo);
   wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
-  const size_t fixed = wn::transition_smem_bytes(e.geo.nw, 0, e.Dp);
+  e.lds_state = e.geo.lds_wpe > 0 ? 3 : 0;
+  const size_t fixed = wn::transition_smem_bytes(e.geo.nw, e.lds_state, e.Dp);
   const size_t budget = lds_per_cu / wg_per_cu;
   const size_t vec_bytes = sizeof(double) * e.Dp;
-  int lds_vecs = budget > fixed + 1024 ? static_cast<int>((budget - fixed - 1024) / vec_bytes) : 0;
+  if (fixed > budget) throw std::invalid_argument("workgroups_per_cu too high for the LDS-resident state");
+  int lds_vecs = budget > fixed + 256 ? static_cast<int>((budget - fixed - 256) / vec_bytes) : 0;
   if (cfg.lds_vectors >= 0 && cfg.lds_vectors < lds_vecs) lds_vecs = cfg.lds_vectors;
   if (e.geo.mem) lds_vecs = 0;  // streaming backend: vectors are far larger than LDS
   e.pool_lds = std::min(lds_vecs, e.pool_total);
-  e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds, e.Dp);
+  e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds + e.lds_state, e.Dp);
   const int usable_cus = std::max(1, e.num_cus - std::max(0, cfg.reserved_cus));
   e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(usable_cus) * wg_per_cu));
 
@@ -466,7 +474,7 @@ void wn_default_config(wn_config* c) {
   c->workgroups_per_cu = 0;
   c->lds_vectors = -1;
   c->reserved_cus = 0;
-  c->reserved0 = 0;
+  c->state_in_lds = 0;
 }
 
 int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params, size_t num_chains,

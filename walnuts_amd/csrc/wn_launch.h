@@ -3,6 +3,7 @@
 
 #include "wn_hip.h"
 
+#include <algorithm>
 #include <stdexcept>
 
 #include "wn_params.h"
@@ -14,11 +15,30 @@ struct InitParams;
 // NW wavefronts cooperate on one chain, each lane holds EPL elements of every vector:
 // padded dimension Dp = 64*NW*EPL.  START_REGS: the macro step's restart state stays in VGPRs.
 // `mem`: the streaming backend (TrajMem) -- vectors in HBM, any dimension; epl is 0 then.
+// `lds_wpe` > 0: the LDS_STATE register kernels (inverse mass + restart state in LDS), compiled for that many
+// wavefronts per SIMD.
 struct Geometry {
   int nw, epl;
   bool start_regs;
   bool mem;
+  int lds_wpe;
 };
+
+// X(NW, EPL, WPE)
+#if defined(WN_SIM_GEOMETRIES)
+#define WN_FOR_EACH_LDS_GEOMETRY(X) X(1, 2, 3)
+#elif defined(WN_FAST_BUILD)
+#define WN_FOR_EACH_LDS_GEOMETRY(X) X(2, 8, 3) X(4, 4, 3) X(4, 4, 4)
+#else
+#define WN_FOR_EACH_LDS_GEOMETRY(X) X(1, 8, 3) X(2, 4, 4) X(2, 8, 3) X(4, 4, 3) X(4, 4, 4) X(4, 8, 3) X(8, 4, 4) X(8, 8, 3)
+#endif
+inline bool lds_geometry_exists(int nw, int epl, int wpe) {
+#define WN_X(NW, EPL, WPE) \
+  if (nw == NW && epl == EPL && wpe == WPE) return true;
+  WN_FOR_EACH_LDS_GEOMETRY(WN_X)
+#undef WN_X
+  return false;
+}
 
 // X(NW) -- wavefronts per chain of the streaming kernels
 #if defined(WN_SIM_GEOMETRIES)
@@ -70,7 +90,7 @@ inline bool geometry_exists(int nw, int epl, bool* start_regs) {
 
 // elems_per_lane == -1 requests the streaming backend explicitly (it is the default above kMaxRegisterDim)
 inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
-  Geometry g{0, 0, true, false};
+  Geometry g{0, 0, true, false, 0};
   if (epl_req < 0 || (dim > kMaxRegisterDim && epl_req == 0)) {
     g.mem = true;
     g.nw = nw_req > 0 ? nw_req : default_mem_waves();
@@ -99,7 +119,7 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
 #define WN_X(NW, EPL, SR)                                  \
   if (64 * NW * EPL >= dim && 64 * NW * EPL < best) {      \
     best = 64 * NW * EPL;                                  \
-    g = Geometry{NW, EPL, SR, false};                      \
+    g = Geometry{NW, EPL, SR, false, 0};                   \
   }
   WN_FOR_EACH_GEOMETRY(WN_X)
 #undef WN_X
@@ -108,6 +128,7 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
 }
 
 inline int default_workgroups_per_cu(const Geometry& g) {
+  if (g.lds_wpe > 0) return std::max(1, 4 * g.lds_wpe / g.nw);  // fill the register budget the kernel was built for
   if (g.mem) return g.nw >= 16 ? 1 : 16 / g.nw;  // streaming: latency is hidden by resident waves
   return g.nw >= 8 ? 1 : 8 / g.nw;
 }

@@ -7,7 +7,12 @@ namespace wn {
 
 constexpr int kMaxLevels = 16;   // span-stack levels => max_trajectory_doublings <= 17
 constexpr int kMaxPool = 64;     // vector buffers per resident chain (free mask is 64 bits)
-constexpr int kMetaDoubles = 248; // per-wave scalar scratch kept in LDS (see Traj::Meta)
+constexpr int kDrawCache = 32;    // tree draws (and their logs) produced per refill, one per lane
+#if defined(WN_PHASE_PROFILE)
+constexpr int kMetaDoubles = 152; // per-wave scalar scratch kept in LDS (see TrajBase::Meta)
+#else
+constexpr int kMetaDoubles = 128;
+#endif
 
 enum ModelKind : int32_t { kStdNormal = 0, kDiagNormal = 1, kFunnel = 2 };
 enum RngMode : int32_t { kRngPhilox = 0, kRngBuffer = 1 };
@@ -66,6 +71,7 @@ struct Params {
   // scratch
   double* arena;         // [slots][pool_global][Dp]
   int64_t arena_stride;  // doubles per slot
+  int32_t lds_state;     // 0, or 3: inverse mass + restart theta/rho vectors kept in LDS (LDS_STATE kernels)
   int32_t pool_lds;      // vector buffers living in LDS
   int32_t pool_total;    // LDS + arena buffers
   uint32_t* work_counter;

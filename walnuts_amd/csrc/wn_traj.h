@@ -225,8 +225,8 @@ struct TrajBase {
     int in_th[kMaxLevels];
     int in_rh[kMaxLevels];
     int sel[kMaxLevels];
-    double u[64];   // tree draws draw_base .. draw_base+63 of this transition
-    double lu[64];  // their logarithms
+    double u[kDrawCache];   // tree draws draw_base .. draw_base+kDrawCache-1 of this transition
+    double lu[kDrawCache];  // their logarithms
 #if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
     unsigned long long prof[16];
     unsigned long long prof_last;
@@ -371,7 +371,7 @@ struct TrajBase {
   }
 
   // ---- randomness (util.hpp:102,112 order; counter-based stream or host-fed variates) ----
-  // The tree consumes wave-uniform scalars one at a time.  They are produced 64 at a time, lane j
+  // The tree consumes wave-uniform scalars one at a time.  They are produced kDrawCache at a time, lane j
   // computing draw number draw_base + j and its logarithm into the wave's LDS scratch, and handed out with
   // a broadcast LDS read.  (A v_readlane hand-out from registers was miscompiled by ROCm 7.2's backend:
   // after a refill the read used the stale register pair; caught by the bit-exact parity tests.)
@@ -385,13 +385,15 @@ struct TrajBase {
       u = wnd::stream_uniform(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamTree,
                               static_cast<uint32_t>(j));
     }
-    meta->u[lane] = u;
-    meta->lu[lane] = wnd::dlog(u);
+    if (lane < kDrawCache) {
+      meta->u[lane] = u;
+      meta->lu[lane] = wnd::dlog(u);
+    }
   }
   __device__ __forceinline__ int next_draw_slot() {
     const int j = uni(n_draw);
     ++n_draw;
-    if (draw_base < 0 || j - draw_base >= 64) refill_draws(j & ~63);
+    if (draw_base < 0 || j - draw_base >= kDrawCache) refill_draws(j & ~(kDrawCache - 1));
     return j - draw_base;
   }
   __device__ __forceinline__ double uniform01() { return uni(meta->u[next_draw_slot()]); }
@@ -670,25 +672,48 @@ struct TrajBase {
 // TrajReg: every vector of the moving end lives in VGPRs (EPL elements per lane), the span pool in LDS +
 // an HBM arena.  A leapfrog micro step touches no memory.
 // ---------------------------------------------------------------------------------------------------
-template <class Model, int NW, int EPL, bool START_REGS>
-struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
-  using Base = TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW>;
+// LDS_STATE: the inverse mass and the restart position / momentum live in three workgroup-private LDS vectors
+// instead of VGPRs (the whole span pool then sits in the HBM arena).  Measured: LDS-resident pool vectors buy
+// ~10 %, a third resident wavefront per SIMD buys more, and 48 fewer VGPRs is what makes it fit.
+template <class Model, int NW, int EPL, bool START_REGS, bool LDS_STATE = false>
+struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model, NW> {
+  using Base = TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model, NW>;
   using typename Base::Meta;
   using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::chain;
   using Base::Dp; using Base::aux; using Base::n_grad; using Base::max_error; using Base::min_micro;
   using Base::w_draw0; using Base::w_score0; using Base::meta;
   static constexpr int L = Base::L;
   static constexpr int NP = EPL / 2;
-  static constexpr bool kHasStartState = START_REGS;
+  static constexpr bool kHasStartState = START_REGS || LDS_STATE;
   static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
   double th0[EPL], rh0[EPL];  // restart state; its gradient is re-evaluated on a retry (a pure function of th0)
   int start_buf[3];
+  WN_LDS double* st_im;   // LDS_STATE: inverse mass / restart theta / restart rho vectors
+  WN_LDS double* st_th0;
+  WN_LDS double* st_rh0;
 
   __device__ __forceinline__ TrajReg(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
                                      WN_LDS double* bc, double* ar)
-      : Base(p, pool, m, r, bc, ar) {}
+      : Base(p, pool, m, r, bc, ar) {
+    // the state vectors sit in front of the LDS part of the pool (persistent_loop reserves them)
+    st_im = pool - 3 * p.dim_padded;
+    st_th0 = pool - 2 * p.dim_padded;
+    st_rh0 = pool - 1 * p.dim_padded;
+  }
+
+  // run f(inv_mass array): from VGPRs, or streamed out of LDS
+  template <class F>
+  __device__ __forceinline__ void with_im(F f) {
+    if (LDS_STATE) {
+      double t[EPL];
+      lds_load(st_im, t);
+      f(t);
+    } else {
+      f(im);
+    }
+  }
 
   // ---- model context -----------------------------------------------------------
   __device__ __forceinline__ int index(int j) const { return ((j >> 1) * L + tid) * 2 + (j & 1); }
@@ -748,8 +773,24 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
       case kTh: pool_store(b, th); break;
       case kRh: pool_store(b, rh); break;
       case kG: pool_store(b, g); break;
-      case kTh0: pool_store(b, th0); break;
-      default: pool_store(b, rh0); break;
+      case kTh0:
+        if (LDS_STATE) {
+          double t[EPL];
+          lds_load(st_th0, t);
+          pool_store(b, t);
+        } else {
+          pool_store(b, th0);
+        }
+        break;
+      default:
+        if (LDS_STATE) {
+          double t[EPL];
+          lds_load(st_rh0, t);
+          pool_store(b, t);
+        } else {
+          pool_store(b, rh0);
+        }
+        break;
     }
   }
   __device__ __forceinline__ void get(int b, Comp c) {
@@ -770,8 +811,10 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
   // joint log density of the moving end: logp_pos + logp_momentum (util.hpp:220-223)
   __device__ __forceinline__ void energy(double lp_partial, double& logp_pos, double& logp_joint) {
     double ke = 0.0;
+    with_im([&](const double (&m)[EPL]) {
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) ke += im[j] * (rh[j] * rh[j]);
+      for (int j = 0; j < EPL; ++j) ke += m[j] * (rh[j] * rh[j]);
+    });
     this->sum2(lp_partial, ke);
     // wave-uniform results go back to scalar registers: they live long and would otherwise hold VGPR pairs
     logp_pos = uni(Model::finish(lp_partial, aux, P.dim));
@@ -785,8 +828,10 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
     for (int s = 0; s < n; ++s) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) rh[j] += half * g[j];
+      with_im([&](const double (&m)[EPL]) {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) th[j] += h * im[j] * rh[j];
+        for (int j = 0; j < EPL; ++j) th[j] += h * m[j] * rh[j];
+      });
       part = model_eval();
 #pragma unroll
       for (int j = 0; j < EPL; ++j) rh[j] += half * g[j];
@@ -840,7 +885,10 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
 
   // the macro step's restart state (walnuts.hpp:324-326)
   __device__ __forceinline__ void macro_begin() {
-    if (START_REGS) {
+    if (LDS_STATE) {
+      lds_store(st_th0, th);
+      lds_store(st_rh0, rh);
+    } else if (START_REGS) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
         th0[j] = th[j];
@@ -853,11 +901,16 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
     }
   }
   __device__ __forceinline__ void macro_retry() {
-    if (START_REGS) {
+    if (LDS_STATE || START_REGS) {
+      if (LDS_STATE) {
+        lds_load(st_th0, th);
+        lds_load(st_rh0, rh);
+      } else {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        th[j] = th0[j];
-        rh[j] = rh0[j];
+        for (int j = 0; j < EPL; ++j) {
+          th[j] = th0[j];
+          rh[j] = rh0[j];
+        }
       }
       // the restart gradient is a pure function of the restart position: same bits as the copy the
       // reference keeps (walnuts.hpp:326), without holding a third vector for the rare retry
@@ -877,17 +930,27 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
     double p_hot = 0.0, p_far = 0.0;
     // a - th == -(th - a) exactly: one subtraction, then a wave-uniform sign flip on the high word
     const uint64_t flip = fwd ? 0ull : 0x8000000000000000ull;
+    with_im([&](const double (&m)[EPL]) {
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      const double diff = wnd::as_f64(wnd::as_u64(th[j] - a[j]) ^ flip);
-      const double sd = im[j] * diff;
-      p_hot += rh[j] * sd;
-      p_far += b[j] * sd;
-    }
+      for (int j = 0; j < EPL; ++j) {
+        const double diff = wnd::as_f64(wnd::as_u64(th[j] - a[j]) ^ flip);
+        const double sd = m[j] * diff;
+        p_hot += rh[j] * sd;
+        p_far += b[j] * sd;
+      }
+    });
     this->sum2(p_hot, p_far);
     return p_hot < 0 || p_far < 0;
   }
-  __device__ __forceinline__ bool uturn_start(bool fwd) { return uturn_vectors(th0, rh0, fwd); }
+  __device__ __forceinline__ bool uturn_start(bool fwd) {
+    if (LDS_STATE) {
+      double a[EPL], b[EPL];
+      lds_load(st_th0, a);
+      lds_load(st_rh0, b);
+      return uturn_vectors(a, b, fwd);
+    }
+    return uturn_vectors(th0, rh0, fwd);
+  }
   __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
     double a[EPL], b[EPL];
     pool_load(bth, a);
@@ -930,7 +993,8 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS>, Model, NW> {
         rh[2 * k + 1] = valid(2 * k + 1) ? chol[2 * k + 1] * z1 : 0.0;
       }
     }
-    if (!START_REGS) {
+    if (LDS_STATE) lds_store(st_im, im);
+    if (!START_REGS && !LDS_STATE) {
       start_buf[0] = this->alloc_cold();
       start_buf[1] = this->alloc_cold();
       start_buf[2] = this->alloc_cold();
@@ -1248,8 +1312,9 @@ constexpr int kMemScratchVectors = 10;  // TrajMem: cur 3 + alt 3 + work 3 + inv
 template <class T, int NW>
 __device__ __forceinline__ void persistent_loop(const Params& P) {
   WN_DYN_SMEM(smem);
-  // layout: [pool_lds * Dp] vectors | per-wave Meta | reduction scratch | broadcast word
-  WN_LDS double* pool = (WN_LDS double*)smem;
+  // layout: [lds_state * Dp] state vectors | [pool_lds * Dp] pool vectors | per-wave Meta | reduction scratch |
+  // broadcast word
+  WN_LDS double* pool = (WN_LDS double*)smem + P.lds_state * P.dim_padded;
   WN_LDS double* tail = pool + P.pool_lds * P.dim_padded;
   WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(tail + (threadIdx.x >> 6) * kMetaDoubles);
   WN_LDS double* red = tail + NW * kMetaDoubles;
@@ -1287,6 +1352,12 @@ __global__ __launch_bounds__(64 * NW) void transition_kernel(const Params P) {
   persistent_loop<TrajReg<Model, NW, EPL, START_REGS>, NW>(P);
 }
 
+// the LDS_STATE variant: register budget for WPE wavefronts per SIMD
+template <class Model, int NW, int EPL, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void transition_kernel_lds(const Params P) {
+  persistent_loop<TrajReg<Model, NW, EPL, true, true>, NW>(P);
+}
+
 template <class Model, int NW>
 __global__ __launch_bounds__(64 * NW) void transition_kernel_mem(const Params P) {
   persistent_loop<TrajMem<Model, NW>, NW>(P);
@@ -1296,8 +1367,8 @@ __global__ __launch_bounds__(64 * NW) void transition_kernel_mem(const Params P)
 template <class Model, int NW, int EPL, bool START_REGS>
 using Traj = TrajReg<Model, NW, EPL, START_REGS>;
 
-inline size_t transition_smem_bytes(int nw, int pool_lds, int dim_padded) {
-  return (static_cast<size_t>(pool_lds) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + 4 * nw + 2) *
+inline size_t transition_smem_bytes(int nw, int lds_vectors, int dim_padded) {
+  return (static_cast<size_t>(lds_vectors) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + 4 * nw + 2) *
          sizeof(double);
 }
 

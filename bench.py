@@ -48,6 +48,8 @@ def parse():
                     help="CUs left free for the RCCL all-gather kernels (default: 0 on one GPU, 16 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (gloo only to exercise the N>1 code path when ranks share one GPU)")
     ap.add_argument("--phase", default="sampling", choices=["sampling", "warmup"],
                     help="which transition kind is timed")
     return ap.parse_args()
@@ -120,13 +122,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     D, C = args.dim, args.chains
     model_id, params = model_setup(args.model, D)
@@ -220,7 +226,7 @@ def main():
                             f"{args.adapt_iters} on-device adaptive warmup transitions then timed {args.phase} transitions",
                 "chains_per_gpu": C, "global_chains": C * world, "dim": D, "model": args.model,
                 "phase": args.phase, "parallelism": f"chains sharded over {world} GPU(s)"
-                                                    + (", RCCL all-gather of draws each step" if world > 1 else ""),
+                                                    + (f", {'RCCL' if args.backend == 'nccl' else 'gloo'} all-gather of draws each step" if world > 1 else ""),
                 "geometry": {"lanes_per_chain": eng.lanes, "dim_padded": eng.dim_padded,
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
                              "reserved_cus": reserved},

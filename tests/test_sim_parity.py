@@ -117,6 +117,43 @@ def test_emulated_sample_device_contract(sim):
         wa.walnuts_device(wa.MODEL_STD_NORMAL, **{**kw, "refresh": -1})
 
 
+def test_engine_argument_and_state_errors(sim):
+    """Error typing of the C ABI: std::invalid_argument -> config (ValueError), anything else -> generic
+    (RuntimeError), as python/src/walnutpie/errors.hpp:42-72 and _ffi.py:195-215 map them."""
+    mk = lambda *a, **k: wa.DeviceEngine(*a, lib_path=sim, **k)
+    with pytest.raises(ValueError, match="num_params"):
+        mk(wa.MODEL_STD_NORMAL, 0, 2, wa.default_config(sim))
+    with pytest.raises(ValueError, match="num_chains"):
+        mk(wa.MODEL_STD_NORMAL, 3, 0, wa.default_config(sim))
+    with pytest.raises(ValueError, match="model"):
+        mk(17, 3, 2, wa.default_config(sim))
+    with pytest.raises(ValueError, match="sigma_sq"):
+        mk(wa.MODEL_DIAG_NORMAL, 3, 2, wa.default_config(sim))
+    with pytest.raises(ValueError, match="funnel"):
+        mk(wa.MODEL_FUNNEL, 1, 2, wa.default_config(sim))
+    with pytest.raises(ValueError, match="max_hamiltonian_error"):
+        mk(wa.MODEL_STD_NORMAL, 3, 2, wa.default_config(sim, max_hamiltonian_error=-1.0))
+    with pytest.raises(ValueError, match="max_nuts_depth|max_trajectory_doublings"):
+        mk(wa.MODEL_STD_NORMAL, 3, 2, wa.default_config(sim, max_trajectory_doublings=0))
+    with pytest.raises(ValueError, match="streaming"):
+        mk(wa.MODEL_FUNNEL, 40, 2, wa.default_config(sim, elems_per_lane=-1))   # no streaming kernel for the funnel
+    e = mk(wa.MODEL_STD_NORMAL, 3, 2, wa.default_config(sim))
+    with pytest.raises(ValueError, match="masses must be positive"):
+        e.set_masses(np.array([[1.0, 0.0, 1.0], [1.0, 1.0, 1.0]]))
+    with pytest.raises(ValueError, match="step size"):
+        e.set_step_sizes([0.1, float("inf")])
+    with pytest.raises(ValueError, match="mass_smoothing"):
+        e.init_masses_from_grad(1.5)
+    with pytest.raises(RuntimeError, match="before freeze"):
+        e.sample_step()
+    with pytest.raises(RuntimeError, match="after freeze"):
+        e.inv_mass()
+    e.freeze()
+    with pytest.raises(RuntimeError, match="after freeze"):
+        e.warmup_step()
+    assert e.inv_mass().shape == (2, 3)
+
+
 def test_emulated_sample_device_output_buffer_check(sim):
     lib = wa.load_library(sim)
     out = np.zeros(10)

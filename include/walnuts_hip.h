@@ -130,6 +130,11 @@ WALNUTS_HIP_EXPORT int wn_engine_set_step_sizes(wn_engine* e, const double* step
 WALNUTS_HIP_EXPORT int wn_engine_init_positions(wn_engine* e, uint64_t seed, uint32_t chain_offset, double scale,
                                                 WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_init_masses_from_grad(wn_engine* e, double smoothing, WalnutpyError** err);
+/* InitConfigBuilder::masses(logp_grad, s, average_masses = true) (config.hpp:371-380): after
+ * wn_engine_init_masses_from_grad (or set_masses), replace every chain's masses by their geometric mean over the
+ * chains of this engine. */
+WALNUTS_HIP_EXPORT int wn_engine_average_masses(wn_engine* e, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_get_masses(wn_engine* e, double* out /*[C*D]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_adapt_step(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyError** err);
 /* the same step-size search with the momentum normals [C*D] supplied by the host (lets a caller feed the
  * reference's own mt19937_64(seed_seq{seed,2}) stream, walnutpy.cpp:75-80) */

@@ -904,6 +904,9 @@ void wno_get_step_sizes(const wno_engine* e, double* out) {
     out[c] = ch.frozen ? ch.step : (e->adapt_ready ? ch.adam.step_size() : ch.step_init);
   }
 }
+void wno_get_masses(const wno_engine* e, double* out) {  // InitConfig::mass(m), config.hpp:74-120
+  for (size_t c = 0; c < e->C; ++c) std::copy(e->chains[c].mass.begin(), e->chains[c].mass.end(), out + c * e->D);
+}
 void wno_get_inv_mass(const wno_engine* e, double* out) {
   for (size_t c = 0; c < e->C; ++c) {
     const auto& ch = e->chains[c];

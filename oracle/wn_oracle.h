@@ -99,6 +99,7 @@ void wno_get_positions(const wno_engine* e, double* out /*[C*D]*/);
 void wno_get_grad_select(const wno_engine* e, double* out /*[C*D]*/);
 void wno_get_logp(const wno_engine* e, double* out /*[C]*/);
 void wno_get_step_sizes(const wno_engine* e, double* out /*[C]*/);
+void wno_get_masses(const wno_engine* e, double* out /*[C*D]*/);
 void wno_get_inv_mass(const wno_engine* e, double* out /*[C*D]*/);
 void wno_get_min_micro(const wno_engine* e, int64_t* out /*[C]*/);
 void wno_get_depths(const wno_engine* e, int32_t* out /*[C]*/);

@@ -71,7 +71,7 @@ def lib():
     L.wno_destroy.argtypes = [vp]
     L.wno_set_rng_mode.argtypes = [vp, i32]
     for name in ("wno_set_positions", "wno_set_masses", "wno_set_step_sizes", "wno_get_positions",
-                 "wno_get_grad_select", "wno_get_logp", "wno_get_step_sizes", "wno_get_inv_mass", "wno_get_adam"):
+                 "wno_get_grad_select", "wno_get_logp", "wno_get_step_sizes", "wno_get_inv_mass", "wno_get_masses", "wno_get_adam"):
         getattr(L, name).argtypes = [vp, _dp]
     L.wno_init_positions.argtypes = [vp, u64, u64, dbl]
     L.wno_init_masses_from_grad.argtypes = [vp, dbl, i32]
@@ -218,6 +218,9 @@ class Engine:
 
     def inv_mass(self):
         return self._vec(self.L.wno_get_inv_mass, (self.C, self.D))
+
+    def masses(self):
+        return self._vec(self.L.wno_get_masses, (self.C, self.D))
 
     def adam(self):
         return self._vec(self.L.wno_get_adam, (self.C, 6))

@@ -79,7 +79,7 @@ def assert_same_state(dev, orc, where: str, warm: bool):
 
 
 def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path=None, geometry=None, seed=1234,
-             init="random", step=None, check_every=1, **cfg_over):
+             init="random", step=None, check_every=1, average_masses=False, **cfg_over):
     """InitConfigBuilder -> warmup -> freeze -> sampling on both sides, bit-compared along the way."""
     dev, orc = make_pair(model, D, C, lib_path, geometry, **cfg_over)
     rng = np.random.default_rng(seed)
@@ -92,8 +92,10 @@ def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path
         orc.init_positions(seed, 7, 2.0)
         dev.synchronize()
         assert np.array_equal(dev.positions(), orc.positions()), "init positions differ"
-    dev.init_masses_from_grad(1e-5)
-    orc.init_masses_from_grad(1e-5)
+    dev.init_masses_from_grad(1e-5, average_masses)
+    orc.init_masses_from_grad(1e-5, average_masses)
+    dev.synchronize()
+    assert np.array_equal(dev.masses(), orc.masses()), "init masses differ"
     for x in (dev, orc):
         x.set_step_sizes(1.0 if step is None else step)
     if step is None:

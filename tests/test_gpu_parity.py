@@ -153,6 +153,12 @@ def test_device_side_initialisation_matches_oracle():
     parity.run_case("funnel", 64, 40, warmup=3, sampling=2, init="device")
 
 
+def test_averaged_initial_masses_match_oracle():
+    # InitConfigBuilder::masses(logp_grad, s, average_masses=true), config.hpp:371-380 (also streaming backend)
+    parity.run_case("diag_normal", 300, 48, warmup=3, sampling=2, init="device", average_masses=True)
+    parity.run_case("diag_normal", 9000, 5, warmup=2, sampling=1, init="device", average_masses=True)
+
+
 def test_ill_conditioned_config2_long_warmup():
     # sigma_d = d+1 (examples/examples.cpp:20-31), D=1024: the config #2 model on a chain subset
     D, C = 1024, 32

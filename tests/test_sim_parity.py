@@ -47,6 +47,12 @@ def test_emulated_engine_lds_pool_and_arena_paths(sim, oracle):
 
 
 @pytest.mark.timeout(600)
+def test_emulated_engine_averaged_init_masses(sim, oracle):
+    # InitConfigBuilder::masses(logp_grad, s, average_masses=true), config.hpp:371-380
+    dev, orc = parity.run_case("diag_normal", 7, 3, warmup=2, sampling=1, lib_path=sim, average_masses=True)
+
+
+@pytest.mark.timeout(600)
 def test_emulated_engine_halving_and_reversibility(sim, oracle):
     # an oversized fixed step forces step halvings and reversibility re-integrations (walnuts.hpp:254-279)
     dev, orc = parity.run_case("std_normal", 6, 2, warmup=0, sampling=4, lib_path=sim, step=3.5,

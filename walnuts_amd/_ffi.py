@@ -64,6 +64,8 @@ SYMBOLS = [
     ("wn_engine_set_step_sizes", _i32, [_vp, _dp, _errpp]),
     ("wn_engine_init_positions", _i32, [_vp, _u64, _u32, _dbl, _errpp]),
     ("wn_engine_init_masses_from_grad", _i32, [_vp, _dbl, _errpp]),
+    ("wn_engine_average_masses", _i32, [_vp, _errpp]),
+    ("wn_engine_get_masses", _i32, [_vp, _dp, _errpp]),
     ("wn_engine_adapt_step", _i32, [_vp, _u64, _u32, _errpp]),
     ("wn_engine_adapt_step_with_normals", _i32, [_vp, _dp, _errpp]),
     ("wn_engine_seed", _i32, [_vp, _u64, _u32, _errpp]),

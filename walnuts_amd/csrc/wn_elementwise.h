@@ -120,6 +120,23 @@ static __global__ void log_mass_colsum_kernel(int C, int D, int Dp, const double
   }
   colsum[d] = s;
 }
+// InitConfigBuilder::masses(..., average_masses = true), config.hpp:371-380: every chain's mass becomes the
+// geometric mean over chains.  Thread per column; chains summed in order.
+static __global__ void mass_log_colsum_kernel(int C, int D, int Dp, const double* mass, double* colsum) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  double s = 0.0;
+  for (int c = 0; c < C; ++c) s += wnd::dlog(mass[static_cast<long long>(c) * Dp + d]);
+  colsum[d] = wnd::dexp(s / static_cast<double>(C));
+}
+static __global__ void mass_broadcast_kernel(int C, int D, int Dp, const double* geom_mean, double* mass) {
+  const long long n = static_cast<long long>(C) * Dp;
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int d = static_cast<int>(i % Dp);
+    if (d < D) mass[i] = geom_mean[d];
+  }
+}
 // per-chain l2_rel_diff(mass_m, geom_mean_mass) (util.hpp:379-382) and rel diff of the step; block per chain
 static __global__ void warmup_spread_kernel(int C, int D, int Dp, const double* draw_ssd, const double* score_ssd,
                                             const double* est_weight, const double* adam, const double* colsum,

@@ -522,6 +522,22 @@ int wn_engine_init_masses_from_grad(wn_engine* e, double smoothing, WalnutpyErro
     run_init(*e, false, true, false, 1.0, smoothing, 0, 0, 0, 0);
   });
 }
+int wn_engine_average_masses(wn_engine* e, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    const int C = static_cast<int>(e->C);
+    hipLaunchKernelGGL(wn::mass_log_colsum_kernel, dim3((e->D + 255) / 256), dim3(256), 0, e->stream, C, e->D, e->Dp,
+                       e->mass.p, e->mon_colsum.p);
+    const int blocks = static_cast<int>(std::min<size_t>((e->C * e->Dp + 255) / 256, 4096));
+    hipLaunchKernelGGL(wn::mass_broadcast_kernel, dim3(blocks), dim3(256), 0, e->stream, C, e->D, e->Dp,
+                       e->mon_colsum.p, e->mass.p);
+    HIP_OK(hipGetLastError());
+    e->adapters_ready = false;
+  });
+}
+int wn_engine_get_masses(wn_engine* e, double* out, WalnutpyError** err) {
+  return guarded(err, [&] { e->download_rows(e->mass, out); });
+}
 int wn_engine_adapt_step(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyError** err) {
   return guarded(err, [&] { run_init(*e, false, false, true, 1.0, 0.0, 0, 0, seed, chain_offset); });
 }

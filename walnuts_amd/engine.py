@@ -78,8 +78,11 @@ class DeviceEngine:
     def init_positions(self, seed: int, chain_offset: int, scale: float):
         self._call(self.lib.wn_engine_init_positions, seed, chain_offset, scale)
 
-    def init_masses_from_grad(self, smoothing: float):
+    def init_masses_from_grad(self, smoothing: float, average: bool = False):
+        """InitConfigBuilder::masses(logp_grad, smoothing, average_masses) (config.hpp:360-382)."""
         self._call(self.lib.wn_engine_init_masses_from_grad, smoothing)
+        if average:
+            self._call(self.lib.wn_engine_average_masses)
 
     def adapt_step(self, seed: int, chain_offset: int = 0):
         self._call(self.lib.wn_engine_adapt_step, seed, chain_offset)
@@ -126,6 +129,9 @@ class DeviceEngine:
 
     def positions(self):
         return self._get(self.lib.wn_engine_get_positions, (self.C, self.D))
+
+    def masses(self):
+        return self._get(self.lib.wn_engine_get_masses, (self.C, self.D))
 
     def inv_mass(self):
         return self._get(self.lib.wn_engine_get_inv_mass, (self.C, self.D))

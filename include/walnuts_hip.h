@@ -166,6 +166,8 @@ WALNUTS_HIP_EXPORT int wn_engine_check(wn_engine* e, WalnutpyError** err);
 
 /* state -> host buffers */
 WALNUTS_HIP_EXPORT int wn_engine_get_positions(wn_engine* e, double* out /*[C*D]*/, WalnutpyError** err);
+/* after freeze: the sampler's inverse masses (walnuts.hpp:703-728); before: AdaptiveWalnuts::inv_mass(), the
+ * estimate the next warmup transition integrates with (adaptive_walnuts.hpp:89-94) */
 WALNUTS_HIP_EXPORT int wn_engine_get_inv_mass(wn_engine* e, double* out /*[C*D]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_step_sizes(wn_engine* e, double* out /*[C]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_logp(wn_engine* e, double* out /*[C]*/, WalnutpyError** err);

@@ -69,6 +69,7 @@ def assert_same_state(dev, orc, where: str, warm: bool):
             checks.append(("estimator." + k, de[k], oe[k]))
         checks.append(("min_micro", dev.min_micro(), orc.min_micro()))
         checks.append(("step_sizes", dev.step_sizes(), orc.step_sizes()))
+        checks.append(("inv_mass estimate", dev.inv_mass(), orc.inv_mass()))
     for name, a, b in checks:
         a, b = np.asarray(a), np.asarray(b)
         if not np.array_equal(a, b.astype(a.dtype) if a.dtype != b.dtype else b):

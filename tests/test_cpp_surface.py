@@ -1,0 +1,106 @@
+"""include/walnuts_hip.hpp -- the C++ mirror of the reference's surface for the many-chain path (SURVEY.md §8b:
+batched AdaptiveWalnuts / WalnutsSampler, per-chain Sampler views, handler callbacks, config builders, the
+top-level walnuts() call).  tests/cpp/cpp_surface.cpp exercises the contracts in C++ and dumps what the handlers
+saw; here the dump is compared bit for bit with the oracle run through the same recipe.
+
+CPU tier: linked against the workgroup emulation.  GPU tier: linked against libwalnuts_hip.so."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "cpusim"))
+import parity  # noqa: E402
+
+wno = parity.wno
+
+
+def build_program(lib_path: str, tag: str) -> str:
+    exe = os.path.join(HERE, "cpp", f"cpp_surface_{tag}")
+    src = os.path.join(HERE, "cpp", "cpp_surface.cpp")
+    hdrs = [os.path.join(ROOT, "include", h) for h in ("walnuts_hip.hpp", "walnuts_hip.h")]
+    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(f) for f in [src, lib_path] + hdrs):
+        return exe
+    libdir, libname = os.path.split(lib_path)
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           src, "-o", exe, lib_path, f"-Wl,-rpath,{libdir}", "-pthread"])
+    return exe
+
+
+def run_and_compare(exe: str, lib_path: str, model: str, C: int, D: int, W: int, S: int, seed: int, tmp_path):
+    dump = str(tmp_path / "dump.bin")
+    r = subprocess.run([exe, model, str(C), str(D), str(W), str(S), str(seed), dump], capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cpp surface ok" in r.stdout
+    raw = np.fromfile(dump, dtype=np.float64)
+    per_chain = W * D + W + W + W * D + 1 + D + S * D + S
+    n_rhat = 1 if (C > 1 and S >= 2) else 0
+    assert raw.size == C * per_chain + n_rhat
+    got = []
+    for c in range(C):
+        r0 = raw[c * per_chain:(c + 1) * per_chain]
+        o = 0
+        rec = {}
+        for name, n, shape in (("warmup_draws", W * D, (W, D)), ("warmup_lp", W, (W,)), ("warmup_step", W, (W,)),
+                               ("warmup_inv_mass", W * D, (W, D)), ("final_step", 1, ()), ("final_inv_mass", D, (D,)),
+                               ("draws", S * D, (S, D)), ("lp", S, (S,))):
+            rec[name] = r0[o:o + n].reshape(shape)
+            o += n
+        got.append(rec)
+
+    # the same recipe on the oracle (device arithmetic order): InitConfigBuilder verbs, then api.hpp:46-69
+    _, om = parity.MODELS[model]
+    from walnuts_amd import _ffi
+    lanes = _ffi.load_library(lib_path).wn_lanes_for_dim(D, 0, 0)   # reduction width of the default geometry
+    cfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_PORTABLE, reduce_lanes=lanes)
+    o = wno.Engine(om, D, C, cfg, params=parity.model_params(model, D))
+    o.init_positions(seed + 5, 0, 2.0)
+    o.init_masses_from_grad(1e-5)
+    o.set_step_sizes(1.0)
+    o.adapt_step(seed + 6, 0)
+    o.seed_chains(seed, 0)
+    for it in range(W):
+        im = o.inv_mass()                       # inverse masses the transition integrates with
+        o.warmup_step(8)
+        pos, lp, st = o.positions(), o.logp(), o.step_sizes()
+        for c in range(C):
+            assert np.array_equal(got[c]["warmup_draws"][it], pos[c]), f"warmup draw it={it} chain={c}"
+            assert got[c]["warmup_lp"][it] == lp[c]
+            assert got[c]["warmup_step"][it] == st[c], "on_warmup step size is the post-update one"
+            assert np.array_equal(got[c]["warmup_inv_mass"][it], im[c]), "on_warmup inverse mass is the pre-transition one"
+    o.freeze()
+    st, im = o.step_sizes(), o.inv_mass()
+    for c in range(C):
+        assert got[c]["final_step"] == st[c] and np.array_equal(got[c]["final_inv_mass"], im[c])
+    for it in range(S):
+        o.sample_step(8)
+        pos, lp = o.positions(), o.logp()
+        for c in range(C):
+            assert np.array_equal(got[c]["draws"][it], pos[c]), f"draw it={it} chain={c}"
+            assert got[c]["lp"][it] == lp[c]
+    if n_rhat:
+        assert raw[-1] == pytest.approx(o.rhat(), rel=1e-12)
+
+
+@pytest.mark.timeout(1800)
+def test_cpp_surface_under_emulation(oracle, tmp_path):
+    import build as simbuild
+    sim = simbuild.build()
+    exe = build_program(sim, "sim")
+    run_and_compare(exe, sim, "diag_normal", 2, 5, 3, 2, 77, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("model,C,D,W,S", [("std_normal", 64, 1024, 12, 8), ("funnel", 40, 128, 12, 8),
+                                           ("diag_normal", 6, 9000, 6, 4)])
+def test_cpp_surface_on_gpu(oracle, tmp_path, model, C, D, W, S):
+    from walnuts_amd import _ffi
+    _ffi.load_library()
+    exe = build_program(_ffi.DEFAULT_LIB, "hip")
+    run_and_compare(exe, _ffi.DEFAULT_LIB, model, C, D, W, S, 4242, tmp_path)

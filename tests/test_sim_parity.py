@@ -152,8 +152,9 @@ def test_engine_argument_and_state_errors(sim):
         e.init_masses_from_grad(1.5)
     with pytest.raises(RuntimeError, match="before freeze"):
         e.sample_step()
-    with pytest.raises(RuntimeError, match="after freeze"):
-        e.inv_mass()
+    e.set_masses(np.array([[4.0, 1.0, 0.25], [1.0, 1.0, 1.0]]))
+    # AdaptiveWalnuts::inv_mass() before any observation: sqrt((1/m)/m), adaptive_walnuts.hpp:54-62,89-94
+    assert np.allclose(e.inv_mass(), [[0.25, 1.0, 4.0], [1.0, 1.0, 1.0]], rtol=1e-15)
     e.freeze()
     with pytest.raises(RuntimeError, match="after freeze"):
         e.warmup_step()

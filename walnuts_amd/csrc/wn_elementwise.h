@@ -56,10 +56,26 @@ static __global__ void freeze_kernel(int C, int Dp, const double* draw_ssd, cons
   }
 }
 
+// AdaptiveWalnuts::inv_mass() during warmup (adaptive_walnuts.hpp:89-94, :297-299): the estimate the NEXT warmup
+// transition will integrate with, written to the (otherwise idle before freeze) inverse-mass plane
+static __global__ void inv_mass_estimate_kernel(int C, int Dp, const double* draw_ssd, const double* score_ssd,
+                                                const double* est_weight, double* inv_mass) {
+  const long long n = static_cast<long long>(C) * Dp;
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long c = i / Dp;
+    inv_mass[i] = __builtin_sqrt((draw_ssd[i] / est_weight[2 * c]) / (score_ssd[i] / est_weight[2 * c + 1]));
+  }
+}
+
 // ---- cross-chain monitors (the reference's controller loops) --------------------------------------
 // Deterministic two-stage sums: stage 1 gives every block a contiguous slice and a fixed tree inside the
 // block, stage 2 (one block) adds the block partials left to right.
+#ifdef WN_CPU_SIM
+constexpr int kMonitorBlocks = 2;  // the emulation pays one OS thread per lane: keep its launches small
+#else
 constexpr int kMonitorBlocks = 256;
+#endif
 
 template <int K, class F>
 static __device__ void block_partial_sums(int n, F f, double* partial /*[gridDim][K]*/) {

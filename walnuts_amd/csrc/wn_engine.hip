@@ -643,7 +643,14 @@ int wn_engine_get_positions(wn_engine* e, double* out, WalnutpyError** err) {
 }
 int wn_engine_get_inv_mass(wn_engine* e, double* out, WalnutpyError** err) {
   return guarded(err, [&] {
-    if (!e->frozen) throw std::runtime_error("inverse mass is available after freeze");
+    if (!e->frozen) {
+      e->ensure_adapters();
+      e->use_device();
+      const int blocks = static_cast<int>(std::min<size_t>((e->C * e->Dp + 255) / 256, 4096));
+      hipLaunchKernelGGL(wn::inv_mass_estimate_kernel, dim3(blocks), dim3(256), 0, e->stream, static_cast<int>(e->C),
+                         e->Dp, e->draw_ssd.p, e->score_ssd.p, e->est_weight.p, e->inv_mass.p);
+      HIP_OK(hipGetLastError());
+    }
     e->download_rows(e->inv_mass, out);
   });
 }

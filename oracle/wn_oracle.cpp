@@ -907,15 +907,17 @@ void wno_get_step_sizes(const wno_engine* e, double* out) {
 void wno_get_masses(const wno_engine* e, double* out) {  // InitConfig::mass(m), config.hpp:74-120
   for (size_t c = 0; c < e->C; ++c) std::copy(e->chains[c].mass.begin(), e->chains[c].mass.end(), out + c * e->D);
 }
-void wno_get_inv_mass(const wno_engine* e, double* out) {
+// WalnutsSampler::inverse masses after freeze; before, AdaptiveWalnuts::inv_mass() = the estimator's current
+// estimate (adaptive_walnuts.hpp:89-94,297-299), which for a fresh adapter is sqrt((1/m)/m), not 1/m bit for bit
+void wno_get_inv_mass(const wno_engine* ce, double* out) {
+  wno_engine* e = const_cast<wno_engine*>(ce);
+  if (!e->chains.empty() && !e->chains[0].frozen) e->ensure_adapters();
   for (size_t c = 0; c < e->C; ++c) {
     const auto& ch = e->chains[c];
     if (ch.frozen) {
       std::copy(ch.inv_mass.begin(), ch.inv_mass.end(), out + c * e->D);
-    } else if (e->adapt_ready) {
-      ch.est.inv_mass(out + c * e->D);
     } else {
-      for (size_t i = 0; i < e->D; ++i) out[c * e->D + i] = 1.0 / ch.mass[i];
+      ch.est.inv_mass(out + c * e->D);
     }
   }
 }

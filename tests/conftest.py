@@ -19,3 +19,16 @@ def oracle():
 
     wno.build()
     return wno
+
+
+@pytest.fixture(scope="session")
+def gpu(oracle):
+    """GPU tier set-up.  torch first: it brings its own copy of the HIP runtime, and a process must not end up with
+    two of them (the second one finds no device) -- once torch's is loaded, libwalnuts_hip.so binds to the same."""
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tier needs a GPU"
+    import walnuts_amd as wa
+
+    wa.load_library()  # the in-tree HIP extension, or raise
+    return wa

@@ -1,8 +1,9 @@
 // Test program for include/walnuts_hip.hpp (the C++ mirror of the reference's surface for the many-chain path).
-// Built by tests/test_cpp_surface.py with g++ and linked against the library under test: the CPU workgroup
-// emulation (CPU tier) or libwalnuts_hip.so (GPU tier).  Usage:
-//   cpp_surface <model: std_normal|diag_normal|funnel> <chains> <dims> <warmup> <sampling> <seed> <dump-file>
-// Runs walnuts_hip::walnuts() with recording handlers (the reference's examples/handlers.hpp ChainStore, restated),
+// Built with g++ as a shared library linked against the library under test -- the CPU workgroup emulation (CPU
+// tier, tests/test_cpp_surface.py builds it) or libwalnuts_hip.so (GPU tier, __graft_entry__.build() builds it so
+// that nothing has to be spawned on the GPU box) -- and called in-process through
+//   int cpp_surface_run(model: std_normal|diag_normal|funnel, chains, dims, warmup, sampling, seed, dump-file)
+// (with -DCPP_SURFACE_MAIN also a command-line program with the same arguments).  Runs walnuts_hip::walnuts() with recording handlers (the reference's examples/handlers.hpp ChainStore, restated),
 // checks the surface's contracts, and writes everything the handlers saw to <dump-file> as raw doubles so that the
 // Python side can compare it bit for bit with the oracle.
 #include <cstdio>
@@ -94,15 +95,11 @@ static void put(std::ofstream& out, const std::vector<double>& v) {
   out.write(reinterpret_cast<const char*>(v.data()), static_cast<std::streamsize>(v.size() * sizeof(double)));
 }
 
-int main(int argc, char** argv) {
-  if (argc != 8) {
-    std::fprintf(stderr, "usage: %s model chains dims warmup sampling seed dump\n", argv[0]);
-    return 2;
-  }
-  const std::string model_name = argv[1];
-  const std::size_t C = std::strtoul(argv[2], nullptr, 10), D = std::strtoul(argv[3], nullptr, 10);
-  const std::size_t W = std::strtoul(argv[4], nullptr, 10), S = std::strtoul(argv[5], nullptr, 10);
-  const std::size_t seed = std::strtoul(argv[6], nullptr, 10);
+extern "C" __attribute__((visibility("default"))) int cpp_surface_run(const char* model_name_c, std::size_t C,
+                                                                       std::size_t D, std::size_t W, std::size_t S,
+                                                                       std::size_t seed, const char* dump_path) try {
+  failures = 0;
+  const std::string model_name = model_name_c;
   const wh::DeviceModel model = make_model(model_name, D);
 
   // ---- configuration classes: defaults and checks of config.hpp ------------------------------------------
@@ -231,7 +228,7 @@ int main(int argc, char** argv) {
   }
 
   // ---- dump for the oracle comparison -----------------------------------------------------------------------
-  std::ofstream out(argv[7], std::ios::binary);
+  std::ofstream out(dump_path, std::ios::binary);
   for (const ChainStore& s : stores) {
     put(out, s.warmup_draws);
     put(out, s.warmup_lp);
@@ -248,6 +245,21 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "%d expectation(s) failed\n", failures);
     return 1;
   }
-  std::puts("cpp surface ok");
   return 0;
+} catch (const std::exception& e) {
+  std::fprintf(stderr, "cpp_surface_run: unexpected exception: %s\n", e.what());
+  return 3;
 }
+
+#ifdef CPP_SURFACE_MAIN
+int main(int argc, char** argv) {
+  if (argc != 8) {
+    std::fprintf(stderr, "usage: %s model chains dims warmup sampling seed dump\n", argv[0]);
+    return 2;
+  }
+  const auto n = [&](int i) { return static_cast<std::size_t>(std::strtoul(argv[i], nullptr, 10)); };
+  const int rc = cpp_surface_run(argv[1], n(2), n(3), n(4), n(5), n(6), argv[7]);
+  if (rc == 0) std::puts("cpp surface ok");
+  return rc;
+}
+#endif

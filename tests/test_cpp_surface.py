@@ -19,24 +19,31 @@ import parity  # noqa: E402
 wno = parity.wno
 
 
-def build_program(lib_path: str, tag: str) -> str:
-    exe = os.path.join(HERE, "cpp", f"cpp_surface_{tag}")
+def surface_library(tag: str) -> str:
+    return os.path.join(HERE, "cpp", f"libcpp_surface_{tag}.so")
+
+
+def build_surface_library(lib_path: str, tag: str) -> str:
+    """g++ the C++ test into a shared library linked against `lib_path` (also called by __graft_entry__.build())."""
+    out = surface_library(tag)
     src = os.path.join(HERE, "cpp", "cpp_surface.cpp")
     hdrs = [os.path.join(ROOT, "include", h) for h in ("walnuts_hip.hpp", "walnuts_hip.h")]
-    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(f) for f in [src, lib_path] + hdrs):
-        return exe
-    libdir, libname = os.path.split(lib_path)
-    subprocess.check_call(["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           src, "-o", exe, lib_path, f"-Wl,-rpath,{libdir}", "-pthread"])
-    return exe
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in [src, lib_path] + hdrs):
+        return out
+    libdir = os.path.dirname(lib_path)
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", "-I",
+                           os.path.join(ROOT, "include"), src, "-o", out, lib_path, f"-Wl,-rpath,{libdir}", "-pthread"])
+    return out
 
 
-def run_and_compare(exe: str, lib_path: str, model: str, C: int, D: int, W: int, S: int, seed: int, tmp_path):
+def run_and_compare(surface: str, lib_path: str, model: str, C: int, D: int, W: int, S: int, seed: int, tmp_path):
+    import ctypes
     dump = str(tmp_path / "dump.bin")
-    r = subprocess.run([exe, model, str(C), str(D), str(W), str(S), str(seed), dump], capture_output=True, text=True,
-                       timeout=1500)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "cpp surface ok" in r.stdout
+    so = ctypes.CDLL(surface)
+    so.cpp_surface_run.restype = ctypes.c_int
+    so.cpp_surface_run.argtypes = [ctypes.c_char_p] + [ctypes.c_size_t] * 5 + [ctypes.c_char_p]
+    rc = so.cpp_surface_run(model.encode(), C, D, W, S, seed, dump.encode())   # in-process: nothing is spawned
+    assert rc == 0, "the C++ expectations failed (see stderr)"
     raw = np.fromfile(dump, dtype=np.float64)
     per_chain = W * D + W + W + W * D + 1 + D + S * D + S
     n_rhat = 1 if (C > 1 and S >= 2) else 0
@@ -91,16 +98,16 @@ def run_and_compare(exe: str, lib_path: str, model: str, C: int, D: int, W: int,
 def test_cpp_surface_under_emulation(oracle, tmp_path):
     import build as simbuild
     sim = simbuild.build()
-    exe = build_program(sim, "sim")
-    run_and_compare(exe, sim, "diag_normal", 2, 5, 3, 2, 77, tmp_path)
+    run_and_compare(build_surface_library(sim, "sim"), sim, "diag_normal", 2, 5, 3, 2, 77, tmp_path)
 
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("model,C,D,W,S", [("std_normal", 64, 1024, 12, 8), ("funnel", 40, 128, 12, 8),
                                            ("diag_normal", 6, 9000, 6, 4)])
-def test_cpp_surface_on_gpu(oracle, tmp_path, model, C, D, W, S):
+def test_cpp_surface_on_gpu(gpu, tmp_path, model, C, D, W, S):
     from walnuts_amd import _ffi
-    _ffi.load_library()
-    exe = build_program(_ffi.DEFAULT_LIB, "hip")
-    run_and_compare(exe, _ffi.DEFAULT_LIB, model, C, D, W, S, 4242, tmp_path)
+    surface = surface_library("hip")
+    # prebuilt by __graft_entry__.build(): a process that spawns children (a compiler) on the GPU box loses its GPU
+    assert os.path.exists(surface), "tests/cpp/libcpp_surface_hip.so missing: run __graft_entry__.build()"
+    run_and_compare(surface, _ffi.DEFAULT_LIB, model, C, D, W, S, 4242, tmp_path)

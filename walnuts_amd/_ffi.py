@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -119,6 +120,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise WalnutsHipError(
             f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C walnuts_amd/csrc). There is no CPU fallback.")
+    if "torch" not in sys.modules and not os.environ.get("WALNUTS_AMD_NO_TORCH"):
+        # PyTorch-ROCm ships its own copy of the HIP runtime.  A process that loads the system copy first (through
+        # this library) and torch's afterwards ends up with two runtimes, and the second finds no device: let
+        # torch's load first so that both bind to one.  (Only the load order matters; nothing of torch is used here.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -218,6 +218,45 @@ WALNUTS_HIP_EXPORT int wn_lanes_for_dim(int num_params, int waves_per_chain, int
 /* (internal) allocates the error object handed back through WalnutpyError** */
 WALNUTS_HIP_EXPORT void* wn_internal_make_error(const char* msg, int type);
 
+/* ---- posterior summaries over device-resident draws --------------------------------------------------------
+ * include/walnutpie/summary.hpp:370-768 (mean, sample_variance, sample_standard_deviation, quantiles,
+ * autocovariance, r_hat, effective_sample_size, monte_carlo_standard_error) for ragged collections of chains, as
+ * MarkovChainsSplit / MarkovChainsUnified (summary.hpp:119-356) describe them.  The draws stay in HBM; results
+ * ([dims] or [k][dims] row-major doubles) come back to host buffers the caller owns.  Same preconditions and
+ * std::invalid_argument messages as the reference (-> config errors). */
+typedef struct wn_chains wn_chains;
+
+/* Borrow draws that already live on the device: chain c's n-th draw is the `dims` doubles at
+ * draws_dev + c * chain_stride + n * dims -- the layout walnutpie_sample_device fills and wn_engine_*_step writes
+ * when called with (draws + n * dims, chain_stride).  lengths[c] <= max_len draws are valid in chain c (NULL: all
+ * max_len).  `stream` (hipStream_t, may be NULL) orders the kernels after the producer. */
+WALNUTS_HIP_EXPORT int wn_chains_view(wn_chains** out, const double* draws_dev, size_t num_chains, size_t max_len,
+                                      size_t dims, int64_t chain_stride, const int64_t* lengths, int device,
+                                      void* stream, WalnutpyError** err);
+/* Copy host draws in MarkovChainsUnified layout (chains stacked, [sum sizes][dims] row-major) to the device. */
+WALNUTS_HIP_EXPORT int wn_chains_upload(wn_chains** out, const double* draws_host, size_t dims, const int64_t* sizes,
+                                        size_t num_chains, int device, WalnutpyError** err);
+WALNUTS_HIP_EXPORT void wn_chains_destroy(wn_chains* chains);
+WALNUTS_HIP_EXPORT size_t wn_chains_num_chains(const wn_chains* chains);
+WALNUTS_HIP_EXPORT size_t wn_chains_dims(const wn_chains* chains);
+WALNUTS_HIP_EXPORT size_t wn_chains_num_draws(const wn_chains* chains);
+WALNUTS_HIP_EXPORT size_t wn_chains_min_chain_size(const wn_chains* chains);
+
+WALNUTS_HIP_EXPORT int wn_summary_mean(wn_chains* chains, double* out /*[D]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_summary_sample_variance(wn_chains* chains, double* out /*[D]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_summary_sample_standard_deviation(wn_chains* chains, double* out /*[D]*/,
+                                                            WalnutpyError** err);
+/* out[k][d] = sorted_d[lo] + frac * (sorted_d[hi] - sorted_d[lo]) (summary.hpp:507-511), exact order statistics */
+WALNUTS_HIP_EXPORT int wn_summary_quantiles(wn_chains* chains, const double* probs, size_t num_probs,
+                                            double* out /*[num_probs*D]*/, WalnutpyError** err);
+/* all lags of every chain, stacked like the draws: out[(first row of chain c) + lag][d] */
+WALNUTS_HIP_EXPORT int wn_summary_autocovariance(wn_chains* chains, double* out /*[num_draws*D]*/,
+                                                 WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_summary_r_hat(wn_chains* chains, double* out /*[D]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_summary_effective_sample_size(wn_chains* chains, double* out /*[D]*/, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_summary_monte_carlo_standard_error(wn_chains* chains, double* out /*[D]*/,
+                                                             WalnutpyError** err);
+
 #ifdef __cplusplus
 }
 #endif

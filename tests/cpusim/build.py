@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "walnuts_amd", "csrc")
 OUT = os.path.join(HERE, "libwalnuts_sim.so")
-SOURCES = ["wn_engine.hip", "wn_sample.hip", "wn_kernels_std_normal.hip", "wn_kernels_diag_normal.hip",
+SOURCES = ["wn_engine.hip", "wn_sample.hip", "wn_summary.hip", "wn_kernels_std_normal.hip", "wn_kernels_diag_normal.hip",
            "wn_kernels_funnel.hip"]
 
 

@@ -105,6 +105,22 @@ SYMBOLS = [
     ("wn_engine_kernel_times", _i32, [_vp, C.POINTER(C.c_float), _i32, C.POINTER(C.c_int), _errpp]),
     ("wn_engine_set_stream", _i32, [_vp, _vp, _errpp]),
     ("wn_lanes_for_dim", _i32, [_i32, _i32, _i32]),
+    # posterior summaries (summary.hpp:370-768)
+    ("wn_chains_view", _i32, [C.POINTER(_vp), _vp, _sz, _sz, _sz, C.c_int64, C.POINTER(C.c_int64), _i32, _vp, _errpp]),
+    ("wn_chains_upload", _i32, [C.POINTER(_vp), _dp, _sz, C.POINTER(C.c_int64), _sz, _i32, _errpp]),
+    ("wn_chains_destroy", None, [_vp]),
+    ("wn_chains_num_chains", _sz, [_vp]),
+    ("wn_chains_dims", _sz, [_vp]),
+    ("wn_chains_num_draws", _sz, [_vp]),
+    ("wn_chains_min_chain_size", _sz, [_vp]),
+    ("wn_summary_mean", _i32, [_vp, _dp, _errpp]),
+    ("wn_summary_sample_variance", _i32, [_vp, _dp, _errpp]),
+    ("wn_summary_sample_standard_deviation", _i32, [_vp, _dp, _errpp]),
+    ("wn_summary_quantiles", _i32, [_vp, _dp, _sz, _dp, _errpp]),
+    ("wn_summary_autocovariance", _i32, [_vp, _dp, _errpp]),
+    ("wn_summary_r_hat", _i32, [_vp, _dp, _errpp]),
+    ("wn_summary_effective_sample_size", _i32, [_vp, _dp, _errpp]),
+    ("wn_summary_monte_carlo_standard_error", _i32, [_vp, _dp, _errpp]),
     ("wn_internal_make_error", _vp, [C.c_char_p, _i32]),
 ]
 

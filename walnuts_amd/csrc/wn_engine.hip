@@ -19,56 +19,7 @@
 #include "wn_launch.h"
 #include "wn_traj.h"
 
-// ---- errors (python/src/walnutpie/errors.hpp:10-72) --------------------------------------
-struct WalnutpyError {
-  std::string msg;
-  WalnutpyErrorType type;
-};
-
-namespace {
-
-void hip_check(hipError_t e, const char* what) {
-  if (e != hipSuccess) {
-    std::stringstream ss;
-    ss << "HIP error in " << what << ": " << hipGetErrorString(e);
-    throw std::runtime_error(ss.str());
-  }
-}
-#define HIP_OK(expr) hip_check((expr), #expr)
-
-template <class F>
-int guarded(WalnutpyError** err, F f) {
-  try {
-    f();
-    return 0;
-  } catch (const std::invalid_argument& e) {
-    if (err) *err = new WalnutpyError{e.what(), config};
-  } catch (const std::exception& e) {
-    if (err) *err = new WalnutpyError{e.what(), generic};
-  } catch (...) {
-    if (err) *err = new WalnutpyError{"Unknown error", generic};
-  }
-  return -1;
-}
-
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  void alloc(size_t count) {
-    release();
-    n = count;
-    if (count) HIP_OK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-  ~DevBuf() { release(); }
-};
-
-}  // namespace
+#include "wn_host.h"
 
 // Host-side reproduction of the reference's per-chain random streams (api.hpp:46-51 + detail::Random,
 // util.hpp:78-162): engine m = mt19937_64(seed_seq{seed, m+1}); per transition D normals (libstdc++'s polar

@@ -9,7 +9,8 @@
  * draws with the chains stacked, plus the chain sizes.
  *
  * Where this differs from the reference in ARITHMETIC ORDER (results agree to rounding, ~1e-16 relative):
- *   - sums run left to right; Eigen's colwise()/sum() reductions are packetised;
+ *   - sums run left to right (over chains: in runs of 256 chains, see chain_sum); Eigen's colwise()/sum()
+ *     reductions are packetised;
  *   - the autocovariance is the direct sum  acov[t] = (1/N) sum_n (y[n]-ybar)(y[n+t]-ybar)  that the reference's
  *     zero-padded FFT evaluates (summary.hpp:55-73; its own test checks the FFT against exactly this direct form,
  *     tests/summary_test.cpp:610-627,681-693).  Eigen::FFT (kissfft) is not in /root/reference.
@@ -47,6 +48,21 @@ struct Chains {
   size_t min_len() const { return *std::min_element(len.begin(), len.end()); }
 };
 
+// Sums over chains: runs of kChainBlock consecutive chains summed left to right, then the run totals left to right.
+// Up to kChainBlock chains this is exactly the reference's left-to-right loop over chains; beyond, the grouping is
+// the device's (walnuts_amd/csrc/wn_summary.hip, block_sum_kernel), which keeps the comparison bit-exact.
+constexpr size_t kChainBlock = 256;
+template <class F>
+double chain_sum(size_t K, F term) {
+  double total = 0;
+  for (size_t b0 = 0; b0 < K; b0 += kChainBlock) {
+    double s = 0;
+    for (size_t k = b0; k < std::min(K, b0 + kChainBlock); ++k) s += term(k);
+    total += s;
+  }
+  return total;
+}
+
 // detail::col_means (:19-22) and detail::sample_variance (:93-99) of one chain
 void chain_moments(const Chains& c, size_t m, double* mean, double* var) {
   const size_t n_m = c.len[m];
@@ -66,46 +82,40 @@ void chain_moments(const Chains& c, size_t m, double* mean, double* var) {
 // sample variance over the rows of a [K][D] matrix (detail::sample_variance(draws), :101-105)
 void rows_sample_variance(const std::vector<double>& a, size_t K, size_t D, double* out) {
   for (size_t d = 0; d < D; ++d) {
-    double s = 0;
-    for (size_t k = 0; k < K; ++k) s += a[k * D + d];
-    const double mu = s / static_cast<double>(K);
-    double q = 0;
-    for (size_t k = 0; k < K; ++k) q += (a[k * D + d] - mu) * (a[k * D + d] - mu);
+    const double mu = chain_sum(K, [&](size_t k) { return a[k * D + d]; }) / static_cast<double>(K);
+    const double q = chain_sum(K, [&](size_t k) { return (a[k * D + d] - mu) * (a[k * D + d] - mu); });
     out[d] = q / static_cast<double>(static_cast<int64_t>(K) - 1);
   }
 }
 void rows_mean(const std::vector<double>& a, size_t K, size_t D, double* out) {
-  for (size_t d = 0; d < D; ++d) {
-    double s = 0;
-    for (size_t k = 0; k < K; ++k) s += a[k * D + d];
-    out[d] = s / static_cast<double>(K);
-  }
+  for (size_t d = 0; d < D; ++d) out[d] = chain_sum(K, [&](size_t k) { return a[k * D + d]; }) / static_cast<double>(K);
 }
 
 void mean(const Chains& c, double* out) {  // :370-378: per-chain column sums added chain by chain, / num_draws
-  std::vector<double> total(c.D, 0.0);
-  for (size_t m = 0; m < c.K(); ++m)
-    for (size_t d = 0; d < c.D; ++d) {
+  for (size_t d = 0; d < c.D; ++d) {
+    const double total = chain_sum(c.K(), [&](size_t m) {
       double s = 0;
       for (size_t n = 0; n < c.len[m]; ++n) s += c.at(m, n, d);
-      total[d] += s;
-    }
-  for (size_t d = 0; d < c.D; ++d) out[d] = total[d] / static_cast<double>(c.N);
+      return s;
+    });
+    out[d] = total / static_cast<double>(c.N);
+  }
 }
 
 void sample_variance(const Chains& c, double* out) {  // :396-405
-  std::vector<double> mu(c.D), sum_sq(c.D, 0.0);
+  std::vector<double> mu(c.D);
   mean(c, mu.data());
-  for (size_t m = 0; m < c.K(); ++m)
-    for (size_t d = 0; d < c.D; ++d) {
+  for (size_t d = 0; d < c.D; ++d) {
+    const double sum_sq = chain_sum(c.K(), [&](size_t m) {
       double q = 0;
       for (size_t n = 0; n < c.len[m]; ++n) {
         const double r = c.at(m, n, d) - mu[d];
         q += r * r;
       }
-      sum_sq[d] += q;
-    }
-  for (size_t d = 0; d < c.D; ++d) out[d] = sum_sq[d] / static_cast<double>(static_cast<int64_t>(c.N) - 1);
+      return q;
+    });
+    out[d] = sum_sq / static_cast<double>(static_cast<int64_t>(c.N) - 1);
+  }
 }
 
 // all lags of one chain and one column, detail::autocovariance_col (:55-73) as a direct sum
@@ -163,9 +173,7 @@ void effective_sample_size(const Chains& c, double* out) {  // :663-749
   for (size_t d = 0; d < D; ++d) {
     const double w_d = W[d], vp_d = var_plus[d];
     auto mean_acov_at_lag = [&](size_t t) {
-      double sum = 0;
-      for (size_t k = 0; k < K; ++k) sum += acov[(c.start[k] + t) * D + d];
-      return sum / static_cast<double>(K);
+      return chain_sum(K, [&](size_t k) { return acov[(c.start[k] + t) * D + d]; }) / static_cast<double>(K);
     };
     std::vector<double> rho(min_len, 0.0);
     double even = 1.0;

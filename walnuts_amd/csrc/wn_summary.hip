@@ -31,6 +31,8 @@ constexpr int kBlock = 256;
 #endif
 constexpr int kWaves = kBlock / 64;
 constexpr int kLagBlock = 16;     // lags per pass of the autocovariance kernel (accumulators + ring in VGPRs)
+constexpr int kChainBlock = 256;  // chains per run of the two-stage sums over chains
+constexpr int kRows = 8;          // draws a lane loads ahead in the radix-select pass
 constexpr int kMaxTargets = 16;   // order statistics per radix-select sweep (16 * 4 KB of LDS histograms)
 
 struct View {
@@ -93,28 +95,35 @@ static __global__ void chain_sqdev_kernel(View v, const double* mu, double* csq)
   }
   csq[static_cast<long long>(s.c) * v.D + s.d] = q;
 }
-// column sums of a [C][D] matrix, rows in order; out = sum / denom
-static __global__ void col_sum_kernel(const double* a, int C, int D, double denom, double* out) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
+// Sums over chains (rows of a [C][width] matrix with row stride `ld`), in two deterministic stages: runs of
+// kChainBlock consecutive chains are summed left to right, then the run totals are summed left to right.  Up to
+// kChainBlock chains this IS the reference's left-to-right loop over chains; beyond, it keeps 65 536-chain
+// reductions from serialising on one thread per column.  With `mu` the terms are (a - mu)^2.
+static __global__ void block_sum_kernel(const double* a, int C, long long ld, int width, const double* mu,
+                                        double* partial /*[blocks][width]*/) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int nb = (C + kChainBlock - 1) / kChainBlock;
+  if (i >= static_cast<long long>(nb) * width) return;
+  const int b = static_cast<int>(i / width), w = static_cast<int>(i % width);
+  const int c_hi = (b + 1) * kChainBlock, c1 = c_hi < C ? c_hi : C;
   double s = 0.0;
-  for (int c = 0; c < C; ++c) s += a[static_cast<long long>(c) * D + d];
-  out[d] = s / denom;
-}
-// mean and sample variance over the rows of a [C][D] matrix (detail::col_means, detail::sample_variance(draws))
-static __global__ void col_stats_kernel(const double* a, int C, int D, double* mean_out, double* var_out) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
-  double s = 0.0;
-  for (int c = 0; c < C; ++c) s += a[static_cast<long long>(c) * D + d];
-  const double mu = s / static_cast<double>(C);
-  double q = 0.0;
-  for (int c = 0; c < C; ++c) {
-    const double r = a[static_cast<long long>(c) * D + d] - mu;
-    q += r * r;
+  if (mu != nullptr) {
+    const double m = mu[w];
+    for (int c = b * kChainBlock; c < c1; ++c) {
+      const double r = a[static_cast<long long>(c) * ld + w] - m;
+      s += r * r;
+    }
+  } else {
+    for (int c = b * kChainBlock; c < c1; ++c) s += a[static_cast<long long>(c) * ld + w];
   }
-  if (mean_out) mean_out[d] = mu;
-  if (var_out) var_out[d] = q / static_cast<double>(C - 1);
+  partial[i] = s;
+}
+static __global__ void final_sum_kernel(const double* partial, int nb, int width, double denom, double* out) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= width) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += partial[static_cast<long long>(b) * width + w];
+  out[w] = s / denom;
 }
 
 // kLagBlock lags [t0, t0 + kLagBlock) of every chain's autocovariance, per column.  The thread streams its chain's
@@ -162,15 +171,6 @@ static __global__ void acov_block_kernel(View v, const double* cmean, int t0, in
     if (blk != nullptr) blk[(static_cast<long long>(s.c) * kLagBlock + j) * D + s.d] = val;
     if (full != nullptr && t < n_c) full[(v.row0[s.c] + t) * D + s.d] = val;
   }
-}
-// mean over chains (in order) of the block's lags: mean_acov_at_lag (:696-704)
-static __global__ void lag_mean_kernel(const double* blk, int C, int D, int t0, int nlags, double* macov) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nlags * D) return;
-  const int j = i / D, d = i % D;
-  double s = 0.0;
-  for (int c = 0; c < C; ++c) s += blk[(static_cast<long long>(c) * kLagBlock + j) * D + d];
-  macov[static_cast<long long>(t0 + j) * D + d] = s / static_cast<double>(C);
 }
 // Geyer's initial positive + monotone sequence on paired lags and the ESS (:706-745), resumable: a dimension whose
 // sequence needs a lag that has not been computed yet parks its state and raises *need_more.
@@ -256,22 +256,36 @@ static __global__ void radix_hist_kernel(View v, int T, int shift, int first, co
   for (int i = threadIdx.x; i < Teff * 16 * 64; i += blockDim.x) hist[i] = 0u;
   __syncthreads();
   if (d < v.D) {
-    unsigned long long pre[kMaxTargets];
+    // the bits above this pass's digit, per target: an element counts for target t iff its own high bits equal them
+    // (~0 never matches: the top bits of a shifted key are zero)
+    const int hs = shift + 4;
+    unsigned long long pre_hi[kMaxTargets];
 #pragma unroll
-    for (int t = 0; t < kMaxTargets; ++t) pre[t] = (!first && t < T) ? prefix[static_cast<long long>(t) * v.D + d] : 0ull;
+    for (int t = 0; t < kMaxTargets; ++t)
+      pre_hi[t] = (!first && t < T) ? prefix[static_cast<long long>(t) * v.D + d] >> hs : ~0ull;
     const int c_hi = (chunk + 1) * chains_per_block, c_end = c_hi < v.C ? c_hi : v.C;
     for (int c = chunk * chains_per_block + wave; c < c_end; c += kWaves) {
       const double* p = v.x + v.off[c] + d;
       const int n = v.len[c];
-      for (int i = 0; i < n; ++i) {
-        const unsigned long long k = order_key(p[static_cast<long long>(i) * v.D]);
-        const unsigned dig = static_cast<unsigned>(k >> shift) & 15u;
-        if (first) {
-          atomicAdd(&hist[dig * 64 + lane], 1u);
-        } else {
+      // kRows loads in flight per lane before any of them is consumed: the LDS atomics below would otherwise
+      // serialise the row loop on HBM latency
+      for (int i0 = 0; i0 < n; i0 += kRows) {
+        double x[kRows];
 #pragma unroll
-          for (int t = 0; t < kMaxTargets; ++t) {
-            if (t < T && ((k ^ pre[t]) >> (shift + 4)) == 0ull) atomicAdd(&hist[(t * 16 + dig) * 64 + lane], 1u);
+        for (int r = 0; r < kRows; ++r) x[r] = (i0 + r < n) ? p[static_cast<long long>(i0 + r) * v.D] : 0.0;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+          if (i0 + r >= n) break;
+          const unsigned long long k = order_key(x[r]);
+          const unsigned dig = static_cast<unsigned>(k >> shift) & 15u;
+          if (first) {
+            atomicAdd(&hist[dig * 64 + lane], 1u);
+          } else {
+            const unsigned long long k_hi = k >> hs;
+#pragma unroll
+            for (int t = 0; t < kMaxTargets; ++t) {
+              if (k_hi == pre_hi[t]) atomicAdd(&hist[(t * 16 + dig) * 64 + lane], 1u);
+            }
           }
         }
       }
@@ -328,6 +342,8 @@ struct wn_chains {
   // lazily computed per-chain moments
   bool have_moments = false;
   DevBuf<double> csum, cmean, cvar;
+  DevBuf<double> partial;  // run totals of the two-stage sums over chains
+  DevBuf<double> lag_blk;  // [C][kLagBlock][D] workspace of the ESS (kept: reallocating GBs per call costs more than the kernels)
 
   wns::View view() const {
     return wns::View{x, off.p, len.p, row0.p, static_cast<int>(C), static_cast<int>(D)};
@@ -385,23 +401,43 @@ void check_sizes(size_t num_chains, size_t dims) {
   if (num_chains > 0x7fffffffull || dims > 0x7fffffffull) throw std::invalid_argument("too many chains or dimensions");
 }
 
-void device_mean(wn_chains* ch, double* d_out /*device [D]*/) {
-  ch->ensure_moments();
-  hipLaunchKernelGGL(wns::col_sum_kernel, dim3(col_blocks(ch->D)), dim3(wns::kBlock), 0, ch->stream, ch->csum.p,
-                     static_cast<int>(ch->C), static_cast<int>(ch->D), static_cast<double>(ch->N), d_out);
+// out[w] = (sum over chains of a[c][w], or of (a[c][w] - mu[w])^2) / denom, chains grouped as block_sum_kernel says
+void chain_sum(wn_chains* ch, const double* a, long long ld, int width, const double* mu, double denom, double* d_out) {
+  const int C = static_cast<int>(ch->C), nb = (C + wns::kChainBlock - 1) / wns::kChainBlock;
+  if (ch->partial.n < static_cast<size_t>(nb) * width) ch->partial.alloc(static_cast<size_t>(nb) * width);
+  hipLaunchKernelGGL(wns::block_sum_kernel, dim3(col_blocks(static_cast<size_t>(nb) * width)), dim3(wns::kBlock), 0,
+                     ch->stream, a, C, ld, width, mu, ch->partial.p);
+  hipLaunchKernelGGL(wns::final_sum_kernel, dim3(col_blocks(width)), dim3(wns::kBlock), 0, ch->stream, ch->partial.p, nb,
+                     width, denom, d_out);
   HIP_OK(hipGetLastError());
 }
-void device_sample_variance(wn_chains* ch, double* d_out /*device [D]*/) {
+void device_mean(wn_chains* ch, double* d_out /*device [D]*/) {  // :370-378
+  ch->ensure_moments();
+  chain_sum(ch, ch->csum.p, static_cast<long long>(ch->D), static_cast<int>(ch->D), nullptr, static_cast<double>(ch->N),
+            d_out);
+}
+void device_sample_variance(wn_chains* ch, double* d_out /*device [D]*/) {  // :396-405
   DevBuf<double> mu, csq;
   mu.alloc(ch->D);
   csq.alloc(ch->C * ch->D);
   device_mean(ch, mu.p);
   hipLaunchKernelGGL(wns::chain_sqdev_kernel, dim3(wns::slot_blocks(static_cast<int>(ch->C), static_cast<int>(ch->D))),
                      dim3(wns::kBlock), 0, ch->stream, ch->view(), mu.p, csq.p);
-  hipLaunchKernelGGL(wns::col_sum_kernel, dim3(col_blocks(ch->D)), dim3(wns::kBlock), 0, ch->stream, csq.p,
-                     static_cast<int>(ch->C), static_cast<int>(ch->D), static_cast<double>(ch->N - 1), d_out);
-  HIP_OK(hipGetLastError());
+  chain_sum(ch, csq.p, static_cast<long long>(ch->D), static_cast<int>(ch->D), nullptr, static_cast<double>(ch->N - 1),
+            d_out);
   HIP_OK(hipStreamSynchronize(ch->stream));  // mu/csq are released on return
+}
+// detail::col_means / detail::sample_variance(draws) over the rows of a [C][D] per-chain matrix (:19-22, :101-105)
+void rows_mean(wn_chains* ch, const double* a, double* d_mean) {
+  chain_sum(ch, a, static_cast<long long>(ch->D), static_cast<int>(ch->D), nullptr, static_cast<double>(ch->C), d_mean);
+}
+void rows_sample_variance(wn_chains* ch, const double* a, double* d_var) {
+  DevBuf<double> mu;
+  mu.alloc(ch->D);
+  rows_mean(ch, a, mu.p);
+  chain_sum(ch, a, static_cast<long long>(ch->D), static_cast<int>(ch->D), mu.p,
+            static_cast<double>(static_cast<long long>(ch->C) - 1), d_var);
+  HIP_OK(hipStreamSynchronize(ch->stream));
 }
 void host_effective_sample_size(wn_chains* ch, double* out) {
   if (ch->N < 3) throw std::invalid_argument("chains must have at least 3 draws");  // :665-667
@@ -410,25 +446,24 @@ void host_effective_sample_size(wn_chains* ch, double* out) {
   if (ch->min_len < 3) throw std::invalid_argument("each chain must have at least 3 draws");
   ch->ensure_moments();
   const int C = static_cast<int>(ch->C), D = static_cast<int>(ch->D), min_len = ch->min_len;
-  DevBuf<double> W, between, var_plus, blk, macov, even, odd, rho, ess;
+  DevBuf<double> W, between, var_plus, macov, even, odd, rho, ess;
+  DevBuf<double>& blk = ch->lag_blk;
   DevBuf<int> st_t, st_done, need;
   W.alloc(D);
   var_plus.alloc(D);
-  hipLaunchKernelGGL(wns::col_stats_kernel, dim3(col_blocks(D)), dim3(wns::kBlock), 0, ch->stream, ch->cvar.p, C, D,
-                     W.p, static_cast<double*>(nullptr));
+  rows_mean(ch, ch->cvar.p, W.p);
   std::vector<double> h_w(D), h_vp(D);
   ch->down(W.p, h_w.data(), D);
   h_vp = h_w;
   if (C > 1) {  // var_plus = W + sample_variance(chain_means), :682-686
     between.alloc(D);
-    hipLaunchKernelGGL(wns::col_stats_kernel, dim3(col_blocks(D)), dim3(wns::kBlock), 0, ch->stream, ch->cmean.p, C, D,
-                       static_cast<double*>(nullptr), between.p);
+    rows_sample_variance(ch, ch->cmean.p, between.p);
     std::vector<double> h_b(D);
     ch->down(between.p, h_b.data(), D);
     for (int d = 0; d < D; ++d) h_vp[d] += h_b[d];
   }
   HIP_OK(hipMemcpyAsync(var_plus.p, h_vp.data(), D * sizeof(double), hipMemcpyHostToDevice, ch->stream));
-  blk.alloc(static_cast<size_t>(C) * wns::kLagBlock * D);
+  if (blk.n == 0) blk.alloc(static_cast<size_t>(C) * wns::kLagBlock * D);
   macov.alloc(static_cast<size_t>(min_len) * D);
   rho.alloc(static_cast<size_t>(min_len) * D);
   even.alloc(D);
@@ -444,8 +479,9 @@ void host_effective_sample_size(wn_chains* ch, double* out) {
     const int t0 = avail, nl = std::min(wns::kLagBlock, min_len - t0);
     hipLaunchKernelGGL(wns::acov_block_kernel, dim3(wns::slot_blocks(C, D)), dim3(wns::kBlock), 0, ch->stream, ch->view(),
                        ch->cmean.p, t0, min_len, blk.p, static_cast<double*>(nullptr));
-    hipLaunchKernelGGL(wns::lag_mean_kernel, dim3(col_blocks(static_cast<size_t>(nl) * D)), dim3(wns::kBlock), 0,
-                       ch->stream, blk.p, C, D, t0, nl, macov.p);
+    // mean_acov_at_lag (:696-704) for the block's lags: blk is a [C][kLagBlock * D] matrix
+    chain_sum(ch, blk.p, static_cast<long long>(wns::kLagBlock) * D, nl * D, nullptr, static_cast<double>(C),
+              macov.p + static_cast<size_t>(t0) * D);
     avail += nl;
     HIP_OK(hipMemsetAsync(need.p, 0, sizeof(int), ch->stream));
     hipLaunchKernelGGL(wns::geyer_kernel, dim3(col_blocks(D)), dim3(wns::kBlock), 0, ch->stream, D, min_len, avail,
@@ -567,15 +603,12 @@ int wn_summary_r_hat(wn_chains* ch, double* out, WalnutpyError** err) {
     if (ch->min_len < 3) throw std::invalid_argument("each chain must have at least 3 draws");    // :598-603
     ch->use();
     ch->ensure_moments();
-    const int C = static_cast<int>(ch->C), D = static_cast<int>(ch->D);
+    const int D = static_cast<int>(ch->D);
     DevBuf<double> var_mu, mean_sig;
     var_mu.alloc(D);
     mean_sig.alloc(D);
-    hipLaunchKernelGGL(wns::col_stats_kernel, dim3(col_blocks(D)), dim3(wns::kBlock), 0, ch->stream, ch->cmean.p, C, D,
-                       static_cast<double*>(nullptr), var_mu.p);
-    hipLaunchKernelGGL(wns::col_stats_kernel, dim3(col_blocks(D)), dim3(wns::kBlock), 0, ch->stream, ch->cvar.p, C, D,
-                       mean_sig.p, static_cast<double*>(nullptr));
-    HIP_OK(hipGetLastError());
+    rows_sample_variance(ch, ch->cmean.p, var_mu.p);
+    rows_mean(ch, ch->cvar.p, mean_sig.p);
     std::vector<double> a(D), b(D);
     ch->down(var_mu.p, a.data(), D);
     ch->down(mean_sig.p, b.data(), D);

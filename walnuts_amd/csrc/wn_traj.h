@@ -212,6 +212,8 @@ enum Comp : int { kTh = 0, kRh = 1, kG = 2, kTh0 = 3, kRh0 = 4 };
 //   leapfrog(h, n) -> partial      energy(partial, lp, lj)        reversible(h, n, lj)
 //   macro_begin() / macro_retry() / macro_commit()
 //   put(b, Comp) / get(b, Comp)    uturn_pool(bth, brh, fwd)      uturn_start(fwd)
+// A backend with kZeroCopy keeps its vectors in pool buffers already: instead of put(b, c) into a buffer the
+// base allocated it offers put_new(c) -> the buffer that now holds the vector (handed over, no copy).
 // ---------------------------------------------------------------------------------------------------
 template <class Self, class Model, int NW>
 struct TrajBase {
@@ -361,13 +363,17 @@ struct TrajBase {
   // give a symbolic vector (kHot = moving end, kStart = restart state) a pool buffer
   __device__ __forceinline__ int materialize(int ref, bool rho) {
     if (ref >= 0) return ref;
-    const int b = alloc();
-    if (ref == kHot) {
-      self().put(b, rho ? kRh : kTh);
+    if constexpr (Self::kZeroCopy) {
+      return self().put_new(ref == kHot ? (rho ? kRh : kTh) : (rho ? kRh0 : kTh0));
     } else {
-      self().put(b, rho ? kRh0 : kTh0);
+      const int b = alloc();
+      if (ref == kHot) {
+        self().put(b, rho ? kRh : kTh);
+      } else {
+        self().put(b, rho ? kRh0 : kTh0);
+      }
+      return b;
     }
-    return b;
   }
 
   // ---- randomness (util.hpp:102,112 order; counter-based stream or host-fed variates) ----
@@ -522,12 +528,18 @@ struct TrajBase {
       self().energy(part, lp_pos, lj);
     }
     int a_bk[3], a_fw[3];
-    a_bk[0] = a_fw[0] = alloc_cold();
-    a_bk[1] = a_fw[1] = alloc_cold();
-    a_bk[2] = a_fw[2] = alloc_cold();
-    self().put(a_bk[0], kTh);
-    self().put(a_bk[1], kRh);
-    self().put(a_bk[2], kG);
+    if constexpr (Self::kZeroCopy) {
+      a_bk[0] = a_fw[0] = self().put_new(kTh);
+      a_bk[1] = a_fw[1] = self().put_new(kRh);
+      a_bk[2] = a_fw[2] = self().put_new(kG);
+    } else {
+      a_bk[0] = a_fw[0] = alloc_cold();
+      a_bk[1] = a_fw[1] = alloc_cold();
+      a_bk[2] = a_fw[2] = alloc_cold();
+      self().put(a_bk[0], kTh);
+      self().put(a_bk[1], kRh);
+      self().put(a_bk[2], kG);
+    }
     int a_sel = a_bk[0];
     double a_lj_bk = lj, a_lj_fw = lj, a_logsum = lj, a_lpsel = lp_pos;
     // The moving end equals one (initially both) of the accumulated span's ends.  An extended end is
@@ -536,13 +548,23 @@ struct TrajBase {
     auto flush_hot_end = [&]() {
       int* endp = hot_is_fw ? a_fw : a_bk;
       const int* other = hot_is_fw ? a_bk : a_fw;
+      if constexpr (Self::kZeroCopy) {
+        // the moving end's buffers become the span end; the old end's buffers go back unless something else
+        // still names them
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (endp[r] == other[r] || endp[r] == a_sel) endp[r] = alloc_cold();
+        for (int r = 0; r < 3; ++r) {
+          if (!(endp[r] == other[r] || endp[r] == a_sel)) release(endp[r]);
+          endp[r] = self().put_new(r == 0 ? kTh : r == 1 ? kRh : kG);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (endp[r] == other[r] || endp[r] == a_sel) endp[r] = alloc_cold();
+        }
+        self().put(endp[0], kTh);
+        self().put(endp[1], kRh);
+        self().put(endp[2], kG);
       }
-      self().put(endp[0], kTh);
-      self().put(endp[1], kRh);
-      self().put(endp[2], kG);
       dirty = false;
     };
 
@@ -685,6 +707,7 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
   static constexpr int L = Base::L;
   static constexpr int NP = EPL / 2;
   static constexpr bool kHasStartState = START_REGS || LDS_STATE;
+  static constexpr bool kZeroCopy = false;
   static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
@@ -1060,28 +1083,35 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
   using Base::n_grad; using Base::max_error; using Base::min_micro; using Base::w_draw0; using Base::w_score0;
   static constexpr int L = Base::L;
   static constexpr bool kHasStartState = true;
+  static constexpr bool kZeroCopy = true;
   static_assert(Model::kElementwise, "the streaming backend needs an element-wise gradient");
 
+  // The three vector sets are pool buffers themselves (role slot r: 0-2 cur, 3-5 alt, 6-8 work).  Handing a
+  // vector to the span pool (put_new) or taking one from it (get) moves a buffer index, not 8*Dp bytes; a slot
+  // whose buffer the pool also names is read-only (`own` bit clear) and gets a fresh buffer before it is written.
   double* cur[3];   // theta, rho, grad of the moving end
   double* alt[3];   // the other set: output of the running macro step / the previous leaf after commit
   double* work[3];  // reversibility re-integration (the reference's scratch vectors, walnuts.hpp:264-266)
+  int slot_buf[9];
+  unsigned own;
   double* im_buf;   // warmup: this transition's inverse mass
   const double* im; // inverse mass row in force
   double ke_part;   // kinetic partial of the state produced by the last pass
+  double ut_hot, ut_far;  // per-lane partials of the level-0 U-turn sums of the last forward pass
+  bool ut_valid;          // ... valid: that pass was the whole macro step (one micro step)
   int tiles;        // pairs per lane
 
   __device__ __forceinline__ TrajMem(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
                                      WN_LDS double* bc, double* ar)
       : Base(p, pool, m, r, bc, ar) {
-    // scratch follows the pool buffers in this workgroup's arena slice
-    double* s = ar + static_cast<long long>(p.pool_total - p.pool_lds) * p.dim_padded;
-    for (int i = 0; i < 3; ++i) {
-      cur[i] = s + static_cast<long long>(i) * p.dim_padded;
-      alt[i] = s + static_cast<long long>(3 + i) * p.dim_padded;
-      work[i] = s + static_cast<long long>(6 + i) * p.dim_padded;
-    }
-    im_buf = s + 9ll * p.dim_padded;
+    // the inverse-mass scratch follows the pool buffers in this workgroup's arena slice
+    im_buf = ar + static_cast<long long>(p.pool_total - p.pool_lds) * p.dim_padded;
     im = im_buf;
+    own = 0u;
+    ut_valid = false;
+    ut_hot = ut_far = 0.0;
+    for (int r = 0; r < 9; ++r) slot_buf[r] = -1;
+    for (int i = 0; i < 3; ++i) cur[i] = alt[i] = work[i] = nullptr;
     ke_part = 0.0;
     tiles = p.dim_padded / (2 * L);
   }
@@ -1108,11 +1138,39 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
       st(dst + o, t[0], t[1]);
     }
   }
-  __device__ __forceinline__ void put(int b, Comp c) {
-    const double* src = c == kTh ? cur[0] : c == kRh ? cur[1] : c == kG ? cur[2] : c == kTh0 ? alt[0] : alt[1];
-    copy(pool_ptr(b), src);
+  __device__ __forceinline__ double*& slot_ptr(int r) { return r < 3 ? cur[r] : r < 6 ? alt[r - 3] : work[r - 6]; }
+  __device__ __forceinline__ void set_slot(int r, int b, bool owned) {
+    slot_buf[r] = b;
+    slot_ptr(r) = pool_ptr(b);
+    own = owned ? (own | (1u << r)) : (own & ~(1u << r));
   }
-  __device__ __forceinline__ void get(int b, Comp c) { copy(cur[c == kTh ? 0 : c == kRh ? 1 : 2], pool_ptr(b)); }
+  // before a pass writes slots r0..r0+2: buffers the span pool also names are left to it
+  __device__ __forceinline__ void ensure_writable(int r0) {
+#pragma unroll
+    for (int r = r0; r < r0 + 3; ++r) {
+      if (!((own >> r) & 1u)) set_slot(r, this->alloc(), true);
+    }
+  }
+  static __device__ __forceinline__ int slot_of(Comp c) {
+    return c == kTh ? 0 : c == kRh ? 1 : c == kG ? 2 : c == kTh0 ? 3 : 4;
+  }
+  // the span pool takes the vector: its buffer changes hands (no copy) unless the pool names that buffer already
+  __device__ __forceinline__ int put_new(Comp c) {
+    const int r = slot_of(c);
+    if ((own >> r) & 1u) {
+      own &= ~(1u << r);
+      return slot_buf[r];
+    }
+    const int b = this->alloc();
+    copy(pool_ptr(b), slot_ptr(r));
+    return b;
+  }
+  // the moving end becomes a vector of the span pool: read it in place
+  __device__ __forceinline__ void get(int b, Comp c) {
+    const int r = slot_of(c);
+    if ((own >> r) & 1u) this->release(slot_buf[r]);
+    set_slot(r, b, false);
+  }
 
   // n micro steps (walnuts.hpp:328-333): the first reads `src` (rho negated for the reversibility check)
   // and writes `dst`, the rest run in place on `dst`.  Returns the log-density partial and leaves the kinetic
@@ -1121,6 +1179,12 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
                                                   int n) {
     const double half = 0.5 * h;
     double part = 0.0, ke = 0.0;
+    // A single-step leaf (n == 1, the usual case once the step size has adapted) has both ends of the two-leaf
+    // span (previous leaf = input, new leaf = output) in registers: the level-0 U-turn sums (walnuts.hpp:192-201)
+    // are accumulated here, in uturn_ptrs' order, and that pass over five vectors is skipped.
+    const bool fuse = !negate && n == 1;
+    const bool fwd = h > 0;
+    double p_hot = 0.0, p_far = 0.0;
     for (int s = 0; s < n; ++s) {
       double* const* in = (s == 0) ? src : dst;
       const bool neg = negate && s == 0;
@@ -1146,6 +1210,15 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
         for (int j = 0; j < 2; ++j) rh2[j] += half * g2[j];
 #pragma unroll
         for (int j = 0; j < 2; ++j) ke += m0[j] * (rh2[j] * rh2[j]);
+        if (fuse) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const double diff = fwd ? (th2[j] - t0[j]) : (t0[j] - th2[j]);
+            const double sd = m0[j] * diff;
+            p_hot += rh2[j] * sd;
+            p_far += r0[j] * sd;
+          }
+        }
         st(dst[0] + o, th2[0], th2[1]);
         st(dst[1] + o, rh2[0], rh2[1]);
         st(dst[2] + o, g2[0], g2[1]);
@@ -1153,9 +1226,17 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
       ++n_grad;
     }
     ke_part = ke;
+    if (!negate) {
+      ut_valid = fuse;
+      ut_hot = p_hot;
+      ut_far = p_far;
+    }
     return part;
   }
-  __device__ __forceinline__ double leapfrog(double h, int n) { return leapfrog_sets(cur, alt, false, h, n); }
+  __device__ __forceinline__ double leapfrog(double h, int n) {
+    ensure_writable(3);
+    return leapfrog_sets(cur, alt, false, h, n);
+  }
   __device__ __forceinline__ void energy(double lp_partial, double& logp_pos, double& logp_joint) {
     double ke = ke_part;
     this->sum2(lp_partial, ke);
@@ -1170,7 +1251,11 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
       double* t = cur[i];
       cur[i] = alt[i];
       alt[i] = t;
+      const int b = slot_buf[i];
+      slot_buf[i] = slot_buf[3 + i];
+      slot_buf[3 + i] = b;
     }
+    own = (own & ~0x3fu) | ((own & 0x7u) << 3) | ((own >> 3) & 0x7u);
   }
   // walnuts.hpp:254-279: coarser reverse paths from (theta', -rho', grad') = the candidate in `alt`
   __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
@@ -1178,6 +1263,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
     while (n >= 2 * min_micro) {
       n /= 2;
       h *= 2;
+      ensure_writable(6);
       const double part = leapfrog_sets(alt, work, true, h, n);
       double lp, lj;
       energy(part, lp, lj);
@@ -1203,7 +1289,14 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
     this->sum2(p_hot, p_far);
     return p_hot < 0 || p_far < 0;
   }
-  __device__ __forceinline__ bool uturn_start(bool fwd) { return uturn_ptrs(alt[0], alt[1], fwd); }
+  __device__ __forceinline__ bool uturn_start(bool fwd) {
+    if (ut_valid) {  // the accepted macro step was one micro step: its pass already holds the partial sums
+      double p_hot = ut_hot, p_far = ut_far;
+      this->sum2(p_hot, p_far);
+      return p_hot < 0 || p_far < 0;
+    }
+    return uturn_ptrs(alt[0], alt[1], fwd);
+  }
   __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
     return uturn_ptrs(pool_ptr(bth), pool_ptr(brh), fwd);
   }
@@ -1211,6 +1304,9 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
   __device__ __forceinline__ double begin_transition(long long row, bool warm) {
     const double wd = w_draw0, ws = w_score0;
     im = warm ? im_buf : P.inv_mass + row;
+    own = 0u;  // the base has just marked every pool buffer free
+    for (int r = 0; r < 9; ++r) slot_buf[r] = -1;
+    ensure_writable(0);
     double part = 0.0, ke = 0.0;
     for (int k = 0; k < tiles; ++k) {
       const int o = pair_offset(k);
@@ -1303,7 +1399,9 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
   }
 };
 
-constexpr int kMemScratchVectors = 10;  // TrajMem: cur 3 + alt 3 + work 3 + inverse mass 1
+// TrajMem: cur 3 + alt 3 + work 3 are pool buffers (the host adds kMemRoleVectors to the pool), + inverse mass 1
+constexpr int kMemRoleVectors = 9;
+constexpr int kMemScratchVectors = 1;
 
 // ---------------------------------------------------------------------------------------
 // persistent kernels: workgroups pull chains from a shared counter (work per transition

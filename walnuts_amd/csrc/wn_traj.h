@@ -133,6 +133,13 @@ struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
       acc += th[j] * th[j];
     }
   }
+  // element-wise models: the gradient alone, the same expression eval() uses (so the same bits)
+  template <int EPL, class Cx>
+  __device__ __forceinline__ static void grad(Cx&, const double (&th)[EPL], double (&g)[EPL], const double (&)[EPL],
+                                              Aux&) {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) g[j] = -th[j];
+  }
   __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return -0.5 * sum; }
 };
 
@@ -149,6 +156,12 @@ struct DiagNormalModel {  // examples/examples.cpp:20-31, params = sigma_sq
       g[j] = -th[j] / s2[j];
       acc += -0.5 * th[j] * th[j] / s2[j];
     }
+  }
+  template <int EPL, class Cx>
+  __device__ __forceinline__ static void grad(Cx&, const double (&th)[EPL], double (&g)[EPL],
+                                              const double (&s2)[EPL], Aux&) {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) g[j] = -th[j] / s2[j];
   }
   __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return sum; }
 };
@@ -1162,7 +1175,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
       return slot_buf[r];
     }
     const int b = this->alloc();
-    copy(pool_ptr(b), slot_ptr(r));
+    if (c != kG) copy(pool_ptr(b), slot_ptr(r));  // gradient buffers are bookkeeping only (never read: see leapfrog_sets)
     return b;
   }
   // the moving end becomes a vector of the span pool: read it in place
@@ -1192,19 +1205,22 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
       ke = 0.0;
       for (int k = 0; k < tiles; ++k) {
         const int o = pair_offset(k);
-        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), g0 = ld(in[2] + o), m0 = ld(im + o);
+        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), m0 = ld(im + o);
         double th2[2] = {t0[0], t0[1]}, rh2[2] = {neg ? -r0[0] : r0[0], neg ? -r0[1] : r0[1]};
-        double g2[2] = {g0[0], g0[1]}, mp2[2] = {1.0, 1.0};
+        double g2[2], mp2[2] = {1.0, 1.0};
         if (Model::kUsesParams) {
           const v2f64 p0 = ld(P.model_params + o);
           mp2[0] = p0[0];
           mp2[1] = p0[1];
         }
+        TileCx cx{o, P.dim};
+        // the gradient is a function of theta alone (element-wise model): recomputing it is cheaper than keeping a
+        // third vector in HBM -- 16 bytes per element and pass less than the 56 the definition charges
+        Model::grad(cx, th2, g2, mp2, aux);
 #pragma unroll
         for (int j = 0; j < 2; ++j) rh2[j] += half * g2[j];
 #pragma unroll
         for (int j = 0; j < 2; ++j) th2[j] += h * m0[j] * rh2[j];
-        TileCx cx{o, P.dim};
         Model::eval(cx, th2, g2, mp2, aux, part);
 #pragma unroll
         for (int j = 0; j < 2; ++j) rh2[j] += half * g2[j];
@@ -1221,7 +1237,6 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
         }
         st(dst[0] + o, th2[0], th2[1]);
         st(dst[1] + o, rh2[0], rh2[1]);
-        st(dst[2] + o, g2[0], g2[1]);
       }
       ++n_grad;
     }
@@ -1347,7 +1362,6 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
       for (int j = 0; j < 2; ++j) ke += m2[j] * (rh2[j] * rh2[j]);
       st(cur[0] + o, th2[0], th2[1]);
       st(cur[1] + o, rh2[0], rh2[1]);
-      st(cur[2] + o, g2[0], g2[1]);
     }
     ++n_grad;
     ke_part = ke;

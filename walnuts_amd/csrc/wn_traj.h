@@ -724,7 +724,11 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
   static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
-  double th0[EPL], rh0[EPL];  // restart state; its gradient is re-evaluated on a retry (a pure function of th0)
+  // restart state.  Its gradient is re-evaluated on a retry (a pure function of th0) when that is a couple of
+  // element-wise operations; a model whose gradient needs a reduction and an exponential (the funnel, where retries
+  // are frequent) keeps the copy the reference keeps (walnuts.hpp:326)
+  static constexpr bool kKeepRestartGrad = START_REGS && !LDS_STATE && !Model::kElementwise;
+  double th0[EPL], rh0[EPL], g0[EPL];
   int start_buf[3];
   WN_LDS double* st_im;   // LDS_STATE: inverse mass / restart theta / restart rho vectors
   WN_LDS double* st_th0;
@@ -929,6 +933,7 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
       for (int j = 0; j < EPL; ++j) {
         th0[j] = th[j];
         rh0[j] = rh[j];
+        if (kKeepRestartGrad) g0[j] = g[j];
       }
     } else {
       pool_store(start_buf[0], th);
@@ -948,10 +953,15 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
           rh[j] = rh0[j];
         }
       }
-      // the restart gradient is a pure function of the restart position: same bits as the copy the
-      // reference keeps (walnuts.hpp:326), without holding a third vector for the rare retry
-      double unused = 0.0;
-      Model::eval(*this, th, g, mp, aux, unused);
+      if (kKeepRestartGrad) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) g[j] = g0[j];
+      } else {
+        // the restart gradient is a pure function of the restart position: same bits as the copy the
+        // reference keeps (walnuts.hpp:326), without holding a third vector for the rare retry
+        double unused = 0.0;
+        Model::eval(*this, th, g, mp, aux, unused);
+      }
     } else {
       pool_load(start_buf[0], th);
       pool_load(start_buf[1], rh);

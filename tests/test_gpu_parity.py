@@ -185,6 +185,21 @@ def test_deep_trees_and_halvings():
     parity.run_case("funnel", 32, 64, warmup=10, sampling=10, step=1.5, max_step_halvings=8, check_every=5)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(step=0.02, max_trajectory_doublings=9),                    # deep trees: the span pool hands buffers around a lot
+    dict(step=2.9, max_trajectory_doublings=4),                     # halving levels + reversibility re-integrations
+    dict(step=0.7, min_micro_steps=2, max_trajectory_doublings=6),  # multi-step leaves: no fused level-0 U-turn
+    dict(step=1.7, max_step_halvings=1),                            # failed leaves end the transition
+    dict(step=0.9, max_hamiltonian_error=1e-3),                     # nearly every level rejected
+    dict(step=0.4, max_trajectory_doublings=1),                     # a single doubling
+])
+def test_streaming_backend_edge_configurations(kw):
+    """The HBM-streaming kernels (zero-copy span pool, fused level-0 U-turn, recomputed gradient) on the same edge
+    cases as the register kernels, warmup included."""
+    parity.run_case("diag_normal", 700, 12, warmup=4, sampling=5, geometry=(2, -1), **kw)
+    parity.run_case("std_normal", 9000, 3, warmup=2, sampling=3, **kw)           # default: streaming above 8192
+
+
 def test_host_supplied_variates_path():
     """kRngBuffer: normals and canonical uniforms supplied by the host (the hook for exact libstdc++-stream
     runs), compared with the oracle fed the same variates."""

@@ -61,6 +61,15 @@ def test_emulated_engine_halving_and_reversibility(sim, oracle):
 
 
 @pytest.mark.timeout(600)
+def test_emulated_streaming_backend_halvings_and_deep_trees(sim, oracle):
+    # the streaming kernels' buffer hand-over under retries, reversibility passes (multi-step leaves) and deeper trees
+    parity.run_case("std_normal", 140, 2, warmup=0, sampling=3, lib_path=sim, geometry=(1, -1), step=2.9,
+                    max_trajectory_doublings=3)
+    parity.run_case("diag_normal", 140, 2, warmup=2, sampling=2, lib_path=sim, geometry=(1, -1), step=0.15,
+                    max_trajectory_doublings=5)
+
+
+@pytest.mark.timeout(600)
 def test_emulated_engine_host_variates(sim, oracle):
     import test_gpu_parity
 

@@ -65,6 +65,19 @@ def model_setup(name, D):
     return wa.MODEL_DIAG_NORMAL, np.array([(1.0 + (d % 16)) ** 2 for d in range(D)])
 
 
+def measured_traffic(args, D):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes recorded under profiles/ (counters
+    are collected in their own runs, never inside a timed bench run); None when this workload was not profiled."""
+    try:
+        entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except OSError:
+        return None, None
+    for e in entries:
+        if (e["model"], e["chains"], e["dim"], e["phase"]) == (args.model, args.chains, D, args.phase):
+            return e["bytes_per_launch"], e["source"]
+    return None, None
+
+
 def cpu_baseline(args, D):
     """The oracle timed on the host cores: reference arithmetic order (left-to-right sums, libm), one thread per
     chain block.  Bounded: 8 chains per core, ~args.cpu_seconds of sampling transitions."""
@@ -208,6 +221,8 @@ def main():
         avg_kernel_ms = float(np.mean(ktimes)) if len(ktimes) else float("nan")
         bytes_per_launch = 56.0 * D * grad_evals / max(args.steps, 1)  # this rank's launches
         achieved = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(args, D)
+        streaming = bool(eng.streaming)
         out = {
             "metric": "leapfrog grad-evals/sec (all chains)",
             "value": total_grad_evals / elapsed,
@@ -233,11 +248,15 @@ def main():
                 "grad_evals_per_transition_per_chain": grad_evals / max(args.steps, 1) / C,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "wn::transition_kernel", "avg_launch_ms": avg_kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "wn::transition_kernel_mem" if streaming else "wn::transition_kernel",
+                         "avg_launch_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "algorithmic bytes = 56*D per grad-eval; the trajectory end lives in VGPRs and the "
-                                 "span pool in LDS, so measured HBM traffic is far below the algorithmic figure"},
+                         "note": ("algorithmic bytes = 56*D per grad-eval; the streaming kernels move theta, rho and the "
+                                  "inverse mass per micro step and recompute the element-wise gradient"
+                                  if streaming else
+                                  "algorithmic bytes = 56*D per grad-eval; the trajectory end lives in VGPRs and the "
+                                  "span pool in LDS, so measured HBM traffic is far below the algorithmic figure")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, D)

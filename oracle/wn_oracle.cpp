@@ -46,7 +46,7 @@ struct MathOps {
 // L > 0: the device order.  Lane l (0 <= l < L) owns elements
 // (k*L + l)*2 + {0,1}, k = 0,1,...; it adds its elements in increasing index
 // order into a partial that starts at +0.0; each group of 64 lanes (one
-// wavefront) then runs an xor butterfly with offsets 1,2,4,8,16,32; wavefront
+// wavefront) then runs an xor butterfly with offsets 32,1,2,4,8,16; wavefront
 // totals are added left to right.
 // ---------------------------------------------------------------------------
 struct Reducer {
@@ -78,7 +78,7 @@ struct Reducer {
       double* v = part.data() + w;
       // lanes beyond `width` do not exist for L < 64 only when L is not a
       // multiple of 64; the engine always uses multiples of 64.
-      for (size_t off = 1; off < 64; off <<= 1) {
+      for (size_t off : {size_t{32}, size_t{1}, size_t{2}, size_t{4}, size_t{8}, size_t{16}}) {
         for (size_t l = 0; l < width; ++l) {
           size_t p = l ^ off;
           tmp[l] = v[l] + (p < width ? v[p] : 0.0);

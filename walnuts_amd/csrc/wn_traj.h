@@ -30,8 +30,8 @@
 // All element-wise arithmetic keeps the reference's association order and the
 // file is compiled with -ffp-contract=off, so element-wise results carry the
 // reference's bits.  Sums over D run in a fixed order (per-lane partial in
-// index order, xor butterfly 1..32 inside a wavefront, wavefronts left to
-// right) that the CPU oracle can replay exactly.
+// index order, xor butterfly with offsets 32,1,2,4,8,16 inside a wavefront,
+// wavefronts left to right) that the CPU oracle can replay exactly.
 #pragma once
 
 #include "wn_hip.h"
@@ -53,11 +53,12 @@ __device__ __forceinline__ double uni(double v) {
   return wnd::as_f64((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
-// xor-butterfly sum over the 64 lanes, offsets 1,2,4,8,16,32: every lane ends with the same bits
+// xor-butterfly sum over the 64 lanes, offsets 32,1,2,4,8,16: every lane ends with the same bits
 // (a+b == b+a), and the CPU oracle replays exactly this association order.
 #if defined(WN_CPU_SIM)
 __device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+  v = v + __shfl_xor(v, 32, 64);
+  for (int off = 1; off < 32; off <<= 1) v = v + __shfl_xor(v, off, 64);
   return v;
 }
 __device__ __forceinline__ double lane_value(double v, int src_lane) { return __shfl(v, src_lane, 64); }
@@ -75,7 +76,19 @@ __device__ __forceinline__ double dpp_partner(double v) {
   const int phi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return wnd::as_f64((static_cast<uint64_t>(static_cast<uint32_t>(phi)) << 32) | static_cast<uint32_t>(plo));
 }
-__device__ __forceinline__ double wave_sum(double v) {
+// Two sums at once.  Offset 32 goes first and packs the pair: after one v_permlane32_swap per dword, lanes 0-31
+// hold a[l] + a[l+32] and lanes 32-63 hold b[l-32] + b[l]; offsets 1..16 never leave a 32-lane half, so ONE
+// butterfly finishes both (18 VALU instead of 36).  Returns the packed register: a's sum in lanes 0-31, b's in
+// lanes 32-63.
+__device__ __forceinline__ double wave_sum_pair(double a, double b) {
+  double v;
+  {
+    const uint64_t ua = wnd::as_u64(a), ub = wnd::as_u64(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(ua), static_cast<uint32_t>(ub), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(ua >> 32), static_cast<uint32_t>(ub >> 32),
+                                                     false, false);
+    v = wnd::as_f64((static_cast<uint64_t>(hi[0]) << 32) | lo[0]) + wnd::as_f64((static_cast<uint64_t>(hi[1]) << 32) | lo[1]);
+  }
   v = v + dpp_partner<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
   v = v + dpp_partner<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
   v = v + dpp_partner<0x141>(v);  // row_half_mirror      : partner quad  (lane ^ 4)
@@ -83,16 +96,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   {
     const uint64_t u = wnd::as_u64(v);
     const uint32_t lo = static_cast<uint32_t>(u), hi = static_cast<uint32_t>(u >> 32);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    v = wnd::as_f64((static_cast<uint64_t>(b[0]) << 32) | a[0]) + wnd::as_f64((static_cast<uint64_t>(b[1]) << 32) | a[1]);
-  }
-  {
-    const uint64_t u = wnd::as_u64(v);
-    const uint32_t lo = static_cast<uint32_t>(u), hi = static_cast<uint32_t>(u >> 32);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    v = wnd::as_f64((static_cast<uint64_t>(b[0]) << 32) | a[0]) + wnd::as_f64((static_cast<uint64_t>(b[1]) << 32) | a[1]);
+    const auto p = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto q = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = wnd::as_f64((static_cast<uint64_t>(q[0]) << 32) | p[0]) + wnd::as_f64((static_cast<uint64_t>(q[1]) << 32) | p[1]);
   }
   return v;
 }
@@ -318,14 +324,22 @@ struct TrajBase {
 
   // ---- reductions -----------------------------------------------------------------
   __device__ __forceinline__ void sum2(double& a, double& b) {
+#if defined(WN_CPU_SIM)
     a = wave_sum(a);
     b = wave_sum(b);
+    const double packed = lane < 32 ? a : b;
+#else
+    const double packed = wave_sum_pair(a, b);  // a's sum in lanes 0-31, b's in lanes 32-63
+    if (NW == 1) {
+      a = uni(packed);
+      b = lane_value(packed, 32);
+      return;
+    }
+#endif
     if (NW > 1) {
       WN_LDS double* r = red + red_parity * (NW * 2);
-      if (lane == 0) {
-        r[wave * 2] = a;
-        r[wave * 2 + 1] = b;
-      }
+      if (lane == 0) r[wave * 2] = packed;
+      if (lane == 32) r[wave * 2 + 1] = packed;
       __syncthreads();
       double ta = r[0], tb = r[1];
 #pragma unroll

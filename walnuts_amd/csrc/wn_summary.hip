@@ -152,7 +152,9 @@ static __global__ void acov_block_kernel(View v, const double* cmean, int t0, in
     for (int i = 0; i < kLagBlock; ++i) {
       const int n = n0 + i;
       if (n < runs) {
-        const double y = p[static_cast<long long>(n) * D] - ybar;
+        // y[n]: for the first block it is the ring's oldest entry (lag 0 pairs y[n] with itself); later blocks read
+        // the draw again
+        const double y = (t0 == 0) ? ring[i % kLagBlock] : p[static_cast<long long>(n) * D] - ybar;
 #pragma unroll
         for (int j = 0; j < kLagBlock; ++j) {
           // ring[(i + j) % kLagBlock] holds y[n + t0 + j]

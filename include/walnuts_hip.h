@@ -193,6 +193,15 @@ WALNUTS_HIP_EXPORT int wn_engine_lp_sums(wn_engine* e, double* out3, WalnutpyErr
 WALNUTS_HIP_EXPORT int wn_engine_lp_sq_dev(wn_engine* e, double mean_of_means, double* out1, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_warmup_spread(wn_engine* e, double* max_rel_diff_step, double* max_rel_diff_mass,
                                                WalnutpyError** err);
+/* the same statistic in the two stages a multi-GPU driver all-reduces between: this engine's sums
+ * over its chains of log step (1) and log mass ([D]) -> all-reduce SUM -> this engine's maxima given the sums over
+ * all `total_chains` chains -> all-reduce MAX */
+WALNUTS_HIP_EXPORT int wn_engine_warmup_sums(wn_engine* e, double* sum_log_step, double* colsum_log_mass /*[D]*/,
+                                             WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_warmup_max_rel(wn_engine* e, double sum_log_step,
+                                                const double* colsum_log_mass /*[D]*/, size_t total_chains,
+                                                double* max_rel_diff_step, double* max_rel_diff_mass,
+                                                WalnutpyError** err);
 
 /* introspection */
 WALNUTS_HIP_EXPORT int wn_engine_lanes(const wn_engine* e);        /* L = 64*NW: the reduction width   */

@@ -1,5 +1,5 @@
-"""CPU tier, world_size 2 over gloo: the N>1 driver logic (chain sharding + double-buffered all-gather of draws)
-run on the test-only workgroup emulation gives exactly the chains of a single-rank run."""
+"""CPU tier, world_size 2 over gloo: the N>1 driver logic (chain sharding, double-buffered all-gather of draws,
+the controllers' all-reduced statistics) run on the test-only workgroup emulation gives exactly the chains of a single-rank run."""
 import os
 import socket
 import subprocess
@@ -18,7 +18,7 @@ ROOT = sys.argv[1]
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "cpusim")]
 import build as simbuild
 import walnuts_amd as wa
-from walnuts_amd.distributed import DrawGather, shard_chains
+from walnuts_amd.distributed import DrawGather, shard_chains, global_rhat, global_warmup_spread
 
 SIM = simbuild.build()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -35,21 +35,33 @@ def make(first, count):
 eng = make(first, count)
 gather = DrawGather(dist, world, count, D, "cpu", torch.float64)
 seen = []
+spread = None
 for it in range(ITERS):
     plane = gather.buffer(it)
-    eng.warmup_step(plane.data_ptr(), D) if it < 2 else (eng.freeze() if it == 2 else None, eng.sample_step(plane.data_ptr(), D))
+    if it == 2:
+        spread = global_warmup_spread(dist, eng, TOTAL)   # the warmup controller's statistic over both ranks
+        eng.freeze()
+    eng.warmup_step(plane.data_ptr(), D) if it < 2 else eng.sample_step(plane.data_ptr(), D)
     eng.synchronize()
     gather.launch(it)
     seen.append(gather.result(it).clone().numpy())
 gather.drain()
+eng.sample_step(); eng.sample_step()
+rhat = global_rhat(dist, eng)                             # the sampling controller's statistic over both ranks
 if rank == 0:
     ref = make(0, TOTAL)
     for it in range(ITERS):
         buf = np.empty((TOTAL, D))
         ptr = buf.ctypes.data
-        ref.warmup_step(ptr, D) if it < 2 else (ref.freeze() if it == 2 else None, ref.sample_step(ptr, D))
+        if it == 2:
+            ref_spread = ref.warmup_spread()
+            ref.freeze()
+        ref.warmup_step(ptr, D) if it < 2 else ref.sample_step(ptr, D)
         ref.synchronize()
         assert np.array_equal(buf, seen[it]), (it, buf, seen[it])
+    ref.sample_step(); ref.sample_step()
+    assert np.allclose(spread, ref_spread, rtol=1e-12), (spread, ref_spread)
+    assert abs(rhat - ref.rhat()) <= 1e-12 * rhat, (rhat, ref.rhat())
     print("DISTRIBUTED_OK")
 dist.barrier()
 dist.destroy_process_group()

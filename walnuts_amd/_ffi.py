@@ -92,6 +92,8 @@ SYMBOLS = [
     ("wn_engine_lp_sums", _i32, [_vp, _dp, _errpp]),
     ("wn_engine_lp_sq_dev", _i32, [_vp, _dbl, _dp, _errpp]),
     ("wn_engine_warmup_spread", _i32, [_vp, _dp, _dp, _errpp]),
+    ("wn_engine_warmup_sums", _i32, [_vp, _dp, _dp, _errpp]),
+    ("wn_engine_warmup_max_rel", _i32, [_vp, _dbl, _dp, _sz, _dp, _dp, _errpp]),
     ("wn_engine_lanes", _i32, [_vp]),
     ("wn_engine_dim_padded", _i32, [_vp]),
     ("wn_engine_is_streaming", _i32, [_vp]),

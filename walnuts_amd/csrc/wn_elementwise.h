@@ -156,6 +156,7 @@ static __global__ void mass_broadcast_kernel(int C, int D, int Dp, const double*
 // per-chain l2_rel_diff(mass_m, geom_mean_mass) (util.hpp:379-382) and rel diff of the step; block per chain
 static __global__ void warmup_spread_kernel(int C, int D, int Dp, const double* draw_ssd, const double* score_ssd,
                                             const double* est_weight, const double* adam, const double* colsum,
+                                            double n_chains /*chains behind colsum: all ranks'*/,
                                             double mean_log_step, double* rel_mass, double* rel_step) {
   __shared__ double sh[256];
   const int c = blockIdx.x;
@@ -164,7 +165,7 @@ static __global__ void warmup_spread_kernel(int C, int D, int Dp, const double* 
     const long long i = static_cast<long long>(c) * Dp + d;
     const double im = __builtin_sqrt((draw_ssd[i] / est_weight[2 * c]) / (score_ssd[i] / est_weight[2 * c + 1]));
     const double mass = wnd::dexp(-wnd::dlog(im));                       // snap.mass, adapt.hpp:141
-    const double gm = wnd::dexp(colsum[d] / static_cast<double>(C));     // geom_mean_mass, adapt.hpp:203-205
+    const double gm = wnd::dexp(colsum[d] / n_chains);                   // geom_mean_mass, adapt.hpp:203-205
     const double r = (mass - gm) / gm;
     acc += r * r;
   }

@@ -711,7 +711,10 @@ int wn_engine_rhat(wn_engine* e, double* rhat, WalnutpyError** err) {
     *rhat = std::sqrt(1 + variance_of_means / mean_of_variances);  // sampler.hpp:145
   });
 }
-int wn_engine_warmup_spread(wn_engine* e, double* max_rel_diff_step, double* max_rel_diff_mass, WalnutpyError** err) {
+// The warmup controller's statistic (adapt.hpp:193-221) in the two stages a multi-GPU driver needs: (1) this
+// engine's sums over chains of log step and of log mass per dimension -- D+1 doubles to all-reduce (SUM) --,
+// (2) given the sums over ALL chains, this engine's largest relative distances -- 2 doubles to all-reduce (MAX).
+int wn_engine_warmup_sums(wn_engine* e, double* sum_log_step, double* colsum_log_mass, WalnutpyError** err) {
   return guarded(err, [&] {
     if (e->frozen) throw std::runtime_error("warmup monitor after freeze");
     e->ensure_adapters();
@@ -721,13 +724,27 @@ int wn_engine_warmup_spread(wn_engine* e, double* max_rel_diff_step, double* max
                        e->mon_partial.p);
     hipLaunchKernelGGL(wn::finish_sums_kernel<1>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p,
                        wn::kMonitorBlocks, e->mon_out.p);
-    double sum_log_step = 0;
-    e->download(e->mon_out, &sum_log_step, 1);
-    const double mean_log_step = sum_log_step / C;  // adapt.hpp:201-202
     hipLaunchKernelGGL(wn::log_mass_colsum_kernel, dim3((e->D + 255) / 256), dim3(256), 0, e->stream, C, e->D, e->Dp,
                        e->draw_ssd.p, e->score_ssd.p, e->est_weight.p, e->mon_colsum.p);
+    HIP_OK(hipGetLastError());
+    e->download(e->mon_out, sum_log_step, 1);
+    e->download(e->mon_colsum, colsum_log_mass, static_cast<size_t>(e->D));
+  });
+}
+int wn_engine_warmup_max_rel(wn_engine* e, double sum_log_step, const double* colsum_log_mass, size_t total_chains,
+                             double* max_rel_diff_step, double* max_rel_diff_mass, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e->frozen) throw std::runtime_error("warmup monitor after freeze");
+    if (total_chains < e->C) throw std::invalid_argument("total_chains is smaller than this engine's chain count");
+    e->ensure_adapters();
+    e->use_device();
+    const int C = static_cast<int>(e->C);
+    HIP_OK(hipMemcpyAsync(e->mon_colsum.p, colsum_log_mass, static_cast<size_t>(e->D) * sizeof(double),
+                          hipMemcpyHostToDevice, e->stream));
+    const double n = static_cast<double>(total_chains);
+    const double mean_log_step = sum_log_step / n;  // adapt.hpp:201-202
     hipLaunchKernelGGL(wn::warmup_spread_kernel, dim3(C), dim3(256), 0, e->stream, C, e->D, e->Dp, e->draw_ssd.p,
-                       e->score_ssd.p, e->est_weight.p, e->adam.p, e->mon_colsum.p, mean_log_step,
+                       e->score_ssd.p, e->est_weight.p, e->adam.p, e->mon_colsum.p, n, mean_log_step,
                        e->mon_rel_mass.p, e->mon_rel_step.p);
     hipLaunchKernelGGL(wn::max2_kernel, dim3(1), dim3(256), 0, e->stream, C, e->mon_rel_mass.p, e->mon_rel_step.p,
                        e->mon_out.p);
@@ -736,6 +753,19 @@ int wn_engine_warmup_spread(wn_engine* e, double* max_rel_diff_step, double* max
     e->download(e->mon_out, m, 2);
     *max_rel_diff_mass = m[0];
     *max_rel_diff_step = m[1];
+  });
+}
+int wn_engine_warmup_spread(wn_engine* e, double* max_rel_diff_step, double* max_rel_diff_mass, WalnutpyError** err) {
+  return guarded(err, [&] {
+    WalnutpyError* inner = nullptr;
+    double sum_log_step = 0;
+    std::vector<double> colsum(static_cast<size_t>(e->D));
+    if (wn_engine_warmup_sums(e, &sum_log_step, colsum.data(), &inner) != 0 ||
+        wn_engine_warmup_max_rel(e, sum_log_step, colsum.data(), e->C, max_rel_diff_step, max_rel_diff_mass, &inner) != 0) {
+      const std::string msg = inner ? inner->msg : "monitor failed";
+      delete inner;
+      throw std::runtime_error(msg);
+    }
   });
 }
 

@@ -1,5 +1,6 @@
-"""Multi-GPU driver logic: chains shard across ranks, the only exchange is an all-gather of each iteration's
-draws (RCCL over xGMI when the process group is `nccl`; `gloo` in the CPU tests).
+"""Multi-GPU driver logic: chains shard across ranks; the exchanges are an all-gather of each iteration's draws
+and the controllers' few-double all-reduces (RCCL over xGMI when the process group is `nccl`; `gloo` in the CPU
+tests).
 
 The reference has no distributed layer (thread-per-chain on one host, adapt.hpp:249-254, sampler.hpp:182-187);
 chains never exchange state inside a transition and per-chain tuning is never pooled (adapt.hpp:257-258), so the
@@ -60,3 +61,33 @@ class DrawGather:
             if self.pending[b] is not None:
                 self.pending[b].wait()
                 self.pending[b] = None
+
+
+def _all_reduce(dist, values, op, device):
+    import torch
+
+    t = torch.as_tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=op)
+    return t.cpu().numpy()
+
+
+def global_rhat(dist, engine, device="cpu") -> float:
+    """R-hat of the log density over the chains of ALL ranks (sampler.hpp:132-145): each rank reduces its chains'
+    Welford statistics to three doubles, one all-reduce, one more double for the variance of the chain means."""
+    s = _all_reduce(dist, engine.lp_sums(), dist.ReduceOp.SUM, device)          # sum means, sum variances, chains
+    q = _all_reduce(dist, [engine.lp_sq_dev(s[0] / s[2])], dist.ReduceOp.SUM, device)[0]
+    variance_of_means = q / (s[2] - 1)
+    mean_of_variances = s[1] / s[2]
+    return float((1 + variance_of_means / mean_of_variances) ** 0.5)
+
+
+def global_warmup_spread(dist, engine, total_chains: int, device="cpu"):
+    """(max rel. step distance, max rel. mass distance) from the geometric means over the chains of ALL ranks
+    (adapt.hpp:193-221): D+1 doubles all-reduced (SUM), then 2 doubles (MAX)."""
+    import numpy as np
+
+    sum_log_step, colsum = engine.warmup_sums()
+    tot = _all_reduce(dist, np.concatenate([[sum_log_step], colsum]), dist.ReduceOp.SUM, device)
+    rel_step, rel_mass = engine.warmup_max_rel(float(tot[0]), tot[1:], total_chains)
+    m = _all_reduce(dist, [rel_step, rel_mass], dist.ReduceOp.MAX, device)
+    return float(m[0]), float(m[1])

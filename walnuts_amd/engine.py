@@ -179,11 +179,41 @@ class DeviceEngine:
         self._call(self.lib.wn_engine_rhat, C.cast(C.byref(v), _dp))
         return v.value
 
+    def lp_sums(self):
+        """Stage 1 of R-hat for a multi-GPU driver: (sum of chain means, sum of chain sample variances, chains) of the
+        log density -- all-reduce SUM."""
+        out = np.zeros(3)
+        self._call(self.lib.wn_engine_lp_sums, out.ctypes.data_as(_dp))
+        return out
+
+    def lp_sq_dev(self, mean_of_means: float) -> float:
+        """Stage 2: sum over this engine's chains of (chain mean - mean of means)^2 -- all-reduce SUM."""
+        v = C.c_double()
+        self._call(self.lib.wn_engine_lp_sq_dev, mean_of_means, C.cast(C.byref(v), _dp))
+        return v.value
+
     def warmup_spread(self):
         """(max rel. step-size distance, max rel. mass distance) from the chains' geometric means
         (adapt.hpp:193-221)."""
         a, b = C.c_double(), C.c_double()
         self._call(self.lib.wn_engine_warmup_spread, C.cast(C.byref(a), _dp), C.cast(C.byref(b), _dp))
+        return a.value, b.value
+
+    def warmup_sums(self):
+        """Stage 1 of the warmup statistic for a multi-GPU driver: (sum over this engine's chains of log step,
+        [D] sums of log mass) -- all-reduce SUM these D+1 doubles."""
+        s = C.c_double()
+        col = np.zeros(self.D)
+        self._call(self.lib.wn_engine_warmup_sums, C.cast(C.byref(s), _dp), col.ctypes.data_as(_dp))
+        return s.value, col
+
+    def warmup_max_rel(self, sum_log_step: float, colsum_log_mass, total_chains: int):
+        """Stage 2: this engine's (max rel. step distance, max rel. mass distance) from the geometric means over
+        ALL `total_chains` chains -- all-reduce MAX."""
+        col = _f64(colsum_log_mass).reshape(self.D)
+        a, b = C.c_double(), C.c_double()
+        self._call(self.lib.wn_engine_warmup_max_rel, sum_log_step, col.ctypes.data_as(_dp), total_chains,
+                   C.cast(C.byref(a), _dp), C.cast(C.byref(b), _dp))
         return a.value, b.value
 
     def timing_reset(self):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time sampling transitions of an arbitrary build of libwalnuts_hip.so through the stable part of the C ABI
-(used to bisect performance between commits):  abi_bench.py <lib.so> <model id> <chains> <dim> <adapt> <steps>"""
+(used to bisect performance between commits):
+   abi_bench.py <lib.so> <model id> <chains> <dim> <adapt> <steps> [waves_per_chain elems_per_lane workgroups_per_cu]"""
 import ctypes as C
 import sys
 import time
@@ -12,6 +13,9 @@ model, chains, dim, adapt, steps = (int(x) for x in sys.argv[2:7])
 vp, err = C.c_void_p, C.c_void_p()
 cfg = (C.c_char * 512)()
 lib.wn_default_config(cfg)
+if len(sys.argv) > 9:  # wn_config: 4 x int32, 9 x double, then waves_per_chain / elems_per_lane / workgroups_per_cu
+    import struct
+    struct.pack_into("iii", cfg, 88, *(int(x) for x in sys.argv[7:10]))
 eng = vp()
 
 

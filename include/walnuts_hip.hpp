@@ -20,6 +20,8 @@
  *                                                          `dim()`, usable in a reference-style chain loop
  *   ChainHandler/GlobalHandler/InterruptCallback           same member names and argument order
  *                               concepts.hpp:173-245
+ *   mean / quantiles / r_hat / effective_sample_size ...   same names over MarkovChains (device-resident draws)
+ *                               summary.hpp:119-768
  *   detail::adapt / detail::sample controllers             run_warmup / run_sampling: same stopping rules on whole
  *                               adapt.hpp:172-259,          iterations (all chains advance in lock step, so every
  *                               sampler.hpp:117-200         chain ends with the same length)
@@ -699,6 +701,103 @@ class BatchedAdaptiveWalnuts {
   std::shared_ptr<detail::Batch<H>> batch_;
   std::size_t iter_ = 0;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// posterior summaries over device-resident draws: include/walnutpie/summary.hpp:119-768 with the reference's
+// function names.  MarkovChains stands where MarkovChainsSplit / MarkovChainsUnified do; results are host vectors
+// ([dims], or row-major [k][dims] for quantiles / [num_draws][dims] for autocovariance).
+// ---------------------------------------------------------------------------------------------------------------
+class MarkovChains {
+ public:
+  /** Chains stacked in one row-major [sum sizes][dims] block on the host (MarkovChainsUnified, summary.hpp:251-356);
+   *  copied to the device. */
+  MarkovChains(const std::vector<double>& draws, const std::vector<std::size_t>& chain_sizes, std::size_t dims,
+               int device = 0) {
+    std::size_t total = 0;
+    std::vector<std::int64_t> sizes;
+    for (std::size_t n : chain_sizes) {
+      total += n;
+      sizes.push_back(static_cast<std::int64_t>(n));
+    }
+    if (dims == 0 || total * dims != draws.size())
+      throw std::invalid_argument("sum of chain sizes must equal number of rows in draws");  // summary.hpp:277-281
+    wn_chains* raw = nullptr;
+    detail::call(wn_chains_upload, &raw, draws.data(), dims, static_cast<const std::int64_t*>(sizes.data()),
+                 sizes.size(), device);
+    h_.reset(raw);
+  }
+  /** One matrix per chain (MarkovChainsSplit, summary.hpp:119-240): chain m is a row-major [rows][dims] block. */
+  static MarkovChains split(const std::vector<std::vector<double>>& chains, std::size_t dims, int device = 0) {
+    if (chains.empty()) throw std::invalid_argument("require at least one chain");
+    std::vector<double> all;
+    std::vector<std::size_t> sizes;
+    for (const auto& c : chains) {
+      if (dims == 0 || c.size() % dims != 0) throw std::invalid_argument("all chains must have the same number of columns");
+      sizes.push_back(c.size() / dims);
+      all.insert(all.end(), c.begin(), c.end());
+    }
+    return MarkovChains(all, sizes, dims, device);
+  }
+  /** Draws already on the device: chain c's n-th draw at draws_dev + c * chain_stride + n * dims (the sampler's draw
+   *  buffer); `lengths` may be null (all max_len); `stream` orders the kernels after the producer. */
+  static MarkovChains view(const double* draws_dev, std::size_t num_chains, std::size_t max_len, std::size_t dims,
+                           std::int64_t chain_stride, const std::int64_t* lengths = nullptr, int device = 0,
+                           void* stream = nullptr) {
+    wn_chains* raw = nullptr;
+    detail::call(wn_chains_view, &raw, draws_dev, num_chains, max_len, dims, chain_stride, lengths, device, stream);
+    MarkovChains m;
+    m.h_.reset(raw);
+    return m;
+  }
+  std::size_t num_chains() const { return wn_chains_num_chains(h_.get()); }
+  std::size_t dims() const { return wn_chains_dims(h_.get()); }
+  std::size_t num_draws() const { return wn_chains_num_draws(h_.get()); }
+  std::size_t min_chain_size() const { return wn_chains_min_chain_size(h_.get()); }
+  wn_chains* handle() const noexcept { return h_.get(); }
+
+ private:
+  MarkovChains() = default;
+  struct Deleter {
+    void operator()(wn_chains* c) const noexcept {
+      if (c) wn_chains_destroy(c);
+    }
+  };
+  std::unique_ptr<wn_chains, Deleter> h_;
+};
+
+namespace detail {
+template <class F>
+inline std::vector<double> summary(F f, const MarkovChains& chains, std::size_t n) {
+  std::vector<double> out(n);
+  call(f, chains.handle(), out.data());
+  return out;
+}
+}  // namespace detail
+
+inline std::vector<double> mean(const MarkovChains& c) { return detail::summary(wn_summary_mean, c, c.dims()); }
+inline std::vector<double> sample_variance(const MarkovChains& c) {
+  return detail::summary(wn_summary_sample_variance, c, c.dims());
+}
+inline std::vector<double> sample_standard_deviation(const MarkovChains& c) {
+  return detail::summary(wn_summary_sample_standard_deviation, c, c.dims());
+}
+inline std::vector<double> r_hat(const MarkovChains& c) { return detail::summary(wn_summary_r_hat, c, c.dims()); }
+inline std::vector<double> effective_sample_size(const MarkovChains& c) {
+  return detail::summary(wn_summary_effective_sample_size, c, c.dims());
+}
+inline std::vector<double> monte_carlo_standard_error(const MarkovChains& c) {
+  return detail::summary(wn_summary_monte_carlo_standard_error, c, c.dims());
+}
+/** Row-major [num_draws][dims]: all lags of every chain, stacked like the draws (summary.hpp:529-545). */
+inline std::vector<double> autocovariance(const MarkovChains& c) {
+  return detail::summary(wn_summary_autocovariance, c, c.num_draws() * c.dims());
+}
+/** Row-major [probs.size()][dims] (summary.hpp:483-514). */
+inline std::vector<double> quantiles(const MarkovChains& c, const std::vector<double>& probs) {
+  std::vector<double> out(probs.size() * c.dims());
+  detail::call(wn_summary_quantiles, c.handle(), probs.data(), probs.size(), out.data());
+  return out;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // drivers

@@ -6,6 +6,7 @@
 // (with -DCPP_SURFACE_MAIN also a command-line program with the same arguments).  Runs walnuts_hip::walnuts() with recording handlers (the reference's examples/handlers.hpp ChainStore, restated),
 // checks the surface's contracts, and writes everything the handlers saw to <dump-file> as raw doubles so that the
 // Python side can compare it bit for bit with the oracle.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -211,6 +212,32 @@ extern "C" __attribute__((visibility("default"))) int cpp_surface_run(const char
     }
     EXPECT(throws<std::out_of_range>([&] { (void)sampler.step_size(C); }, "chain index"));
     EXPECT(throws<std::runtime_error>([&] { adapter(); }, "after freeze"));
+  }
+
+  // ---- posterior summaries with the reference's names (summary.hpp; hand values of tests/summary_test.cpp) ------
+  {
+    // chain 0: [[1,2],[3,4]]  chain 1: [[5,6],[7,8],[9,10]]  chain 2: [[11,12],[13,14],[15,16]]
+    const wh::MarkovChains ex = wh::MarkovChains::split({{1, 2, 3, 4}, {5, 6, 7, 8, 9, 10}, {11, 12, 13, 14, 15, 16}}, 2);
+    EXPECT(ex.num_chains() == 3 && ex.dims() == 2 && ex.num_draws() == 8 && ex.min_chain_size() == 2);
+    const auto near = [](double a, double b) { return std::fabs(a - b) <= 1e-10; };
+    const std::vector<double> mu = wh::mean(ex), var = wh::sample_variance(ex), sd = wh::sample_standard_deviation(ex);
+    EXPECT(near(mu[0], 8.0) && near(mu[1], 9.0) && near(var[0], 24.0) && near(var[1], 24.0));
+    EXPECT(near(sd[0], std::sqrt(24.0)));
+    const std::vector<double> q = wh::quantiles(ex, {0.0, 0.25, 0.5, 0.75, 1.0});   // numpy values, :534-543
+    const double want[10] = {1.0, 2.0, 4.5, 5.5, 8.0, 9.0, 11.5, 12.5, 15.0, 16.0};
+    for (int i = 0; i < 10; ++i) EXPECT(near(q[static_cast<std::size_t>(i)], want[i]));
+    EXPECT(wh::quantiles(wh::MarkovChains({9, 11, 5, 3}, {4}, 1), {0.6})[0] == 8.2);   // doc example, :558-568
+    EXPECT(wh::autocovariance(ex).size() == 16);
+    EXPECT(throws<std::invalid_argument>([&] { (void)wh::quantiles(ex, {1.5}); }, "probs must be in [0, 1]"));
+    EXPECT(throws<std::invalid_argument>([&] { (void)wh::r_hat(ex); }, "at least 3 draws"));
+    const wh::MarkovChains three = wh::MarkovChains::split({{1, 10, 2, 8, 3, 9}, {4, 5, 6, 7, 5, 6}, {7, 2, 9, 4, 8, 3}}, 2);
+    const std::vector<double> rh = wh::r_hat(three);                                 // :846-862
+    EXPECT(std::fabs(rh[0] - std::sqrt(10.0)) <= 1e-14 && std::fabs(rh[1] - std::sqrt(10.0)) <= 1e-14);
+    const std::vector<double> ess = wh::effective_sample_size(three), mcse = wh::monte_carlo_standard_error(three);
+    const std::vector<double> sd3 = wh::sample_standard_deviation(three);
+    EXPECT(ess[0] > 0 && near(mcse[0], sd3[0] / std::sqrt(ess[0])));
+    EXPECT(throws<std::invalid_argument>([&] { (void)wh::r_hat(wh::MarkovChains({1, 2, 3}, {3}, 1)); }, "at least two chains"));
+    EXPECT(throws<std::invalid_argument>([] { wh::MarkovChains({1, 2, 3}, {2}, 1); }, "sum of chain sizes"));
   }
 
   // ---- early stopping bounds (adapt.hpp:172-229, sampler.hpp:117-158) ----------------------------------------

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--state-in-lds", type=int, default=0)
     ap.add_argument("--reserved-cus", type=int, default=-1,
                     help="CUs left free for the RCCL all-gather kernels (default: 0 on one GPU, 16 otherwise)")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="all-gather the draws of every k-th transition (1 = every draw, the north star's exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -180,7 +182,8 @@ def main():
             eng.sample_step(plane.data_ptr(), D)
         # the path's only exchange: all-gather of this iteration's draws over xGMI, overlapped with the next
         # transition (no-op on one GPU)
-        gather.launch(i)
+        if i % args.gather_every == 0:
+            gather.launch(i)
 
     def fence():
         gather.drain()
@@ -241,7 +244,8 @@ def main():
                             f"{args.adapt_iters} on-device adaptive warmup transitions then timed {args.phase} transitions",
                 "chains_per_gpu": C, "global_chains": C * world, "dim": D, "model": args.model,
                 "phase": args.phase, "parallelism": f"chains sharded over {world} GPU(s)"
-                                                    + (f", {'RCCL' if args.backend == 'nccl' else 'gloo'} all-gather of draws each step" if world > 1 else ""),
+                                                    + (f", {'RCCL' if args.backend == 'nccl' else 'gloo'} all-gather of draws every "
+                                                       f"{args.gather_every} step(s)" if world > 1 else ""),
                 "geometry": {"lanes_per_chain": eng.lanes, "dim_padded": eng.dim_padded,
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
                              "reserved_cus": reserved},

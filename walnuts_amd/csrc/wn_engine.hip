@@ -126,7 +126,7 @@ struct wn_engine {
   void check_transitions() {
     use_device();
     HIP_OK(hipMemsetAsync(scratch64.p, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(wn::count_failed_kernel, dim3(256), dim3(256), 0, stream, depth.p, static_cast<int>(C),
+    hipLaunchKernelGGL(wn::count_failed_kernel, dim3(std::min<size_t>(256, (C + 255) / 256)), dim3(256), 0, stream, depth.p, static_cast<int>(C),
                        scratch64.p);
     HIP_OK(hipGetLastError());
     unsigned long long bad = 0;
@@ -661,7 +661,7 @@ int wn_engine_total_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err) 
   return guarded(err, [&] {
     e->use_device();
     HIP_OK(hipMemsetAsync(e->scratch64.p, 0, sizeof(unsigned long long), e->stream));
-    hipLaunchKernelGGL(wn::sum_i64_kernel, dim3(256), dim3(256), 0, e->stream, e->grad_evals.p,
+    hipLaunchKernelGGL(wn::sum_i64_kernel, dim3(std::min<size_t>(256, (e->C + 255) / 256)), dim3(256), 0, e->stream, e->grad_evals.p,
                        static_cast<int>(e->C), e->scratch64.p);
     HIP_OK(hipGetLastError());
     unsigned long long v = 0;

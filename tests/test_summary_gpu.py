@@ -36,6 +36,16 @@ def test_summaries_match_oracle_bitwise(C, D, lens):
     sp.check_all(sp.ar_chains(rng, C, D, lens, phi))
 
 
+def test_many_chains_slabbed_lag_table_matches_oracle_bitwise():
+    """More chains than one slab of the ESS's lag table (8 192): slabs, runs of 256 chains inside them and a partial
+    last run give the oracle's bits; ragged lengths."""
+    rng = np.random.default_rng(77)
+    C, D = 16384 + 300, 3
+    lens = [int(n) for n in rng.integers(6, 40, size=C)]
+    phi = np.array([0.9, 0.0, -0.4])
+    sp.check_all(sp.ar_chains(rng, C, D, lens, phi), probs=(0.1, 0.5), full_acov=False)
+
+
 def test_many_quantiles_and_ties():
     rng = np.random.default_rng(9)
     x = rng.integers(-5, 6, size=(400, 9)).astype(float)

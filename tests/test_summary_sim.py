@@ -32,3 +32,14 @@ def test_emulated_summaries_match_oracle_bitwise(sim, oracle):
     x = rng.integers(-3, 4, size=(30, 3)).astype(float)
     x[x == 0] *= np.where(rng.uniform(size=(x == 0).sum()) < 0.5, -1.0, 1.0)
     sp.check_all([x[:11], x[11:]], lib_path=sim, probs=np.linspace(0, 1, 11))
+
+
+@pytest.mark.timeout(600)
+def test_emulated_lag_table_in_slabs(sim, oracle):
+    # more chains than one slab of the ESS's lag table (256 under the emulation): two slabs, a partial last run
+    rng = np.random.default_rng(8)
+    C = 310
+    chains = sp.ar_chains(rng, C, 1, [int(n) for n in rng.integers(5, 9, size=C)], np.array([0.5]))
+    dev = sp.wa.MarkovChains.from_host(chains, lib_path=sim)
+    assert np.array_equal(sp.ws.effective_sample_size(dev), sp.wnso.effective_sample_size(chains))
+    assert np.array_equal(sp.ws.r_hat(dev), sp.wnso.r_hat(chains))

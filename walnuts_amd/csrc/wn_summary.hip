@@ -32,6 +32,13 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kLagBlock = 16;     // lags per pass of the autocovariance kernel (accumulators + ring in VGPRs)
 constexpr int kChainBlock = 256;  // chains per run of the two-stage sums over chains
+// the ESS computes its lag table for this many chains at a time (a multiple of kChainBlock): the [chains][16][D]
+// workspace stays at 1 GB for 1 024 dimensions however many chains there are
+#if defined(WN_CPU_SIM)
+constexpr int kLagSlabChains = 256;
+#else
+constexpr int kLagSlabChains = 8192;
+#endif
 constexpr int kRows = 8;          // draws a lane loads ahead in the radix-select pass
 constexpr int kMaxTargets = 16;   // order statistics per radix-select sweep (16 * 4 KB of LDS histograms)
 
@@ -118,11 +125,12 @@ static __global__ void block_sum_kernel(const double* a, int C, long long ld, in
   }
   partial[i] = s;
 }
-static __global__ void final_sum_kernel(const double* partial, int nb, int width, double denom, double* out) {
+static __global__ void final_sum_kernel(const double* partial, int nb, long long ld, int width, double denom,
+                                        double* out) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= width) return;
   double s = 0.0;
-  for (int b = 0; b < nb; ++b) s += partial[static_cast<long long>(b) * width + w];
+  for (int b = 0; b < nb; ++b) s += partial[static_cast<long long>(b) * ld + w];
   out[w] = s / denom;
 }
 
@@ -131,15 +139,9 @@ static __global__ void final_sum_kernel(const double* partial, int nb, int width
 // registers, so each draw costs one new load (+ one re-read of x[n], an L2 hit) for kLagBlock multiply-adds, each
 // lag accumulated over n ascending.  Output: blk[c][j][d] (block mode, for the ESS) or the reference's stacked
 // [num_draws][D] table (full mode: row = first draw of the chain + lag).
-static __global__ void acov_block_kernel(View v, const double* cmean, int t0, int max_lag /*exclusive*/, double* blk,
-                                         double* full) {
-  const Slot s = slot_of(v);
-  if (!s.ok) return;
-  const long long D = v.D;
-  const double* p = v.x + v.off[s.c] + s.d;
-  const int n_c = v.len[s.c];
-  const double ybar = cmean[static_cast<long long>(s.c) * D + s.d];
-  double acc[kLagBlock], ring[kLagBlock];
+static __device__ __forceinline__ void chain_lag_block(const double* p, long long D, int n_c, double ybar, int t0,
+                                                       double (&acc)[kLagBlock]) {
+  double ring[kLagBlock];
 #pragma unroll
   for (int j = 0; j < kLagBlock; ++j) {
     acc[j] = 0.0;
@@ -165,12 +167,23 @@ static __global__ void acov_block_kernel(View v, const double* cmean, int t0, in
       }
     }
   }
+}
+static __global__ void acov_block_kernel(View v, int c_base, int c_count, const double* cmean, int t0,
+                                         int max_lag /*exclusive*/, double* blk /*[c_count][kLagBlock][D]*/, double* full) {
+  Slot s = slot_of(v);
+  if (s.c >= c_count || s.d >= v.D) return;
+  const int c_local = s.c;
+  s.c += c_base;
+  const long long D = v.D;
+  const int n_c = v.len[s.c];
+  double acc[kLagBlock];
+  chain_lag_block(v.x + v.off[s.c] + s.d, D, n_c, cmean[static_cast<long long>(s.c) * D + s.d], t0, acc);
 #pragma unroll
   for (int j = 0; j < kLagBlock; ++j) {
     const int t = t0 + j;
     if (t >= max_lag) continue;
     const double val = acc[j] / static_cast<double>(n_c);  // biased estimate, :70-71
-    if (blk != nullptr) blk[(static_cast<long long>(s.c) * kLagBlock + j) * D + s.d] = val;
+    if (blk != nullptr) blk[(static_cast<long long>(c_local) * kLagBlock + j) * D + s.d] = val;
     if (full != nullptr && t < n_c) full[(v.row0[s.c] + t) * D + s.d] = val;
   }
 }
@@ -345,7 +358,7 @@ struct wn_chains {
   bool have_moments = false;
   DevBuf<double> csum, cmean, cvar;
   DevBuf<double> partial;  // run totals of the two-stage sums over chains
-  DevBuf<double> lag_blk;  // [C][kLagBlock][D] workspace of the ESS (kept: reallocating GBs per call costs more than the kernels)
+  DevBuf<double> lag_blk;  // [slab][kLagBlock][D] workspace of the ESS (kept between calls)
 
   wns::View view() const {
     return wns::View{x, off.p, len.p, row0.p, static_cast<int>(C), static_cast<int>(D)};
@@ -410,7 +423,7 @@ void chain_sum(wn_chains* ch, const double* a, long long ld, int width, const do
   hipLaunchKernelGGL(wns::block_sum_kernel, dim3(col_blocks(static_cast<size_t>(nb) * width)), dim3(wns::kBlock), 0,
                      ch->stream, a, C, ld, width, mu, ch->partial.p);
   hipLaunchKernelGGL(wns::final_sum_kernel, dim3(col_blocks(width)), dim3(wns::kBlock), 0, ch->stream, ch->partial.p, nb,
-                     width, denom, d_out);
+                     static_cast<long long>(width), width, denom, d_out);
   HIP_OK(hipGetLastError());
 }
 void device_mean(wn_chains* ch, double* d_out /*device [D]*/) {  // :370-378
@@ -465,7 +478,11 @@ void host_effective_sample_size(wn_chains* ch, double* out) {
     for (int d = 0; d < D; ++d) h_vp[d] += h_b[d];
   }
   HIP_OK(hipMemcpyAsync(var_plus.p, h_vp.data(), D * sizeof(double), hipMemcpyHostToDevice, ch->stream));
-  if (blk.n == 0) blk.alloc(static_cast<size_t>(C) * wns::kLagBlock * D);
+  const int slab = std::min(C, wns::kLagSlabChains);
+  const int runs_of_chains = (C + wns::kChainBlock - 1) / wns::kChainBlock;
+  if (blk.n < static_cast<size_t>(slab) * wns::kLagBlock * D) blk.alloc(static_cast<size_t>(slab) * wns::kLagBlock * D);
+  if (ch->partial.n < static_cast<size_t>(runs_of_chains) * wns::kLagBlock * D)
+    ch->partial.alloc(static_cast<size_t>(runs_of_chains) * wns::kLagBlock * D);
   macov.alloc(static_cast<size_t>(min_len) * D);
   rho.alloc(static_cast<size_t>(min_len) * D);
   even.alloc(D);
@@ -479,11 +496,20 @@ void host_effective_sample_size(wn_chains* ch, double* out) {
   bool first = true;
   while (true) {
     const int t0 = avail, nl = std::min(wns::kLagBlock, min_len - t0);
-    hipLaunchKernelGGL(wns::acov_block_kernel, dim3(wns::slot_blocks(C, D)), dim3(wns::kBlock), 0, ch->stream, ch->view(),
-                       ch->cmean.p, t0, min_len, blk.p, static_cast<double*>(nullptr));
-    // mean_acov_at_lag (:696-704) for the block's lags: blk is a [C][kLagBlock * D] matrix
-    chain_sum(ch, blk.p, static_cast<long long>(wns::kLagBlock) * D, nl * D, nullptr, static_cast<double>(C),
-              macov.p + static_cast<size_t>(t0) * D);
+    // mean_acov_at_lag (:696-704) for the block's lags: slab by slab, the per-chain lag values go to the workspace
+    // and the runs of kChainBlock chains inside the slab are summed; then the run totals, left to right
+    const int width = wns::kLagBlock * D;
+    for (int c0 = 0; c0 < C; c0 += slab) {
+      const int cn = std::min(slab, C - c0), nb = (cn + wns::kChainBlock - 1) / wns::kChainBlock;
+      hipLaunchKernelGGL(wns::acov_block_kernel, dim3(wns::slot_blocks(cn, D)), dim3(wns::kBlock), 0, ch->stream,
+                         ch->view(), c0, cn, ch->cmean.p, t0, min_len, blk.p, static_cast<double*>(nullptr));
+      hipLaunchKernelGGL(wns::block_sum_kernel, dim3(col_blocks(static_cast<size_t>(nb) * width)), dim3(wns::kBlock), 0,
+                         ch->stream, blk.p, cn, static_cast<long long>(width), width, static_cast<const double*>(nullptr),
+                         ch->partial.p + static_cast<size_t>(c0 / wns::kChainBlock) * width);
+    }
+    hipLaunchKernelGGL(wns::final_sum_kernel, dim3(col_blocks(static_cast<size_t>(nl) * D)), dim3(wns::kBlock), 0,
+                       ch->stream, ch->partial.p, runs_of_chains, static_cast<long long>(width), nl * D,
+                       static_cast<double>(C), macov.p + static_cast<size_t>(t0) * D);
     avail += nl;
     HIP_OK(hipMemsetAsync(need.p, 0, sizeof(int), ch->stream));
     hipLaunchKernelGGL(wns::geyer_kernel, dim3(col_blocks(D)), dim3(wns::kBlock), 0, ch->stream, D, min_len, avail,
@@ -626,7 +652,7 @@ int wn_summary_autocovariance(wn_chains* ch, double* out, WalnutpyError** err) {
     full.alloc(static_cast<size_t>(ch->N) * D);
     for (int t0 = 0; t0 < ch->max_len; t0 += wns::kLagBlock)
       hipLaunchKernelGGL(wns::acov_block_kernel, dim3(wns::slot_blocks(C, D)), dim3(wns::kBlock), 0, ch->stream,
-                         ch->view(), ch->cmean.p, t0, ch->max_len, static_cast<double*>(nullptr), full.p);
+                         ch->view(), 0, C, ch->cmean.p, t0, ch->max_len, static_cast<double*>(nullptr), full.p);
     HIP_OK(hipGetLastError());
     ch->down(full.p, out, static_cast<size_t>(ch->N) * D);
   });

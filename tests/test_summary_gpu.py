@@ -50,6 +50,9 @@ def test_many_quantiles_and_ties():
     rng = np.random.default_rng(9)
     x = rng.integers(-5, 6, size=(400, 9)).astype(float)
     sp.check_all([x[:150], x[150:]], probs=np.linspace(0, 1, 41), full_acov=False)
+    z = rng.integers(0, 2, size=(30000, 3)).astype(float)      # two values, 15 000 ties each: every radix pass runs
+    z[:, 2] += rng.normal(size=30000) * 1e-9                   # ... next to a column that takes the gathered finish
+    sp.check_all([z[:9000], z[9000:]], probs=[0.0, 0.3, 0.5, 0.77, 1.0], full_acov=False)
     y = rng.normal(size=(999, 5)) * 10.0 ** rng.integers(-300, 300, size=5)   # every binade
     sp.check_all([y[:500], y[500:]], probs=[0.0, 1e-9, 0.5, 1 - 1e-9, 1.0], full_acov=False)
 

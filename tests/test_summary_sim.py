@@ -27,7 +27,7 @@ def test_emulated_summaries_match_oracle_bitwise(sim, oracle):
     # ragged chains, two column tiles (D > 64), lags beyond one lag block, strong and weak autocorrelation
     D = 70
     phi = np.where(np.arange(D) % 3 == 0, 0.95, 0.1)
-    sp.check_all(sp.ar_chains(rng, 3, D, [41, 37, 52], phi), lib_path=sim)
+    sp.check_all(sp.ar_chains(rng, 3, D, [41, 37, 52], phi), lib_path=sim, probs=(0.0, 0.6))
     # more order statistics than one radix-select sweep holds; duplicates, negative values, zeros of both signs
     x = rng.integers(-3, 4, size=(30, 3)).astype(float)
     x[x == 0] *= np.where(rng.uniform(size=(x == 0).sum()) < 0.5, -1.0, 1.0)

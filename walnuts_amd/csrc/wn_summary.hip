@@ -40,7 +40,14 @@ constexpr int kLagSlabChains = 256;
 constexpr int kLagSlabChains = 8192;
 #endif
 constexpr int kRows = 8;          // draws a lane loads ahead in the radix-select pass
-constexpr int kMaxTargets = 16;   // order statistics per radix-select sweep (16 * 4 KB of LDS histograms)
+constexpr int kMaxTargets = 16;
+// radix select: draws left per (target, dimension) at which the rest is finished in a gathered list instead of more
+// passes over all draws
+#if defined(WN_CPU_SIM)
+constexpr int kCandidateCap = 8;
+#else
+constexpr int kCandidateCap = 2048;
+#endif   // order statistics per radix-select sweep (16 * 4 KB of LDS histograms)
 
 struct View {
   const double* x;        // draws
@@ -318,7 +325,8 @@ static __global__ void radix_hist_kernel(View v, int T, int shift, int first, co
 }
 // choose the bin that holds the target's rank; extend its prefix; make the rank relative to the bin
 static __global__ void radix_pick_kernel(int D, int T, int shift, int first, const unsigned long long* ghist,
-                                         unsigned long long* prefix, unsigned long long* rank) {
+                                         unsigned long long* prefix, unsigned long long* rank,
+                                         unsigned long long* match /*draws left in the chosen bin*/) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= T * D) return;
   const int t = i / D, d = i % D;
@@ -335,6 +343,79 @@ static __global__ void radix_pick_kernel(int D, int T, int shift, int first, con
   }
   prefix[i] |= static_cast<unsigned long long>(bin) << shift;
   rank[i] = r - below;
+  match[i] = h[bin];
+}
+
+// Once few draws are left in every target's bin, the remaining passes over ALL draws are replaced by one pass that
+// copies the keys still in the running (high bits above `shift` equal to the target's prefix) to a short list per
+// (target, dimension) ...
+static __global__ void radix_collect_kernel(View v, int T, int shift, const unsigned long long* prefix, int cap,
+                                            unsigned long long* cand /*[T*D][cap]*/, unsigned* cand_n /*[T*D]*/,
+                                            int chains_per_block) {
+  const int tiles = (v.D + 63) / 64;
+  const int tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+  const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
+  const int d = tile * 64 + lane;
+  if (d >= v.D) return;
+  unsigned long long pre_hi[kMaxTargets];
+#pragma unroll
+  for (int t = 0; t < kMaxTargets; ++t) pre_hi[t] = t < T ? prefix[static_cast<long long>(t) * v.D + d] >> shift : ~0ull;
+  const int c_hi = (chunk + 1) * chains_per_block, c_end = c_hi < v.C ? c_hi : v.C;
+  for (int c = chunk * chains_per_block + wave; c < c_end; c += kWaves) {
+    const double* p = v.x + v.off[c] + d;
+    const int n = v.len[c];
+    for (int i0 = 0; i0 < n; i0 += kRows) {
+      double x[kRows];
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) x[r] = (i0 + r < n) ? p[static_cast<long long>(i0 + r) * v.D] : 0.0;
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        if (i0 + r >= n) break;
+        const unsigned long long k = order_key(x[r]);
+        const unsigned long long k_hi = k >> shift;
+#pragma unroll
+        for (int t = 0; t < kMaxTargets; ++t) {
+          if (k_hi == pre_hi[t]) {
+            const long long slot = static_cast<long long>(t) * v.D + d;
+            const unsigned pos = atomicAdd(&cand_n[slot], 1u);
+            if (pos < static_cast<unsigned>(cap)) cand[slot * cap + pos] = k;
+          }
+        }
+      }
+    }
+  }
+}
+// ... and the order statistic is finished inside the list, one bit at a time (the list's order does not matter).
+// One 64-thread block per (target, dimension).
+static __global__ void radix_finish_kernel(int TD, int shift, int cap, const unsigned long long* cand,
+                                           const unsigned* cand_n, unsigned long long* prefix, unsigned long long* rank) {
+  __shared__ unsigned cnt0;
+  const int slot = blockIdx.x;
+  if (slot >= TD) return;
+  const unsigned long long* list = cand + static_cast<long long>(slot) * cap;
+  const int n = static_cast<int>(cand_n[slot]);
+  unsigned long long pre = prefix[slot], r = rank[slot];
+  for (int b = shift - 1; b >= 0; --b) {
+    if (threadIdx.x == 0) cnt0 = 0u;
+    __syncthreads();
+    unsigned mine = 0u;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const unsigned long long k = list[i];
+      if ((k >> (b + 1)) == (pre >> (b + 1)) && ((k >> b) & 1ull) == 0ull) ++mine;
+    }
+    if (mine) atomicAdd(&cnt0, mine);
+    __syncthreads();
+    const unsigned long long zeros = cnt0;
+    if (r >= zeros) {
+      pre |= 1ull << b;
+      r -= zeros;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    prefix[slot] = pre;
+    rank[slot] = r;
+  }
 }
 
 }  // namespace wns
@@ -716,13 +797,33 @@ int wn_summary_quantiles(wn_chains* ch, const double* probs, size_t num_probs, d
       const size_t smem = static_cast<size_t>(T) * 16 * 64 * sizeof(unsigned);
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(wns::radix_hist_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+      DevBuf<unsigned long long> match, cand;
+      DevBuf<unsigned> cand_n;
+      match.alloc(static_cast<size_t>(T) * D);
+      std::vector<unsigned long long> h_match(static_cast<size_t>(T) * D);
       for (int pass = 0; pass < 16; ++pass) {
         const int shift = 60 - 4 * pass, first = pass == 0 ? 1 : 0;
         HIP_OK(hipMemsetAsync(ghist.p, 0, ghist.n * sizeof(unsigned long long), ch->stream));
         hipLaunchKernelGGL(wns::radix_hist_kernel, dim3(chunks * tiles), dim3(wns::kBlock), smem, ch->stream, ch->view(),
                            T, shift, first, prefix.p, ghist.p, chains_per_block);
         hipLaunchKernelGGL(wns::radix_pick_kernel, dim3(col_blocks(static_cast<size_t>(T) * D)), dim3(wns::kBlock), 0,
-                           ch->stream, D, T, shift, first, ghist.p, prefix.p, rank.p);
+                           ch->stream, D, T, shift, first, ghist.p, prefix.p, rank.p, match.p);
+        if (pass >= 2 && pass < 15) {
+          // few draws left in every bin?  then gather them once and finish there instead of passing over all the
+          // draws another (15 - pass) times
+          ch->down(match.p, h_match.data(), h_match.size());
+          const unsigned long long most = *std::max_element(h_match.begin(), h_match.end());
+          if (most <= static_cast<unsigned long long>(wns::kCandidateCap)) {
+            cand.alloc(static_cast<size_t>(T) * D * wns::kCandidateCap);
+            cand_n.alloc(static_cast<size_t>(T) * D);
+            HIP_OK(hipMemsetAsync(cand_n.p, 0, cand_n.n * sizeof(unsigned), ch->stream));
+            hipLaunchKernelGGL(wns::radix_collect_kernel, dim3(chunks * tiles), dim3(wns::kBlock), 0, ch->stream,
+                               ch->view(), T, shift, prefix.p, wns::kCandidateCap, cand.p, cand_n.p, chains_per_block);
+            hipLaunchKernelGGL(wns::radix_finish_kernel, dim3(T * D), dim3(64), 0, ch->stream, T * D, shift,
+                               wns::kCandidateCap, cand.p, cand_n.p, prefix.p, rank.p);
+            break;
+          }
+        }
       }
       HIP_OK(hipGetLastError());
       std::vector<unsigned long long> h_key(static_cast<size_t>(T) * D);

@@ -5,7 +5,6 @@ saw; here the dump is compared bit for bit with the oracle run through the same 
 
 CPU tier: linked against the workgroup emulation.  GPU tier: linked against libwalnuts_hip.so."""
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -19,21 +18,8 @@ import parity  # noqa: E402
 wno = parity.wno
 
 
-def surface_library(tag: str) -> str:
-    return os.path.join(HERE, "cpp", f"libcpp_surface_{tag}.so")
-
-
-def build_surface_library(lib_path: str, tag: str) -> str:
-    """g++ the C++ test into a shared library linked against `lib_path` (also called by __graft_entry__.build())."""
-    out = surface_library(tag)
-    src = os.path.join(HERE, "cpp", "cpp_surface.cpp")
-    hdrs = [os.path.join(ROOT, "include", h) for h in ("walnuts_hip.hpp", "walnuts_hip.h")]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in [src, lib_path] + hdrs):
-        return out
-    libdir = os.path.dirname(lib_path)
-    subprocess.check_call(["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", "-I",
-                           os.path.join(ROOT, "include"), src, "-o", out, lib_path, f"-Wl,-rpath,{libdir}", "-pthread"])
-    return out
+sys.path.insert(0, os.path.join(HERE, "cpp"))
+from build_surface import build_surface_library, surface_library  # noqa: E402
 
 
 def run_and_compare(surface: str, lib_path: str, model: str, C: int, D: int, W: int, S: int, seed: int, tmp_path):

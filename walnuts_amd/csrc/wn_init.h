@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
     if (Q.do_masses) {
       (void)t.model_eval();
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) mass[j] = t.valid(j) ? (1 - Q.smoothing) * fabs(t.g[j]) + Q.smoothing : 1.0;
+      for (int j = 0; j < EPL; ++j) mass[j] = t.valid(j) ? (1 - Q.smoothing) * fabs(t.G(j)) + Q.smoothing : 1.0;
       t.vstore(Q.mass + row, mass);
     } else {
       t.vload(Q.mass + row, mass);
@@ -104,12 +104,12 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
         double lp, lj0, lj1;
         t.energy(part, lp, lj0);
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) t.rh[j] = t.rh[j] + 0.5 * h * t.g[j];
+        for (int j = 0; j < EPL; ++j) t.rh[j] = t.rh[j] + 0.5 * h * t.G(j);
 #pragma unroll
         for (int j = 0; j < EPL; ++j) t.th[j] = t.th[j] + h * (t.im[j] * t.rh[j]);
         part = t.model_eval();
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) t.rh[j] = t.rh[j] + 0.5 * h * t.g[j];
+        for (int j = 0; j < EPL; ++j) t.rh[j] = t.rh[j] + 0.5 * h * t.G(j);
         t.energy(part, lp, lj1);
         return lj1 - lj0;
       };

@@ -129,6 +129,8 @@ struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
   static constexpr int kKind = kStdNormal;
   static constexpr bool kUsesParams = false;
   static constexpr bool kElementwise = true;
+  // grad = -theta: the register kernels carry no gradient vector at all (a sign modifier on theta at every use)
+  static constexpr bool kGradIsNegTheta = true;
   struct Aux {};
   template <int EPL, class Cx>
   __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
@@ -153,6 +155,7 @@ struct DiagNormalModel {  // examples/examples.cpp:20-31, params = sigma_sq
   static constexpr int kKind = kDiagNormal;
   static constexpr bool kUsesParams = true;
   static constexpr bool kElementwise = true;
+  static constexpr bool kGradIsNegTheta = false;
   struct Aux {};
   template <int EPL, class Cx>
   __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
@@ -176,6 +179,7 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
   static constexpr int kKind = kFunnel;
   static constexpr bool kUsesParams = false;
   static constexpr bool kElementwise = false;  // the gradient needs sum(x^2): register backend only
+  static constexpr bool kGradIsNegTheta = false;
   struct Aux {
     double v, S, hev;
   };
@@ -738,6 +742,10 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
   static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
+  // gradient of the moving end at element j.  Where it is just -theta (standard normal) nothing is stored, parked or
+  // reloaded for it: `g` is dead, its pool buffers are bookkeeping only, and 2*EPL registers are free.
+  static constexpr bool kNoGrad = Model::kGradIsNegTheta;
+  __device__ __forceinline__ double G(int j) const { return kNoGrad ? -th[j] : g[j]; }
   // restart state.  Its gradient is re-evaluated on a retry (a pure function of th0) when that is a couple of
   // element-wise operations; a model whose gradient needs a reduction and an exponential (the funnel, where retries
   // are frequent) keeps the copy the reference keeps (walnuts.hpp:326)
@@ -826,7 +834,9 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
     switch (c) {
       case kTh: pool_store(b, th); break;
       case kRh: pool_store(b, rh); break;
-      case kG: pool_store(b, g); break;
+      case kG:
+        if (!kNoGrad) pool_store(b, g);
+        break;
       case kTh0:
         if (LDS_STATE) {
           double t[EPL];
@@ -851,7 +861,9 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
     switch (c) {
       case kTh: pool_load(b, th); break;
       case kRh: pool_load(b, rh); break;
-      default: pool_load(b, g); break;
+      default:
+        if (!kNoGrad) pool_load(b, g);
+        break;
     }
   }
 
@@ -881,14 +893,14 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
     double part = 0.0;
     for (int s = 0; s < n; ++s) {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) rh[j] += half * g[j];
+      for (int j = 0; j < EPL; ++j) rh[j] += half * G(j);
       with_im([&](const double (&m)[EPL]) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) th[j] += h * m[j] * rh[j];
       });
       part = model_eval();
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) rh[j] += half * g[j];
+      for (int j = 0; j < EPL; ++j) rh[j] += half * G(j);
     }
     return part;
   }
@@ -905,16 +917,16 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
   // while coarser reverse paths are tried from (theta', -rho', grad').
   __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
     if (n == 1) return true;
-    const int k0 = this->alloc(), k1 = this->alloc(), k2 = this->alloc();  // short-lived: LDS first
+    const int k0 = this->alloc(), k1 = this->alloc(), k2 = kNoGrad ? -1 : this->alloc();  // short-lived: LDS first
     pool_store(k0, th);
     pool_store(k1, rh);
-    pool_store(k2, g);
+    if (!kNoGrad) pool_store(k2, g);
     bool result = true;
     bool first = true;
     while (n >= 2 * min_micro) {
       if (!first) {
         pool_load(k0, th);
-        pool_load(k2, g);
+        if (!kNoGrad) pool_load(k2, g);
       }
       first = false;
       double keep[EPL];
@@ -930,7 +942,7 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
     }
     pool_load(k0, th);
     pool_load(k1, rh);
-    pool_load(k2, g);
+    if (!kNoGrad) pool_load(k2, g);
     this->release(k0);
     this->release(k1);
     this->release(k2);
@@ -952,7 +964,7 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
     } else {
       pool_store(start_buf[0], th);
       pool_store(start_buf[1], rh);
-      pool_store(start_buf[2], g);
+      if (!kNoGrad) pool_store(start_buf[2], g);
     }
   }
   __device__ __forceinline__ void macro_retry() {
@@ -970,7 +982,7 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
       if (kKeepRestartGrad) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) g[j] = g0[j];
-      } else {
+      } else if (!kNoGrad) {
         // the restart gradient is a pure function of the restart position: same bits as the copy the
         // reference keeps (walnuts.hpp:326), without holding a third vector for the rare retry
         double unused = 0.0;
@@ -979,7 +991,7 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
     } else {
       pool_load(start_buf[0], th);
       pool_load(start_buf[1], rh);
-      pool_load(start_buf[2], g);
+      if (!kNoGrad) pool_load(start_buf[2], g);
     }
   }
   __device__ __forceinline__ void macro_commit() {}
@@ -1095,8 +1107,8 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
       vload(P.est_score_ssd + row, ssd);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
-        mean[j] += (g[j] - mean[j]) / ws;
-        ssd[j] = discount * ssd[j] + (g[j] - mean[j]) * (g[j] - mean[j]);
+        mean[j] += (G(j) - mean[j]) / ws;
+        ssd[j] = discount * ssd[j] + (G(j) - mean[j]) * (G(j) - mean[j]);
       }
       vstore(P.est_score_mean + row, mean);
       vstore(P.est_score_ssd + row, ssd);

@@ -16,6 +16,8 @@ lib.wn_default_config(cfg)
 if len(sys.argv) > 9:  # wn_config: 4 x int32, 9 x double, then waves_per_chain / elems_per_lane / workgroups_per_cu
     import struct
     struct.pack_into("iii", cfg, 88, *(int(x) for x in sys.argv[7:10]))
+    if len(sys.argv) > 10:
+        struct.pack_into("i", cfg, 100, int(sys.argv[10]))  # lds_vectors
 eng = vp()
 
 

@@ -304,7 +304,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   // residency: how many chains (workgroups) share a CU, and how much of the span pool sits in LDS
   const size_t lds_per_cu = 160 * 1024;
   e.pool_total = std::min(required_pool(cfg, e.geo.start_regs) + (e.geo.mem ? wn::kMemRoleVectors : 0), wn::kMaxPool);
-  int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo);
+  int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo, model == WN_MODEL_STD_NORMAL);
   wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
   e.lds_state = e.geo.lds_wpe > 0 ? 3 : 0;
   const size_t fixed = wn::transition_smem_bytes(e.geo.nw, e.lds_state, e.Dp);

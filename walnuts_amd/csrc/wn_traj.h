@@ -1495,8 +1495,15 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
 #endif
 }
 
+// Without a gradient vector (grad = -theta) the 8-elements-per-lane kernels are built for three wavefronts per SIMD:
+// the 31 VGPRs that spill to scratch cost less than the third wave hides (measured: 2.95 -> 2.55 ms per step on the
+// headline workload with 6 chains per CU).
+template <class Model, int EPL>
+constexpr int min_waves_per_simd() {
+  return (Model::kGradIsNegTheta && EPL == 8) ? 3 : 1;
+}
 template <class Model, int NW, int EPL, bool START_REGS>
-__global__ __launch_bounds__(64 * NW) void transition_kernel(const Params P) {
+__global__ __launch_bounds__(64 * NW, (min_waves_per_simd<Model, EPL>())) void transition_kernel(const Params P) {
   persistent_loop<TrajReg<Model, NW, EPL, START_REGS>, NW>(P);
 }
 

@@ -29,7 +29,8 @@ def call(fn, *a):
         raise RuntimeError(lib.walnutpie_get_error_message(err).decode())
 
 
-call(lib.wn_engine_create, C.byref(eng), model, dim, None, C.c_size_t(chains), cfg)
+params = (C.c_double * dim)(*[(1.0 + (d % 16)) ** 2 for d in range(dim)]) if model == 1 else None
+call(lib.wn_engine_create, C.byref(eng), model, dim, params, C.c_size_t(chains), cfg)
 call(lib.wn_engine_init_positions, eng, C.c_uint64(1234), C.c_uint32(0), C.c_double(2.0))
 call(lib.wn_engine_init_masses_from_grad, eng, C.c_double(1e-5))
 steps_arr = (C.c_double * chains)(*([1.0] * chains))

@@ -97,3 +97,20 @@ def test_cpp_surface_on_gpu(gpu, tmp_path, model, C, D, W, S):
     # prebuilt by __graft_entry__.build(): a process that spawns children (a compiler) on the GPU box loses its GPU
     assert os.path.exists(surface), "tests/cpp/libcpp_surface_hip.so missing: run __graft_entry__.build()"
     run_and_compare(surface, _ffi.DEFAULT_LIB, model, C, D, W, S, 4242, tmp_path)
+
+
+@pytest.mark.timeout(600)
+def test_example_program_builds_and_runs_under_emulation(tmp_path):
+    """examples/walnuts_hip_api.cpp (the device counterpart of the reference's examples/walnutpie_api.cpp) compiles
+    warning-free against include/walnuts_hip.hpp and runs end to end (tiny sizes, workgroup emulation)."""
+    import subprocess
+
+    import build as simbuild
+    sim = simbuild.build()
+    exe = str(tmp_path / "walnuts_hip_api")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "walnuts_hip_api.cpp"), sim,
+                           f"-Wl,-rpath,{os.path.dirname(sim)}", "-pthread", "-o", exe])
+    r = subprocess.run([exe, "2", "3", "2", "4"], capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FINISHED NORMALLY." in r.stdout and "# warmup_draws = 2; # draws = 4" in r.stdout

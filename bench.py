@@ -36,7 +36,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chains", type=int, default=65536, help="chains PER GPU (weak scaling)")
     ap.add_argument("--dim", type=int, default=1024)
-    ap.add_argument("--model", default="std_normal", choices=["std_normal", "diag_normal", "funnel"])
+    ap.add_argument("--model", default="std_normal", choices=["std_normal", "diag_normal", "ill_normal", "funnel"],
+                    help="diag_normal: sigma_d = 1 + (d mod 16) (config #4); ill_normal: sigma_d = d + 1 (config #2, "
+                         "examples/examples.cpp:20-31)")
     ap.add_argument("--adapt-iters", type=int, default=100, help="untimed adaptive warmup transitions")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--waves-per-chain", type=int, default=0)
@@ -64,6 +66,8 @@ def model_setup(name, D):
         return wa.MODEL_STD_NORMAL, None
     if name == "funnel":
         return wa.MODEL_FUNNEL, None
+    if name == "ill_normal":
+        return wa.MODEL_DIAG_NORMAL, np.array([(d + 1.0) ** 2 for d in range(D)])
     return wa.MODEL_DIAG_NORMAL, np.array([(1.0 + (d % 16)) ** 2 for d in range(D)])
 
 
@@ -88,7 +92,8 @@ def cpu_baseline(args, D):
 
     cores = os.cpu_count() or 1
     chains = 8 * cores
-    om = {"std_normal": wno.MODEL_STD_NORMAL, "diag_normal": wno.MODEL_DIAG_NORMAL, "funnel": wno.MODEL_FUNNEL}[args.model]
+    om = {"std_normal": wno.MODEL_STD_NORMAL, "diag_normal": wno.MODEL_DIAG_NORMAL, "ill_normal": wno.MODEL_DIAG_NORMAL,
+          "funnel": wno.MODEL_FUNNEL}[args.model]
     _, params = model_setup(args.model, D)
     cfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=0)
     e = wno.Engine(om, D, chains, cfg, params=params)

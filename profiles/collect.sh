@@ -13,7 +13,7 @@ HEAD="--steps 10 --warmup 3 --adapt-iters 100"
 CFG4="--model diag_normal --chains 8192 --dim 16384 --steps 5 --warmup 2 --adapt-iters 100"
 python3 $ROOT/bench.py > $OUT/bench_headline.json 2> $OUT/bench_headline.err
 python3 $ROOT/bench.py --phase warmup --no-cpu-baseline > $OUT/bench_headline_warmup.json 2>> $OUT/bench_headline.err
-python3 $ROOT/bench.py --no-cpu-baseline --model diag_normal --chains 4096 --dim 1024 --adapt-iters 300 > $OUT/bench_cfg2.json 2>> $OUT/bench_headline.err
+python3 $ROOT/bench.py --no-cpu-baseline --model ill_normal --chains 4096 --dim 1024 --adapt-iters 300 > $OUT/bench_cfg2.json 2>> $OUT/bench_headline.err
 python3 $ROOT/bench.py --no-cpu-baseline --model funnel --chains 16384 --dim 128 --adapt-iters 300 > $OUT/bench_cfg3.json 2>> $OUT/bench_headline.err
 python3 $ROOT/bench.py --no-cpu-baseline $CFG4 > $OUT/bench_cfg4.json 2>> $OUT/bench_headline.err
 rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline $HEAD > /dev/null 2>&1

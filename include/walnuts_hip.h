@@ -224,6 +224,8 @@ WALNUTS_HIP_EXPORT int wn_engine_kernel_times(wn_engine* e, float* ms_out, int m
  * draws are ordered after the kernels without host synchronisation) */
 WALNUTS_HIP_EXPORT int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane);
+/* the default launch geometry depends on the model (heavier gradients prefer one wavefront per chain) */
+WALNUTS_HIP_EXPORT int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane);
 /* (internal) allocates the error object handed back through WalnutpyError** */
 WALNUTS_HIP_EXPORT void* wn_internal_make_error(const char* msg, int type);
 

@@ -49,7 +49,8 @@ def run_and_compare(surface: str, lib_path: str, model: str, C: int, D: int, W: 
     # the same recipe on the oracle (device arithmetic order): InitConfigBuilder verbs, then api.hpp:46-69
     _, om = parity.MODELS[model]
     from walnuts_amd import _ffi
-    lanes = _ffi.load_library(lib_path).wn_lanes_for_dim(D, 0, 0)   # reduction width of the default geometry
+    dm, _ = parity.MODELS[model]
+    lanes = _ffi.load_library(lib_path).wn_lanes_for_model_dim(dm, D, 0, 0)   # reduction width of the default geometry
     cfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_PORTABLE, reduce_lanes=lanes)
     o = wno.Engine(om, D, C, cfg, params=parity.model_params(model, D))
     o.init_positions(seed + 5, 0, 2.0)

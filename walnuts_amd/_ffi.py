@@ -107,6 +107,7 @@ SYMBOLS = [
     ("wn_engine_kernel_times", _i32, [_vp, C.POINTER(C.c_float), _i32, C.POINTER(C.c_int), _errpp]),
     ("wn_engine_set_stream", _i32, [_vp, _vp, _errpp]),
     ("wn_lanes_for_dim", _i32, [_i32, _i32, _i32]),
+    ("wn_lanes_for_model_dim", _i32, [_i32, _i32, _i32, _i32]),
     # posterior summaries (summary.hpp:370-768)
     ("wn_chains_view", _i32, [C.POINTER(_vp), _vp, _sz, _sz, _sz, C.c_int64, C.POINTER(C.c_int64), _i32, _vp, _errpp]),
     ("wn_chains_upload", _i32, [C.POINTER(_vp), _dp, _sz, C.POINTER(C.c_int64), _sz, _i32, _errpp]),

@@ -288,7 +288,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.C = num_chains;
   e.cfg = cfg;
   e.device = cfg.device;
-  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane);
+  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, model == WN_MODEL_STD_NORMAL);
   if (!e.geo.mem && cfg.state_in_lds > 0) {
     if (!wn::lds_geometry_exists(e.geo.nw, e.geo.epl, cfg.state_in_lds))
       throw std::invalid_argument("no LDS-state kernel for this geometry / waves-per-SIMD budget");
@@ -809,12 +809,15 @@ int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {
     e->own_stream = false;
   });
 }
-int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane) {
+int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {
   try {
-    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane).nw;
+    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, model == WN_MODEL_STD_NORMAL).nw;
   } catch (...) {
     return -1;
   }
+}
+int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane) {
+  return wn_lanes_for_model_dim(WN_MODEL_STD_NORMAL, num_params, waves_per_chain, elems_per_lane);
 }
 
 }  // extern "C"

@@ -117,8 +117,14 @@ struct Model {
       case WNO_MODEL_DIAG_NORMAL: {
         // examples/examples.cpp:20-31 with sigma_sq supplied per coordinate
         const double* s2 = params.data();
-        logp = r.sum(D, [&](size_t i) { return -0.5 * x[i] * x[i] / s2[i]; });
-        for (size_t i = 0; i < D; ++i) g[i] = -x[i] / s2[i];
+        if (m.mode == WNO_MATH_PORTABLE) {
+          // device arithmetic: the engine multiplies by 1/sigma_sq, rounded once (wn_engine_create)
+          logp = r.sum(D, [&](size_t i) { return -0.5 * x[i] * x[i] * (1.0 / s2[i]); });
+          for (size_t i = 0; i < D; ++i) g[i] = -x[i] * (1.0 / s2[i]);
+        } else {
+          logp = r.sum(D, [&](size_t i) { return -0.5 * x[i] * x[i] / s2[i]; });
+          for (size_t i = 0; i < D; ++i) g[i] = -x[i] / s2[i];
+        }
         break;
       }
       case WNO_MODEL_FUNNEL: {

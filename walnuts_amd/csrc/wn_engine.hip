@@ -359,6 +359,14 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   {
     std::vector<double> mp(e.Dp, 1.0);
     if (model_params) std::copy(model_params, model_params + num_params, mp.begin());
+    if (model == WN_MODEL_DIAG_NORMAL) {
+      // the kernels multiply by 1/sigma_sq, rounded once here, instead of dividing by sigma_sq at every gradient
+      // evaluation (an fp64 division costs about ten multiply-adds on the device; DESIGN.md "differs on purpose")
+      for (int i = 0; i < num_params; ++i) {
+        if (!(mp[i] > 0) || !std::isfinite(mp[i])) throw std::invalid_argument("sigma_sq must be positive and finite");
+        mp[i] = 1.0 / mp[i];
+      }
+    }
     HIP_OK(hipMemcpyAsync(e.model_params.p, mp.data(), mp.size() * sizeof(double), hipMemcpyHostToDevice, e.stream));
     HIP_OK(hipStreamSynchronize(e.stream));
   }

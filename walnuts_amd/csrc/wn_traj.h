@@ -151,7 +151,9 @@ struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
   __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return -0.5 * sum; }
 };
 
-struct DiagNormalModel {  // examples/examples.cpp:20-31, params = sigma_sq
+// The device receives 1/sigma_sq (rounded once on the host, wn_engine_create) and multiplies where the reference's
+// example divides: (-0.5 x x) * (1/s2) and -x * (1/s2) -- within an ulp of the quotients, a third of the instructions.
+struct DiagNormalModel {  // examples/examples.cpp:20-31, params = 1 / sigma_sq
   static constexpr int kKind = kDiagNormal;
   static constexpr bool kUsesParams = true;
   static constexpr bool kElementwise = true;
@@ -159,18 +161,18 @@ struct DiagNormalModel {  // examples/examples.cpp:20-31, params = sigma_sq
   struct Aux {};
   template <int EPL, class Cx>
   __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
-                                              const double (&s2)[EPL], Aux&, double& acc) {
+                                              const double (&rs2)[EPL], Aux&, double& acc) {
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
-      g[j] = -th[j] / s2[j];
-      acc += -0.5 * th[j] * th[j] / s2[j];
+      g[j] = -th[j] * rs2[j];
+      acc += -0.5 * th[j] * th[j] * rs2[j];
     }
   }
   template <int EPL, class Cx>
   __device__ __forceinline__ static void grad(Cx&, const double (&th)[EPL], double (&g)[EPL],
-                                              const double (&s2)[EPL], Aux&) {
+                                              const double (&rs2)[EPL], Aux&) {
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) g[j] = -th[j] / s2[j];
+    for (int j = 0; j < EPL; ++j) g[j] = -th[j] * rs2[j];
   }
   __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return sum; }
 };

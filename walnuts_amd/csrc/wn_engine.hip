@@ -288,7 +288,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.C = num_chains;
   e.cfg = cfg;
   e.device = cfg.device;
-  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, model == WN_MODEL_STD_NORMAL);
+  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, model != WN_MODEL_FUNNEL);
   if (!e.geo.mem && cfg.state_in_lds > 0) {
     if (!wn::lds_geometry_exists(e.geo.nw, e.geo.epl, cfg.state_in_lds))
       throw std::invalid_argument("no LDS-state kernel for this geometry / waves-per-SIMD budget");
@@ -304,7 +304,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   // residency: how many chains (workgroups) share a CU, and how much of the span pool sits in LDS
   const size_t lds_per_cu = 160 * 1024;
   e.pool_total = std::min(required_pool(cfg, e.geo.start_regs) + (e.geo.mem ? wn::kMemRoleVectors : 0), wn::kMaxPool);
-  int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo, model == WN_MODEL_STD_NORMAL);
+  int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo, model != WN_MODEL_FUNNEL);
   wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
   e.lds_state = e.geo.lds_wpe > 0 ? 3 : 0;
   const size_t fixed = wn::transition_smem_bytes(e.geo.nw, e.lds_state, e.Dp);
@@ -819,7 +819,7 @@ int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {
 }
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {
   try {
-    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, model == WN_MODEL_STD_NORMAL).nw;
+    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, model != WN_MODEL_FUNNEL).nw;
   } catch (...) {
     return -1;
   }

@@ -106,9 +106,8 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_mod
   }
   // measured on MI355X (profiles/): wave-uniform tree logic is replicated per wavefront, so few waves with
   // many elements per lane win until VGPR pressure caps residency
-  // ... except that a model with real arithmetic in its gradient (the diagonal normal's two divisions per element, the
-  // funnel's reduction) is better off with ONE wavefront per chain up to 1024 dimensions: no cross-wave barriers and
-  // half the replicated scalar work (measured on 1024-dim diagonal normals: +18 % at 4 096 chains, +37 % at 65 536)
+  // ... except that a model whose gradient needs a reduction and keeps a gradient vector (the funnel) is better off
+  // with ONE wavefront per chain up to 1024 dimensions: no cross-wave barriers, half the replicated scalar work
   static const int pref_light[][2] = {{1, 2}, {1, 4}, {1, 8}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
   static const int pref_heavy[][2] = {{1, 2}, {1, 4}, {1, 8}, {1, 16}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
   const int(*pref)[2] = light_model ? pref_light : pref_heavy;

@@ -131,6 +131,8 @@ struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
   static constexpr bool kElementwise = true;
   // grad = -theta: the register kernels carry no gradient vector at all (a sign modifier on theta at every use)
   static constexpr bool kGradIsNegTheta = true;
+  static constexpr bool kCheapGrad = true;
+  __device__ __forceinline__ static double grad_elem(double th, double) { return -th; }
   struct Aux {};
   template <int EPL, class Cx>
   __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
@@ -158,6 +160,9 @@ struct DiagNormalModel {  // examples/examples.cpp:20-31, params = 1 / sigma_sq
   static constexpr bool kUsesParams = true;
   static constexpr bool kElementwise = true;
   static constexpr bool kGradIsNegTheta = false;
+  // one multiply per element: cheaper to recompute at each use than to keep, park and reload a gradient vector
+  static constexpr bool kCheapGrad = true;
+  __device__ __forceinline__ static double grad_elem(double th, double rs2) { return -th * rs2; }
   struct Aux {};
   template <int EPL, class Cx>
   __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
@@ -182,6 +187,8 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
   static constexpr bool kUsesParams = false;
   static constexpr bool kElementwise = false;  // the gradient needs sum(x^2): register backend only
   static constexpr bool kGradIsNegTheta = false;
+  static constexpr bool kCheapGrad = false;
+  __device__ __forceinline__ static double grad_elem(double, double) { return 0.0; }
   struct Aux {
     double v, S, hev;
   };
@@ -744,10 +751,11 @@ struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model,
   static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
-  // gradient of the moving end at element j.  Where it is just -theta (standard normal) nothing is stored, parked or
-  // reloaded for it: `g` is dead, its pool buffers are bookkeeping only, and 2*EPL registers are free.
-  static constexpr bool kNoGrad = Model::kGradIsNegTheta;
-  __device__ __forceinline__ double G(int j) const { return kNoGrad ? -th[j] : g[j]; }
+  // gradient of the moving end at element j.  Where it is just -theta (standard normal) or one multiply (diagonal
+  // normal) nothing is stored, parked or reloaded for it: `g` is dead, its pool buffers are bookkeeping only, and
+  // 2*EPL registers are free.
+  static constexpr bool kNoGrad = Model::kCheapGrad;
+  __device__ __forceinline__ double G(int j) const { return kNoGrad ? Model::grad_elem(th[j], mp[j]) : g[j]; }
   // restart state.  Its gradient is re-evaluated on a retry (a pure function of th0) when that is a couple of
   // element-wise operations; a model whose gradient needs a reduction and an exponential (the funnel, where retries
   // are frequent) keeps the copy the reference keeps (walnuts.hpp:326)
@@ -1497,12 +1505,12 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
 #endif
 }
 
-// Without a gradient vector (grad = -theta) the 8-elements-per-lane kernels are built for three wavefronts per SIMD:
+// Without a gradient vector (standard / diagonal normal) the 8-elements-per-lane kernels are built for three wavefronts per SIMD:
 // the 31 VGPRs that spill to scratch cost less than the third wave hides (measured: 2.95 -> 2.55 ms per step on the
 // headline workload with 6 chains per CU).
 template <class Model, int EPL>
 constexpr int min_waves_per_simd() {
-  return (Model::kGradIsNegTheta && EPL == 8) ? 3 : 1;
+  return (Model::kCheapGrad && EPL == 8) ? 3 : 1;
 }
 template <class Model, int NW, int EPL, bool START_REGS>
 __global__ __launch_bounds__(64 * NW, (min_waves_per_simd<Model, EPL>())) void transition_kernel(const Params P) {

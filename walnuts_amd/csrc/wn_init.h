@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
   WN_LDS double* base = (WN_LDS double*)smem;
   WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(base + (threadIdx.x >> 6) * kMetaDoubles);
   WN_LDS double* red = base + NW * kMetaDoubles;
-  WN_LDS double* bcast = red + 4 * NW;
+  WN_LDS double* bcast = red + kRedDoubles(NW);
   T t(P, base, meta, red, bcast, nullptr);
   constexpr int L = T::L;
   constexpr int NP = T::NP;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * NW) void init_kernel_mem(const InitParams Q) {
   WN_LDS double* base = (WN_LDS double*)smem;
   WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(base + (threadIdx.x >> 6) * kMetaDoubles);
   WN_LDS double* red = base + NW * kMetaDoubles;
-  WN_LDS double* bcast = red + 4 * NW;
+  WN_LDS double* bcast = red + kRedDoubles(NW);
   double* rho0 = Q.scratch + static_cast<long long>(blockIdx.x) * Q.scratch_stride;
   T t(P, base, meta, red, bcast, rho0);
   constexpr int L = T::L;

@@ -41,6 +41,9 @@
 
 namespace wn {
 
+// reduction scratch in LDS: two parity halves of (2 per wavefront + 1 carried scalar)
+constexpr int kRedDoubles(int nw) { return 2 * (2 * nw + 1); }
+
 // ---- wave-uniform helpers ----------------------------------------------------
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uni(double v) {
@@ -280,6 +283,8 @@ struct TrajBase {
   int Dp;
   unsigned long long free_mask;
   int red_parity;
+  double carry;       // scalar computed by wavefront 0 that the next sum2 hands to the other wavefronts
+  bool carry_armed;
   long long n_grad;
   int n_draw;
   int draw_base;  // first tree-draw index held in meta->u / meta->lu (-1: none)
@@ -299,6 +304,8 @@ struct TrajBase {
     wave = tid >> 6;
     Dp = p.dim_padded;
     red_parity = 0;
+    carry = 0.0;
+    carry_armed = false;
   }
 
 #if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
@@ -346,13 +353,15 @@ struct TrajBase {
     if (NW == 1) {
       a = uni(packed);
       b = lane_value(packed, 32);
+      carry_armed = false;
       return;
     }
 #endif
     if (NW > 1) {
-      WN_LDS double* r = red + red_parity * (NW * 2);
+      WN_LDS double* r = red + red_parity * (NW * 2 + 1);
       if (lane == 0) r[wave * 2] = packed;
       if (lane == 32) r[wave * 2 + 1] = packed;
+      if (carry_armed && tid == 0) r[NW * 2] = carry;  // wavefront 0's scalar rides along (see lse_on_leader)
       __syncthreads();
       double ta = r[0], tb = r[1];
 #pragma unroll
@@ -362,10 +371,19 @@ struct TrajBase {
       }
       a = ta;
       b = tb;
+      if (carry_armed) carry = uni(r[NW * 2]);
       red_parity ^= 1;
     }
+    carry_armed = false;
     a = uni(a);
     b = uni(b);
+  }
+  // log_sum_exp for the merge that follows a U-turn test: a hundred instructions of wave-uniform scalar maths.  Only
+  // wavefront 0 evaluates it, BEFORE the test, and the value travels to the other wavefronts of the chain in the LDS
+  // exchange the test's reduction does anyway -- their SIMDs run other chains' waves meanwhile.
+  __device__ __forceinline__ void lse_on_leader(double x1, double x2) {
+    if (NW == 1 || wave == 0) carry = log_sum_exp(x1, x2);
+    carry_armed = NW > 1;
   }
   __device__ __forceinline__ double sum1(double a) {
     double b = 0.0;
@@ -526,7 +544,8 @@ struct TrajBase {
       WN_PHASE(kPhEnergy);
       self().energy(part, logp_pos, logp_joint);
       if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
-        if (P.warmup) adam_observe(wnd::dexp(-fabs(logp_start - logp_joint)));
+        // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
+        if (P.warmup && wave == 0) adam_observe(wnd::dexp(-fabs(logp_start - logp_joint)));
       }
       if (fabs(logp_start - logp_joint) <= max_error) {
         WN_PHASE(kPhReversible);
@@ -644,13 +663,14 @@ struct TrajBase {
           const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
           const double s_logsum = uni(meta->logsum[sp]), s_lpsel = uni(meta->lpsel[sp]);
           WN_PHASE(kPhUturn);
+          lse_on_leader(s_logsum, c_logsum);
           if (uturn_against(s_in_th, s_in_rh, fwd)) {  // walnuts.hpp:490-492
             ok = false;
             break;
           }
           WN_PHASE(kPhCombine);
           // combine<Barker> (walnuts.hpp:370-386): old = s, new = c
-          const double total = uni(log_sum_exp(s_logsum, c_logsum));
+          const double total = uni(carry);
           const bool update = log_uniform01() < c_logsum - total;
           const int n_sel = update ? c_sel : s_sel;
           const double n_lpsel = update ? c_lpsel : s_lpsel;
@@ -694,8 +714,9 @@ struct TrajBase {
 
       WN_PHASE(kPhTopMerge);
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
+      lse_on_leader(a_logsum, c_logsum);
       const bool turned = fwd ? uturn_against(a_bk[0], a_bk[1], true) : uturn_against(a_fw[0], a_fw[1], false);
-      const double total = uni(log_sum_exp(a_logsum, c_logsum));
+      const double total = uni(carry);
       const bool update = log_uniform01() < c_logsum - a_logsum;  // Metropolis
       // the new span's inner end is never read again
       release_unless(c_in_th, c_sel, -3, -3);
@@ -1476,7 +1497,7 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   WN_LDS double* tail = pool + P.pool_lds * P.dim_padded;
   WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(tail + (threadIdx.x >> 6) * kMetaDoubles);
   WN_LDS double* red = tail + NW * kMetaDoubles;
-  WN_LDS double* bcast = red + 4 * NW;
+  WN_LDS double* bcast = red + kRedDoubles(NW);
   WN_LDS int* next_chain = (WN_LDS int*)(bcast + 1);
   double* arena = P.arena + static_cast<long long>(blockIdx.x) * P.arena_stride;
 
@@ -1533,7 +1554,7 @@ template <class Model, int NW, int EPL, bool START_REGS>
 using Traj = TrajReg<Model, NW, EPL, START_REGS>;
 
 inline size_t transition_smem_bytes(int nw, int lds_vectors, int dim_padded) {
-  return (static_cast<size_t>(lds_vectors) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + 4 * nw + 2) *
+  return (static_cast<size_t>(lds_vectors) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + kRedDoubles(nw) + 2) *
          sizeof(double);
 }
 

@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--elems-per-lane", type=int, default=0)
     ap.add_argument("--workgroups-per-cu", type=int, default=0)
     ap.add_argument("--lds-vectors", type=int, default=-1)
-    ap.add_argument("--state-in-lds", type=int, default=0)
+    ap.add_argument("--reg-vectors", type=int, default=-1)
     ap.add_argument("--reserved-cus", type=int, default=-1,
                     help="CUs left free for the RCCL all-gather kernels (default: 0 on one GPU, 16 otherwise)")
     ap.add_argument("--gather-every", type=int, default=1,
@@ -161,7 +161,7 @@ def main():
     reserved = args.reserved_cus if args.reserved_cus >= 0 else (16 if world > 1 else 0)
     cfg = wa.default_config(device=local_rank, waves_per_chain=args.waves_per_chain, elems_per_lane=args.elems_per_lane,
                             workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors,
-                            reserved_cus=reserved, state_in_lds=args.state_in_lds)
+                            reserved_cus=reserved, reg_vectors=args.reg_vectors)
     eng = wa.DeviceEngine(model_id, D, C, cfg, params=params)
     if world > 1:
         # kernels on torch's current stream: RCCL collectives on the draws are then ordered after them by torch

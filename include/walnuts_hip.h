@@ -109,8 +109,8 @@ typedef struct wn_config {
   int32_t lds_vectors;              /* span-pool vectors kept in LDS (-1: as many as fit) */
   int32_t reserved_cus;             /* compute units the persistent grid leaves free (e.g. for RCCL kernels that
                                        all-gather the previous iteration's draws while this one runs); 0 */
-  int32_t state_in_lds;             /* k > 0: use the kernels that keep inverse mass + restart state in LDS and are
-                                       built for k wavefronts per SIMD (more resident chains); 0: registers */
+  int32_t reg_vectors;              /* span-pool vectors kept in VGPRs (-1: as many as the kernel was built with);
+                                       what fits neither LDS nor registers overflows to an HBM arena */
 } wn_config;
 
 WALNUTS_HIP_EXPORT void wn_default_config(wn_config* cfg);

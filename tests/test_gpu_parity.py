@@ -52,7 +52,7 @@ def _need_gpu(gpu):
     ("std_normal", 2048, 32, (8, 4)),
     ("std_normal", 4096, 24, (8, 8)),
     ("std_normal", 4000, 16, (16, 4)),
-    ("std_normal", 8192, 12, (16, 8)),      # restart state parked in the span pool
+    ("std_normal", 8192, 12, (16, 8)),      # the largest register geometry
     ("diag_normal", 1024, 96, None),        # config #2/#4 family
     ("diag_normal", 130, 64, (1, 4)),
     ("funnel", 128, 128, None),             # config #3
@@ -66,17 +66,17 @@ def test_engine_matches_oracle_bitwise(model, D, C, geometry):
     parity.run_case(model, D, C, warmup=12, sampling=8, geometry=geometry, check_every=2)
 
 
-@pytest.mark.parametrize("model,D,C,geometry,wpe", [
-    ("std_normal", 1024, 96, (2, 8), 3),
-    ("std_normal", 1024, 64, (4, 4), 3),
-    ("std_normal", 1000, 64, (4, 4), 4),
-    ("diag_normal", 500, 48, (1, 8), 3),
-    ("funnel", 300, 48, (2, 4), 4),
-    ("diag_normal", 4096, 16, (8, 8), 3),
+@pytest.mark.parametrize("model,D,C,geometry,lds,reg", [
+    ("std_normal", 1024, 96, (2, 8), 2, -1),    # two LDS vectors, the rest overflows to the HBM arena
+    ("std_normal", 1024, 64, (2, 8), 0, 0),     # the whole span pool in the HBM arena
+    ("diag_normal", 1000, 64, (4, 4), 1, -1),
+    ("funnel", 300, 48, (2, 4), 0, -1),
+    ("std_normal", 100, 64, None, 3, -1),
 ])
-def test_lds_state_kernels_match_oracle_bitwise(model, D, C, geometry, wpe):
-    """The kernels that keep inverse mass + restart state in LDS (more resident chains per CU)."""
-    parity.run_case(model, D, C, warmup=10, sampling=6, geometry=geometry, state_in_lds=wpe, check_every=2)
+def test_span_pool_tiers_match_oracle_bitwise(model, D, C, geometry, lds, reg):
+    """Where a span-pool vector lives (LDS, register bank, HBM arena) must not change a single bit."""
+    parity.run_case(model, D, C, warmup=10, sampling=6, geometry=geometry, lds_vectors=lds, reg_vectors=reg,
+                    check_every=2)
 
 
 @pytest.mark.parametrize("kw", [

@@ -22,28 +22,24 @@ def sim():
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("model,D,geometry", [
     ("std_normal", 10, None),          # (1,2): D < one pair per lane, heavy padding
-    ("diag_normal", 130, (1, 4)),      # (1,4): restart state parked in the span pool
+    ("diag_normal", 130, (1, 4)),      # (1,4): four elements per lane
     ("funnel", 9, (2, 2)),             # two wavefronts: cross-wave reductions, broadcasts, barriers
     ("diag_normal", 300, (1, -1)),     # streaming backend (vectors in HBM scratch), 3 tiles per lane
-    ("std_normal", 11, (1, 2, 3)),     # LDS-state kernels: inverse mass + restart state in LDS
 ])
 def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry):
-    extra = {}
-    if geometry is not None and len(geometry) == 3:
-        extra["state_in_lds"] = geometry[2]
-        geometry = geometry[:2]
-    parity.run_case(model, D, 2, warmup=4, sampling=3, lib_path=sim, geometry=geometry, step=None, **extra)
+    parity.run_case(model, D, 2, warmup=4, sampling=3, lib_path=sim, geometry=geometry, step=None)
 
 
 @pytest.mark.timeout(600)
 def test_emulated_engine_lds_pool_and_arena_paths(sim, oracle):
-    # same chains with the whole pool in "LDS", half of it, none of it: identical results
+    # same chains with the span pool in LDS, split over LDS / registers / HBM arena, in registers + arena only, in
+    # the arena only: identical results
     outs = []
-    for lds in (-1, 5, 0):
+    for lds, reg in ((-1, -1), (2, 3), (0, 4), (0, 0)):
         dev, orc = parity.run_case("std_normal", 12, 2, warmup=2, sampling=2, lib_path=sim, lds_vectors=lds,
-                                   max_trajectory_doublings=4)
+                                   reg_vectors=reg, max_trajectory_doublings=4)
         outs.append(dev.positions())
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
 
 
 @pytest.mark.timeout(600)

@@ -1,0 +1,663 @@
+// wn_chip.h -- TrajChip: the register backend of the Walnuts transition whose span pool stays on the chip.
+//
+// Same tree, same random-number order and the same arithmetic as wn_traj.h's TrajBase::run (walnuts.hpp:520-563
+// wrapped as adaptive_walnuts.hpp:234-251 / walnuts.hpp:682-692), laid out for what the MI355X measurements of
+// round 1 said bounds the headline workload (65 536 chains x 1 024 dims): 10 of the 13 GB the kernel moved per
+// launch were span-pool vectors going to the per-workgroup HBM arena and register spills, not the 2.7 GB the
+// chains' state needs.
+//
+//  * Ping-pong trajectory end.  The moving end is TWO register sets.  A macro step (walnuts.hpp:307-345) reads
+//    set A and writes set 1-A, so the restart state the reference copies (walnuts.hpp:324-326) is simply the set
+//    that was not written: a halving retry costs nothing and no leaf copies its predecessor.  Leaves are built in
+//    pairs (even leaf: set 0 -> 1, odd leaf: set 1 -> 0), which makes the set index a compile-time constant
+//    everywhere; the one single-leaf extension of a transition (the first doubling) copies once.
+//  * Level-0 merges never touch memory: both leaves of the pair are in registers when the odd leaf is done, and the
+//    two U-turn products (walnuts.hpp:192-201) ride in the SAME reduction as the leaf's two energies (sum4).
+//  * Three-tier span pool behind the wave-uniform buffer indices: LDS vectors, then RP vectors kept in VGPRs
+//    (statically indexed, reached through a wave-uniform switch), then -- only when a deep tree needs more than
+//    the chip holds -- the HBM arena.  With 4 chains per CU at D = 1024 that is 4 + 6 vectors on chip against a
+//    worst case of 12 live pool vectors at the default five doublings.
+//  * The "other" end of the accumulated span is one (theta, rho[, grad]) triple that is swapped with the moving
+//    end when the walk turns around; nothing is written while the walk keeps its direction.
+#pragma once
+
+#include "wn_traj.h"
+
+namespace wn {
+
+// N doubles per lane addressed by a wave-uniform index: one column of a register bank.  The index reaches the
+// hardware as VGPR-relative addressing (s_set_gpr_idx_on + v_mov), so a pool vector moves in and out of the bank
+// with two VALU moves per element and no code per slot.
+#if defined(WN_CPU_SIM)
+#define WN_VEC_OF(N) __attribute__((vector_size(8 * (N))))
+#else
+#define WN_VEC_OF(N) __attribute__((ext_vector_type(N)))
+#endif
+template <int N>
+struct RegColumn {
+  typedef double type WN_VEC_OF(N);
+};
+template <>
+struct RegColumn<0> {
+  typedef double type WN_VEC_OF(2);  // placeholder, never touched
+};
+
+// RA + RB = pool vectors kept in registers, as two banks whose sizes are vector widths (2, 4, 8, 16) or 0
+template <class Model, int NW, int EPL, int RA, int RB>
+struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
+  using Base = TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW>;
+  static constexpr int RP = RA + RB;
+  using typename Base::Meta;
+  using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::wave;
+  using Base::chain; using Base::aux; using Base::n_grad; using Base::n_draw; using Base::draw_base; using Base::err;
+  using Base::max_error; using Base::min_micro; using Base::step; using Base::free_mask; using Base::onchip_mask;
+  using Base::w_draw0; using Base::w_score0; using Base::meta; using Base::carry;
+  static constexpr int L = Base::L;
+  static constexpr int NP = EPL / 2;
+  static constexpr int kDp = L * EPL;  // padded dimension: a compile-time constant of the geometry
+  static constexpr int kRegPool = RP;
+  static constexpr bool kNoGrad = Model::kCheapGrad;  // the gradient is recomputed from theta at each use
+  static constexpr bool kHasStartState = true;
+  static constexpr bool kZeroCopy = false;
+  static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
+
+  double th[2][EPL], rh[2][EPL], g[2][EPL];  // the two sets of the moving end (g is dead when kNoGrad)
+  double im[EPL], mp[EPL];                    // inverse mass diagonal, model parameters
+  typename RegColumn<RA>::type bank_a[EPL];   // register tier of the span pool: element j of slot k is bank_a[j][k]
+  typename RegColumn<RB>::type bank_b[EPL];
+  int n_lds, n_reg;                           // pool buffers [0, n_lds) live in LDS, [n_lds, n_lds + n_reg) in the banks
+
+  __device__ __forceinline__ TrajChip(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
+                                      WN_LDS double* bc, double* ar)
+      : Base(p, pool, m, r, bc, ar) {
+    n_lds = p.pool_lds;
+    n_reg = p.pool_reg < RP ? p.pool_reg : RP;
+    const int on = n_lds + n_reg;
+    onchip_mask = on >= 64 ? ~0ull : ((1ull << on) - 1ull);
+  }
+
+  // ---- model context (what Model::eval sees) ------------------------------------------------------
+  __device__ __forceinline__ int index(int j) const { return ((j >> 1) * L + tid) * 2 + (j & 1); }
+  __device__ __forceinline__ bool valid(int j) const { return index(j) < P.dim; }
+  template <int S>
+  __device__ __forceinline__ double G(int j) const {
+    return kNoGrad ? Model::grad_elem(th[S][j], mp[j]) : g[S][j];
+  }
+
+  // ---- vector buffers -----------------------------------------------------------------------------
+  __device__ __forceinline__ void vload(const double* base, double (&v)[EPL]) const {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const v2f64 t = *reinterpret_cast<const v2f64*>(base + (k * L + tid) * 2);
+      v[2 * k] = t[0];
+      v[2 * k + 1] = t[1];
+    }
+  }
+  __device__ __forceinline__ void vstore(double* base, const double (&v)[EPL]) const {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      v2f64 t;
+      t[0] = v[2 * k];
+      t[1] = v[2 * k + 1];
+      *reinterpret_cast<v2f64*>(base + (k * L + tid) * 2) = t;
+    }
+  }
+  __device__ __forceinline__ void lds_load(const WN_LDS double* base, double (&v)[EPL]) const {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const v2f64 t = *reinterpret_cast<const WN_LDS v2f64*>(base + (k * L + tid) * 2);
+      v[2 * k] = t[0];
+      v[2 * k + 1] = t[1];
+    }
+  }
+  __device__ __forceinline__ void lds_store(WN_LDS double* base, const double (&v)[EPL]) const {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      v2f64 t;
+      t[0] = v[2 * k];
+      t[1] = v[2 * k + 1];
+      *reinterpret_cast<WN_LDS v2f64*>(base + (k * L + tid) * 2) = t;
+    }
+  }
+  __device__ __forceinline__ void pool_load(int b, double (&v)[EPL]) {
+    if (b < n_lds) {
+      lds_load(lds_pool + b * kDp, v);
+      return;
+    }
+    const int k = b - n_lds;
+    if (RP > 0 && k < n_reg) {
+      if (RB == 0 || k < RA) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) v[j] = bank_a[j][k];
+      } else {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) v[j] = bank_b[j][k - RA];
+      }
+      return;
+    }
+    vload(arena + static_cast<long long>(k - n_reg) * kDp, v);
+  }
+  __device__ __forceinline__ void pool_store(int b, const double (&v)[EPL]) {
+    if (b < n_lds) {
+      lds_store(lds_pool + b * kDp, v);
+      return;
+    }
+    const int k = b - n_lds;
+    if (RP > 0 && k < n_reg) {
+      if (RB == 0 || k < RA) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) bank_a[j][k] = v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) bank_b[j][k - RA] = v[j];
+      }
+      return;
+    }
+    vstore(arena + static_cast<long long>(k - n_reg) * kDp, v);
+  }
+
+  // No pool buffer is live across transitions.  The register allocator cannot see that (the banks are read through
+  // run-time indices), so they are redefined here and their registers are free while the chain is loaded and its
+  // momentum drawn.
+  __device__ __forceinline__ void kill_register_pool() {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      if (RA > 0) bank_a[j] = typename RegColumn<RA>::type{};
+      if (RB > 0) bank_b[j] = typename RegColumn<RB>::type{};
+    }
+  }
+
+  // ---- Hamiltonian pieces -------------------------------------------------------------------------
+  template <int S>
+  __device__ __forceinline__ double model_eval() {
+    ++n_grad;
+    double part = 0.0;
+    Model::eval(*this, th[S], g[S], mp, aux, part);
+    return part;
+  }
+  // kinetic partial of set S (util.hpp:220-223 before the -0.5)
+  template <int S>
+  __device__ __forceinline__ double kinetic_partial() const {
+    double ke = 0.0;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) ke += im[j] * (rh[S][j] * rh[S][j]);
+    return ke;
+  }
+  // one leapfrog micro step (walnuts.hpp:329-332) reading set A and writing set B (A == B: in place);
+  // returns the new state's log-density partial
+  template <int A, int B>
+  __device__ __forceinline__ double micro_step(double h, double half) {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) rh[B][j] = rh[A][j] + half * G<A>(j);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) th[B][j] = th[A][j] + h * im[j] * rh[B][j];
+    const double part = model_eval<B>();
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) rh[B][j] += half * G<B>(j);
+    return part;
+  }
+  // n micro steps in place on set S (walnuts.hpp:328-333)
+  template <int S>
+  __device__ __forceinline__ double leapfrog_inplace(double h, int n, double part) {
+    const double half = 0.5 * h;
+    for (int s = 0; s < n; ++s) part = micro_step<S, S>(h, half);
+    return part;
+  }
+  __device__ __forceinline__ void finish_energy(double lp_sum, double ke_sum, double& logp_pos, double& logp_joint) {
+    // wave-uniform results go back to scalar registers: they live long and would otherwise hold VGPR pairs
+    logp_pos = uni(Model::finish(lp_sum, aux, P.dim));
+    logp_joint = uni(logp_pos + (-0.5 * ke_sum));
+  }
+
+  // walnuts.hpp:218-235 in place on set S
+  template <int S>
+  __device__ __forceinline__ bool within_tolerance(double h, int n, double logp_entry) {
+    double part = leapfrog_inplace<S>(h, n, 0.0);
+    double ke = kinetic_partial<S>();
+    this->sum2(part, ke);
+    double lp, lj;
+    finish_energy(part, ke, lp, lj);
+    return fabs(lj - logp_entry) <= max_error;
+  }
+
+  // walnuts.hpp:254-279.  The candidate (set S) is parked in pool buffers while coarser reverse paths are tried
+  // from (theta', -rho', grad').
+  template <int S>
+  __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
+    if (n == 1) return true;
+    const int k0 = this->alloc(), k1 = this->alloc(), k2 = kNoGrad ? -1 : this->alloc();
+    pool_store(k0, th[S]);
+    pool_store(k1, rh[S]);
+    if (!kNoGrad) pool_store(k2, g[S]);
+    bool result = true;
+    bool first = true;
+    while (n >= 2 * min_micro) {
+      if (!first) {
+        pool_load(k0, th[S]);
+        if (!kNoGrad) pool_load(k2, g[S]);
+      }
+      first = false;
+      double keep[EPL];
+      pool_load(k1, keep);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) rh[S][j] = -keep[j];
+      n /= 2;
+      h *= 2;
+      if (within_tolerance<S>(h, n, logp_joint)) {
+        result = false;
+        break;
+      }
+    }
+    pool_load(k0, th[S]);
+    pool_load(k1, rh[S]);
+    if (!kNoGrad) pool_load(k2, g[S]);
+    this->release(k0);
+    this->release(k1);
+    this->release(k2);
+    return result;
+  }
+
+  // walnuts.hpp:192-201 partial sums: `H` is the outer end of the newer span, (a, b) = (theta, rho) of the far end
+  template <int H>
+  __device__ __forceinline__ void uturn_partials(const double (&a)[EPL], const double (&b)[EPL], bool fwd, double& p_hot,
+                                                 double& p_far) const {
+    p_hot = 0.0;
+    p_far = 0.0;
+    // a - th == -(th - a) exactly: one subtraction, then a wave-uniform sign flip on the high word
+    const uint64_t flip = fwd ? 0ull : 0x8000000000000000ull;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      const double diff = wnd::as_f64(wnd::as_u64(th[H][j] - a[j]) ^ flip);
+      const double sd = im[j] * diff;
+      p_hot += rh[H][j] * sd;
+      p_far += b[j] * sd;
+    }
+  }
+  // the moving end (always set 0 when a pool-resident span is merged) against a span end kept in the pool
+  __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
+    double a[EPL], b[EPL];
+    pool_load(bth, a);
+    pool_load(brh, b);
+    double p_hot, p_far;
+    uturn_partials<0>(a, b, fwd, p_hot, p_far);
+    this->sum2(p_hot, p_far);
+    return p_hot < 0 || p_far < 0;
+  }
+
+  // walnuts.hpp:307-345 from set A into set 1-A.  `want_turn`: also evaluate the U-turn test of the two-leaf span
+  // (previous leaf = set A, new leaf = set 1-A), whose two sums share the energy reduction.
+  template <int A>
+  __device__ __forceinline__ bool macro_step(bool fwd, double logp_start, double& logp_pos, double& logp_joint,
+                                             bool want_turn, bool& turned) {
+    constexpr int B = 1 - A;
+    double h = fwd ? step : -step;
+    int n = min_micro;
+    for (int halvings = 0; halvings < P.max_halvings; ++halvings, n *= 2, h *= 0.5) {
+      WN_PHASE(kPhLeapfrog);
+      double part = micro_step<A, B>(h, 0.5 * h);
+      part = leapfrog_inplace<B>(h, n - 1, part);
+      double ke = kinetic_partial<B>();
+      double p_hot = 0.0, p_far = 0.0;
+      WN_PHASE(kPhEnergy);
+      if (want_turn) {
+        uturn_partials<B>(th[A], rh[A], fwd, p_hot, p_far);
+        this->sum4(part, ke, p_hot, p_far);
+      } else {
+        this->sum2(part, ke);
+      }
+      finish_energy(part, ke, logp_pos, logp_joint);
+      if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
+        // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
+        if (P.warmup && wave == 0) this->adam_observe(wnd::dexp(-fabs(logp_start - logp_joint)));
+      }
+      WN_PHASE(kPhRestart);
+      if (fabs(logp_start - logp_joint) <= max_error) {
+        WN_PHASE(kPhReversible);
+        const bool rev = reversible<B>(h, n, logp_joint);
+        WN_PHASE(kPhRestart);
+        turned = p_hot < 0 || p_far < 0;
+        return rev;
+      }
+    }
+    return false;
+  }
+
+  // give a symbolic vector (kHot = set 0, kStart = set 1) a pool buffer
+  __device__ __forceinline__ int materialize(int ref, bool rho) {
+    if (ref >= 0) return ref;
+    const int b = this->alloc();
+    if (ref == kHot) {
+      pool_store(b, rho ? rh[0] : th[0]);
+    } else {
+      pool_store(b, rho ? rh[1] : th[1]);
+    }
+    return b;
+  }
+
+  // ------------------------------------------------------------------------------------
+  // one MCMC transition (walnuts.hpp:520-563 wrapped as adaptive_walnuts.hpp:234-251 or walnuts.hpp:682-692)
+  // ------------------------------------------------------------------------------------
+  __device__ void run(int chain_id) {
+    WN_PHASE(kPhPrologue);
+    this->refresh_ids();
+    chain = chain_id;
+    err = 0;
+    n_grad = 0;
+    n_draw = 0;
+    draw_base = -1;
+    max_error = P.max_error;
+    free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
+    const long long row = static_cast<long long>(chain) * kDp;
+    const bool warm = P.warmup != 0;
+    this->load_tuning(warm);
+
+    // momentum refresh + initial point (walnuts.hpp:528-535), into set 0
+    double lp_pos, lj;
+    {
+      double part = begin_transition(row, warm);
+      double ke = kinetic_partial<0>();
+      this->sum2(part, ke);
+      finish_energy(part, ke, lp_pos, lj);
+    }
+    kill_register_pool();
+    // The accumulated span (walnuts.hpp:34-131) is: the moving end (set 0), the other end parked in the pool,
+    // the selected position and three scalars.  Both ends are the initial point to begin with.
+    int o_th = this->alloc_cold(), o_rh = this->alloc_cold(), o_g = kNoGrad ? -1 : this->alloc_cold();
+    pool_store(o_th, th[0]);
+    pool_store(o_rh, rh[0]);
+    if (!kNoGrad) pool_store(o_g, g[0]);
+    int a_sel = o_th;
+    double lj_hot = lj, lj_other = lj, a_logsum = lj, a_lpsel = lp_pos;
+    bool both = true, hot_fw = true;
+
+    int depth = 1;
+    for (; depth <= P.max_depth; ++depth) {
+      WN_PHASE(kPhDoublingStart);
+      const bool fwd = this->uniform01() < 0.5;  // bernoulli(0.5), walnuts.hpp:552
+      if (both) {
+        hot_fw = fwd;
+        both = false;
+      } else if (fwd != hot_fw) {
+        // the walk turns around: the moving end and the parked end change places
+        double a[EPL], b[EPL];
+        pool_load(o_th, a);
+        pool_load(o_rh, b);
+        if (o_th == a_sel) o_th = this->alloc_cold();  // the selected position keeps its buffer
+        pool_store(o_th, th[0]);
+        pool_store(o_rh, rh[0]);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+          th[0][j] = a[j];
+          rh[0][j] = b[j];
+        }
+        if (!kNoGrad) {
+          pool_load(o_g, a);
+          pool_store(o_g, g[0]);
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) g[0][j] = a[j];
+        }
+        const double t = lj_hot;
+        lj_hot = lj_other;
+        lj_other = t;
+        hot_fw = fwd;
+      }
+      double h_cur = lj_hot;
+
+      // ---- build_span(depth-1) (walnuts.hpp:464-495) as a post-order walk over 2^(depth-1) leaves, two at a time ----
+      const int nleaf = 1 << (depth - 1);
+      int sp = 0;
+      bool ok = true;
+      bool top_turned = false;
+      int c_in_th = kHot, c_in_rh = kHot, c_sel = kHot;
+      double c_logsum = 0.0, c_lpsel = 0.0;
+      if (nleaf == 1) {
+        // a single leaf: its U-turn test against the span's other end (= the initial point, still in set 0 when
+        // the leaf is done) rides in the leaf's reduction
+        double leaf_lp, leaf_lj;
+        ok = macro_step<0>(fwd, h_cur, leaf_lp, leaf_lj, true, top_turned);
+        if (ok) {
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) {
+            th[0][j] = th[1][j];
+            rh[0][j] = rh[1][j];
+            if (!kNoGrad) g[0][j] = g[1][j];
+          }
+          h_cur = leaf_lj;
+          c_logsum = leaf_lj;
+          c_lpsel = leaf_lp;
+        }
+      } else {
+        for (int i = 0; i < nleaf; i += 2) {
+          double e_lp, e_lj, leaf_lp, leaf_lj;
+          bool pair_turned = false, unused = false;
+          if (!macro_step<0>(fwd, h_cur, e_lp, e_lj, false, unused)) {  // build_leaf, walnuts.hpp:420-442
+            ok = false;
+            break;
+          }
+          if (!macro_step<1>(fwd, e_lj, leaf_lp, leaf_lj, true, pair_turned)) {
+            ok = false;
+            break;
+          }
+          h_cur = leaf_lj;
+          // level-0 merge, combine<Barker> (walnuts.hpp:370-386): old = the even leaf (set 1), new = the odd leaf (set 0)
+          WN_PHASE(kPhCombine);
+          {
+            const double total = uni(log_sum_exp(e_lj, leaf_lj));
+            if (pair_turned) {  // walnuts.hpp:490-492
+              ok = false;
+              break;
+            }
+            const bool update = this->log_uniform01() < leaf_lj - total;
+            c_in_th = kStart;
+            c_in_rh = kStart;
+            c_sel = update ? kHot : kStart;
+            c_lpsel = update ? leaf_lp : e_lp;
+            c_logsum = total;
+          }
+          for (int l = 1; ((i + 1) >> l) & 1; ++l) {
+            --sp;
+            const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
+            const double s_logsum = uni(meta->logsum[sp]), s_lpsel = uni(meta->lpsel[sp]);
+            WN_PHASE(kPhUturn);
+            this->lse_on_leader(s_logsum, c_logsum);
+            if (uturn_pool(s_in_th, s_in_rh, fwd)) {  // walnuts.hpp:490-492
+              ok = false;
+              break;
+            }
+            WN_PHASE(kPhCombine);
+            const double total = uni(carry);
+            const bool update = this->log_uniform01() < c_logsum - total;
+            const int n_sel = update ? c_sel : s_sel;
+            const double n_lpsel = update ? c_lpsel : s_lpsel;
+            this->release_unless(s_sel, s_in_th, s_in_rh, n_sel);
+            this->release_unless(c_in_th, s_in_th, s_in_rh, n_sel);
+            this->release_unless(c_in_rh, s_in_th, s_in_rh, n_sel);
+            this->release_unless(c_sel, s_in_th, s_in_rh, n_sel);
+            c_in_th = s_in_th;
+            c_in_rh = s_in_rh;
+            c_sel = n_sel;
+            c_lpsel = n_lpsel;
+            c_logsum = total;
+          }
+          if (!ok) break;
+          WN_PHASE(kPhPush);
+          if (i + 2 < nleaf) {
+            // the next pair overwrites both sets: whatever is still symbolic gets pool buffers
+            const bool sel_is_inner = (c_sel == c_in_th);
+            c_in_th = materialize(c_in_th, false);
+            c_in_rh = materialize(c_in_rh, true);
+            c_sel = sel_is_inner ? c_in_th : materialize(c_sel, false);
+            if (lane == 0) {
+              meta->in_th[sp] = c_in_th;
+              meta->in_rh[sp] = c_in_rh;
+              meta->sel[sp] = c_sel;
+              meta->logsum[sp] = c_logsum;
+              meta->lpsel[sp] = c_lpsel;
+            }
+            ++sp;
+          }
+        }
+      }
+      if (!ok) break;  // walnuts.hpp:543-545
+
+      // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
+      WN_PHASE(kPhTopMerge);
+      bool turned;
+      double total;
+      if (nleaf == 1) {
+        turned = top_turned;
+        total = uni(log_sum_exp(a_logsum, c_logsum));
+      } else {
+        this->lse_on_leader(a_logsum, c_logsum);
+        turned = uturn_pool(o_th, o_rh, fwd);
+        total = uni(carry);
+      }
+      const bool update = this->log_uniform01() < c_logsum - a_logsum;  // Metropolis
+      // the new span's inner end is never read again
+      this->release_unless(c_in_th, c_sel, -3, -3);
+      this->release_unless(c_in_rh, -3, -3, -3);
+      if (update) {
+        c_sel = materialize(c_sel, false);
+        if (a_sel != o_th) this->release(a_sel);
+        a_sel = c_sel;
+        a_lpsel = c_lpsel;
+      } else {
+        this->release(c_sel);
+      }
+      lj_hot = h_cur;
+      a_logsum = total;
+      if (turned) break;  // walnuts.hpp:549,556-558
+    }
+
+    // ---- selected state out (walnuts.hpp:560-562), estimator update (adaptive_walnuts.hpp:247-248) ----
+    WN_PHASE(kPhEpilogue);
+    this->refresh_ids();
+    finish_transition(a_sel, row, warm);
+    this->store_scalars(warm, depth, a_lpsel);
+  }
+
+  // load the chain, refresh the momentum (walnuts.hpp:528-529), evaluate the initial point (:532)
+  __device__ __forceinline__ double begin_transition(long long row, bool warm) {
+    const auto& Q = this->cold();
+    vload(Q.theta + row, th[0]);
+    if (Model::kUsesParams) vload(Q.model_params, mp);
+    double chol[EPL];
+    if (warm) {
+      // adaptive_walnuts.hpp:235-236 with MassEstimator::inv_mass_estimate :89-94
+      const double wd = w_draw0, ws = w_score0;
+      double ds[EPL], ss[EPL];
+      vload(Q.est_draw_ssd + row, ds);
+      vload(Q.est_score_ssd + row, ss);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        im[j] = __builtin_sqrt((ds[j] / wd) / (ss[j] / ws));
+        chol[j] = __builtin_sqrt(1.0 / im[j]);
+      }
+    } else {
+      vload(Q.inv_mass + row, im);
+      vload(Q.chol_mass + row, chol);  // 1/sqrt(inv_mass), walnuts.hpp:647, computed once at freeze
+    }
+    if (Q.rng_mode == kRngBuffer) {
+      double z[EPL];
+      vload(Q.z_buf + row, z);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) rh[0][j] = chol[j] * z[j];
+    } else {
+      const uint64_t seed = Q.seed;
+      const uint32_t key_chain = Q.chain_offset + chain, key_tr = Q.transition;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        double z0, z1;
+        const uint32_t pair = static_cast<uint32_t>(k * L + tid);
+        wnd::stream_normal_pair(seed, key_chain, key_tr, wnd::kStreamMomentum, pair, z0, z1);
+        rh[0][2 * k] = valid(2 * k) ? chol[2 * k] * z0 : 0.0;
+        rh[0][2 * k + 1] = valid(2 * k + 1) ? chol[2 * k + 1] * z1 : 0.0;
+      }
+    }
+    return model_eval<0>();
+  }
+
+  __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
+    const auto& Q = this->cold();
+    pool_load(a_sel, th[0]);
+    vstore(Q.theta + row, th[0]);
+    double* draws = Q.draws_out;
+    if (draws != nullptr) {
+      double* out = draws + static_cast<long long>(chain) * Q.draws_stride;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        if (valid(j)) out[index(j)] = th[0][j];
+      }
+    }
+    if (warm) {
+      // adaptive_walnuts.hpp:247-248: observe (theta_sel, grad_sel).  grad_sel is a pure
+      // function of theta_sel, so it is re-evaluated instead of being carried through the tree.
+      const long long keep_grad = n_grad;
+      (void)model_eval<0>();
+      n_grad = keep_grad;
+      const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(Q.warmup_iter));
+      const double wd = discount * w_draw0 + 1;
+      const double ws = discount * w_score0 + 1;
+      double mean[EPL], ssd[EPL];
+      vload(Q.est_draw_mean + row, mean);
+      vload(Q.est_draw_ssd + row, ssd);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {  // online_moments.hpp:184-191 (lazy delta => (y - mean_new)^2)
+        mean[j] += (th[0][j] - mean[j]) / wd;
+        ssd[j] = discount * ssd[j] + (th[0][j] - mean[j]) * (th[0][j] - mean[j]);
+      }
+      vstore(Q.est_draw_mean + row, mean);
+      vstore(Q.est_draw_ssd + row, ssd);
+      vload(Q.est_score_mean + row, mean);
+      vload(Q.est_score_ssd + row, ssd);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        mean[j] += (G<0>(j) - mean[j]) / ws;
+        ssd[j] = discount * ssd[j] + (G<0>(j) - mean[j]) * (G<0>(j) - mean[j]);
+      }
+      vstore(Q.est_score_mean + row, mean);
+      vstore(Q.est_score_ssd + row, ssd);
+    }
+  }
+};
+
+// Geometry table of the on-chip kernels: waves per SIMD the register budget is cut for, and how many pool vectors
+// live in registers (two banks, each a vector width).  One vector costs 2*EPL VGPRs per lane; the moving end's two
+// sets, the inverse mass and the two operands of a pool-side U-turn test come first, the register pool takes what
+// the budget leaves.
+template <class Model, int EPL>
+constexpr int chip_waves_per_simd() {
+#if defined(WN_WPE8)
+  if (EPL == 8) return WN_WPE8;
+#endif
+  // a model that keeps its gradient vectors (two more per set) gets the next larger register budget
+  if (!Model::kCheapGrad) return EPL >= 8 ? 1 : EPL == 4 ? 2 : 3;
+  return EPL >= 16 ? 1 : EPL == 8 ? 2 : EPL == 4 ? 3 : 4;
+}
+template <class Model, int EPL>
+constexpr int chip_bank_a() {
+#if defined(WN_RA8)
+  if (EPL == 8) return WN_RA8;
+#endif
+  if (EPL >= 16) return 0;   // 512 registers, 32 per vector
+  if (EPL == 8) return 0;    // 256 registers, 16 per vector: measured, any bank makes the allocator spill
+  return 0;
+}
+template <class Model, int EPL>
+constexpr int chip_bank_b() {
+#if defined(WN_RB8)
+  if (EPL == 8) return WN_RB8;
+#endif
+  return 0;
+}
+template <class Model, int EPL>
+constexpr int chip_reg_pool() {
+  return chip_bank_a<Model, EPL>() + chip_bank_b<Model, EPL>();
+}
+
+template <class Model, int NW, int EPL>
+__global__ __launch_bounds__(64 * NW, (chip_waves_per_simd<Model, EPL>())) void transition_kernel_chip(const Params P) {
+  persistent_loop<TrajChip<Model, NW, EPL, chip_bank_a<Model, EPL>(), chip_bank_b<Model, EPL>()>, NW>(P);
+}
+
+}  // namespace wn

@@ -43,7 +43,7 @@ struct wn_engine {
   int device = 0;
   int num_cus = 256;
   int grid = 0;
-  int pool_lds = 0, pool_total = 0, lds_state = 0;
+  int pool_lds = 0, pool_reg = 0, pool_total = 0;
   int64_t arena_stride = 0;  // doubles per persistent workgroup: HBM part of the span pool (+ streaming scratch)
   size_t smem = 0;
   hipStream_t stream = nullptr;
@@ -199,7 +199,7 @@ struct wn_engine {
     P.warmup_iter = warmup_iter;
     P.arena = arena.p;
     P.arena_stride = arena_stride;
-    P.lds_state = lds_state;
+    P.pool_reg = pool_reg;
     P.pool_lds = pool_lds;
     P.pool_total = pool_total;
     P.work_counter = counter.p;
@@ -260,11 +260,11 @@ void wn_engine::advance_reference_streams() {
 
 namespace {
 
-int required_pool(const wn_config& c, bool start_regs) {
-  // accumulated span 6 + its selection 1, one entry (<=3) per stack level 0..max_depth-2, the span
-  // under construction 3, the parked state of a reversibility check 3, restart state, slack
+int required_pool(const wn_config& c) {
+  // other end of the accumulated span 3 + its selection 1, one entry (<= 3 vectors) per stack level
+  // 1..max_depth-2, the span under construction 3, the parked state of a reversibility check 3, slack
   const int levels = std::max(1, c.max_trajectory_doublings - 1);
-  return 7 + 3 * levels + 3 + 3 + (start_regs ? 0 : 3) + 2;
+  return 4 + 3 * levels + 3 + 3 + 2;
 }
 
 void build_engine(wn_engine& e, int model, int num_params, const double* model_params, size_t num_chains,
@@ -289,11 +289,6 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.cfg = cfg;
   e.device = cfg.device;
   e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, model != WN_MODEL_FUNNEL);
-  if (!e.geo.mem && cfg.state_in_lds > 0) {
-    if (!wn::lds_geometry_exists(e.geo.nw, e.geo.epl, cfg.state_in_lds))
-      throw std::invalid_argument("no LDS-state kernel for this geometry / waves-per-SIMD budget");
-    e.geo.lds_wpe = cfg.state_in_lds;
-  }
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
@@ -303,11 +298,16 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
 
   // residency: how many chains (workgroups) share a CU, and how much of the span pool sits in LDS
   const size_t lds_per_cu = 160 * 1024;
-  e.pool_total = std::min(required_pool(cfg, e.geo.start_regs) + (e.geo.mem ? wn::kMemRoleVectors : 0), wn::kMaxPool);
-  int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo, model != WN_MODEL_FUNNEL);
+  e.pool_total = required_pool(cfg) + (e.geo.mem ? wn::kMemRoleVectors : 0);
+  if (e.pool_total > wn::kMaxPool)
+    throw std::invalid_argument("max_trajectory_doublings needs more span-pool vectors than the device free mask holds");
+  e.pool_reg = wn::register_pool(model, e.geo);
+  if (cfg.reg_vectors >= 0) e.pool_reg = std::min(e.pool_reg, cfg.reg_vectors);
+  const int wps = wn::waves_per_simd(model, e.geo);
+  int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo, wps);
   wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
-  e.lds_state = e.geo.lds_wpe > 0 ? 3 : 0;
-  const size_t fixed = wn::transition_smem_bytes(e.geo.nw, e.lds_state, e.Dp);
+  if (!e.geo.mem) wg_per_cu = std::min(wg_per_cu, std::max(1, 4 * wps / e.geo.nw));
+  const size_t fixed = wn::transition_smem_bytes(e.geo.nw, 0, e.Dp);
   const size_t budget = lds_per_cu / wg_per_cu;
   const size_t vec_bytes = sizeof(double) * e.Dp;
   if (fixed > budget) throw std::invalid_argument("workgroups_per_cu too high for the LDS-resident state");
@@ -315,7 +315,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   if (cfg.lds_vectors >= 0 && cfg.lds_vectors < lds_vecs) lds_vecs = cfg.lds_vectors;
   if (e.geo.mem) lds_vecs = 0;  // streaming backend: vectors are far larger than LDS
   e.pool_lds = std::min(lds_vecs, e.pool_total);
-  e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds + e.lds_state, e.Dp);
+  e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds, e.Dp);
   const int usable_cus = std::max(1, e.num_cus - std::max(0, cfg.reserved_cus));
   e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(usable_cus) * wg_per_cu));
 
@@ -340,8 +340,9 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.mon_rel_mass.alloc(num_chains);
   e.mon_rel_step.alloc(num_chains);
   e.scratch64.alloc(1);
-  const size_t arena_vecs =
-      static_cast<size_t>(e.pool_total - e.pool_lds) + (e.geo.mem ? wn::kMemScratchVectors : 0);
+  // what neither LDS nor the kernels' register pool holds (deep trees only) overflows to a per-workgroup HBM arena
+  const size_t arena_vecs = static_cast<size_t>(std::max(0, e.pool_total - e.pool_lds - e.pool_reg)) +
+                            (e.geo.mem ? wn::kMemScratchVectors : 0);
   e.arena_stride = static_cast<int64_t>(arena_vecs) * e.Dp;
   e.arena.alloc(std::max<size_t>(1, static_cast<size_t>(e.grid) * arena_vecs * e.Dp));
   e.model_params.alloc(e.Dp);
@@ -432,8 +433,8 @@ void wn_default_config(wn_config* c) {
   c->elems_per_lane = 0;
   c->workgroups_per_cu = 0;
   c->lds_vectors = -1;
+  c->reg_vectors = -1;
   c->reserved_cus = 0;
-  c->state_in_lds = 0;
 }
 
 int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params, size_t num_chains,

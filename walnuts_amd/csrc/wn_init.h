@@ -6,7 +6,7 @@
 // (adaptive_walnuts.hpp:54-62,205-223) and freeze it into a WalnutsSampler (:263-271).
 #pragma once
 
-#include "wn_traj.h"
+#include "wn_chip.h"
 
 namespace wn {
 
@@ -29,7 +29,7 @@ struct InitParams {
 template <class Model, int NW, int EPL>
 __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
   WN_DYN_SMEM(smem);
-  using T = Traj<Model, NW, EPL, true>;
+  using T = TrajChip<Model, NW, EPL, 0, 0>;  // the register kernels' vector helpers; set 0 is the working state
   Params P{};  // only the fields the model context and reductions read
   P.num_chains = Q.num_chains;
   P.dim = Q.dim;
@@ -53,18 +53,18 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
         double z0, z1;
         wnd::stream_normal_pair(Q.pos_seed, Q.pos_chain_offset + chain, 0u, wnd::kStreamInitPos,
                                 static_cast<uint32_t>(k * L + t.tid), z0, z1);
-        t.th[2 * k] = t.valid(2 * k) ? z0 * Q.scale : 0.0;
-        t.th[2 * k + 1] = t.valid(2 * k + 1) ? z1 * Q.scale : 0.0;
+        t.th[0][2 * k] = t.valid(2 * k) ? z0 * Q.scale : 0.0;
+        t.th[0][2 * k + 1] = t.valid(2 * k + 1) ? z1 * Q.scale : 0.0;
       }
-      t.vstore(Q.theta + row, t.th);
+      t.vstore(Q.theta + row, t.th[0]);
     } else {
-      t.vload(Q.theta + row, t.th);
+      t.vload(Q.theta + row, t.th[0]);
     }
     double mass[EPL];
     if (Q.do_masses) {
-      (void)t.model_eval();
+      (void)t.template model_eval<0>();
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) mass[j] = t.valid(j) ? (1 - Q.smoothing) * fabs(t.G(j)) + Q.smoothing : 1.0;
+      for (int j = 0; j < EPL; ++j) mass[j] = t.valid(j) ? (1 - Q.smoothing) * fabs(t.template G<0>(j)) + Q.smoothing : 1.0;
       t.vstore(Q.mass + row, mass);
     } else {
       t.vload(Q.mass + row, mass);
@@ -90,27 +90,31 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
         }
       }
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) th_keep[j] = t.th[j];
+      for (int j = 0; j < EPL; ++j) th_keep[j] = t.th[0][j];
       double step = uni(Q.step_init[chain]);
       const double log09 = wnd::dlog(0.9), log06 = wnd::dlog(0.6), rt = __builtin_sqrt(0.5);
       // util.hpp:242-259
       auto leapfrog_error = [&](double h) -> double {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-          t.th[j] = th_keep[j];
-          t.rh[j] = rho0[j];
+          t.th[0][j] = th_keep[j];
+          t.rh[0][j] = rho0[j];
         }
-        double part = t.model_eval();
+        double part = t.template model_eval<0>();
         double lp, lj0, lj1;
-        t.energy(part, lp, lj0);
+        double ke = t.template kinetic_partial<0>();
+        t.sum2(part, ke);
+        t.finish_energy(part, ke, lp, lj0);
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) t.rh[j] = t.rh[j] + 0.5 * h * t.G(j);
+        for (int j = 0; j < EPL; ++j) t.rh[0][j] = t.rh[0][j] + 0.5 * h * t.template G<0>(j);
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) t.th[j] = t.th[j] + h * (t.im[j] * t.rh[j]);
-        part = t.model_eval();
+        for (int j = 0; j < EPL; ++j) t.th[0][j] = t.th[0][j] + h * (t.im[j] * t.rh[0][j]);
+        part = t.template model_eval<0>();
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) t.rh[j] = t.rh[j] + 0.5 * h * t.G(j);
-        t.energy(part, lp, lj1);
+        for (int j = 0; j < EPL; ++j) t.rh[0][j] = t.rh[0][j] + 0.5 * h * t.template G<0>(j);
+        ke = t.template kinetic_partial<0>();
+        t.sum2(part, ke);
+        t.finish_energy(part, ke, lp, lj1);
         return lj1 - lj0;
       };
       while (leapfrog_error(step) > log09) step *= 2;

@@ -13,32 +13,11 @@ namespace wn {
 struct InitParams;
 
 // NW wavefronts cooperate on one chain, each lane holds EPL elements of every vector:
-// padded dimension Dp = 64*NW*EPL.  START_REGS: the macro step's restart state stays in VGPRs.
-// `mem`: the streaming backend (TrajMem) -- vectors in HBM, any dimension; epl is 0 then.
-// `lds_wpe` > 0: the LDS_STATE register kernels (inverse mass + restart state in LDS), compiled for that many
-// wavefronts per SIMD.
+// padded dimension Dp = 64*NW*EPL.  `mem`: the streaming backend (TrajMem) -- vectors in HBM, any dimension; epl is 0 then.
 struct Geometry {
   int nw, epl;
-  bool start_regs;
   bool mem;
-  int lds_wpe;
 };
-
-// X(NW, EPL, WPE)
-#if defined(WN_SIM_GEOMETRIES)
-#define WN_FOR_EACH_LDS_GEOMETRY(X) X(1, 2, 3)
-#elif defined(WN_FAST_BUILD)
-#define WN_FOR_EACH_LDS_GEOMETRY(X) X(2, 8, 3) X(4, 4, 3) X(4, 4, 4)
-#else
-#define WN_FOR_EACH_LDS_GEOMETRY(X) X(1, 8, 3) X(2, 4, 4) X(2, 8, 3) X(4, 4, 3) X(4, 4, 4) X(4, 8, 3) X(8, 4, 4) X(8, 8, 3)
-#endif
-inline bool lds_geometry_exists(int nw, int epl, int wpe) {
-#define WN_X(NW, EPL, WPE) \
-  if (nw == NW && epl == EPL && wpe == WPE) return true;
-  WN_FOR_EACH_LDS_GEOMETRY(WN_X)
-#undef WN_X
-  return false;
-}
 
 // X(NW) -- wavefronts per chain of the streaming kernels
 #if defined(WN_SIM_GEOMETRIES)
@@ -65,24 +44,20 @@ inline int default_mem_waves() {
 }
 constexpr int kMaxRegisterDim = 8192;
 
-// X(NW, EPL, START_REGS)
-#if defined(WN_SIM_GEOMETRIES)  // tests/cpusim: small workgroups only; (1,4) exercises the pool-resident restart state
-#define WN_FOR_EACH_GEOMETRY(X) X(1, 2, true) X(1, 4, false) X(2, 2, true)
+// X(NW, EPL) -- the register kernels (TrajChip, wn_chip.h)
+#if defined(WN_SIM_GEOMETRIES)  // tests/cpusim: small workgroups only
+#define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(1, 4) X(2, 2)
 #elif defined(WN_FAST_BUILD)
-#define WN_FOR_EACH_GEOMETRY(X) X(1, 2, true) X(4, 4, true) X(2, 8, true)
+#define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(4, 4) X(2, 8) X(1, 16)
 #else
-#define WN_FOR_EACH_GEOMETRY(X)                                                                     \
-  X(1, 2, true) X(1, 4, true) X(1, 8, true) X(1, 16, true) X(2, 2, true) X(2, 4, true) X(2, 8, true)   \
-  X(4, 2, true) X(4, 4, true) X(4, 8, true) X(8, 2, true) X(8, 4, true) X(8, 8, true) X(16, 4, true)     \
-  X(16, 8, false)
+#define WN_FOR_EACH_GEOMETRY(X)                                                            \
+  X(1, 2) X(1, 4) X(1, 8) X(1, 16) X(2, 2) X(2, 4) X(2, 8) X(4, 2) X(4, 4) X(4, 8) X(8, 2) \
+  X(8, 4) X(8, 8) X(16, 4) X(16, 8)
 #endif
 
-inline bool geometry_exists(int nw, int epl, bool* start_regs) {
-#define WN_X(NW, EPL, SR)          \
-  if (nw == NW && epl == EPL) {    \
-    *start_regs = SR;              \
-    return true;                   \
-  }
+inline bool geometry_exists(int nw, int epl) {
+#define WN_X(NW, EPL) \
+  if (nw == NW && epl == EPL) return true;
   WN_FOR_EACH_GEOMETRY(WN_X)
 #undef WN_X
   return false;
@@ -90,7 +65,7 @@ inline bool geometry_exists(int nw, int epl, bool* start_regs) {
 
 // elems_per_lane == -1 requests the streaming backend explicitly (it is the default above kMaxRegisterDim)
 inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_model = true) {
-  Geometry g{0, 0, true, false, 0};
+  Geometry g{0, 0, false};
   if (epl_req < 0 || (dim > kMaxRegisterDim && epl_req == 0)) {
     g.mem = true;
     g.nw = nw_req > 0 ? nw_req : default_mem_waves();
@@ -98,7 +73,7 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_mod
     return g;
   }
   if (nw_req > 0 && epl_req > 0) {
-    if (!geometry_exists(nw_req, epl_req, &g.start_regs) || 64 * nw_req * epl_req < dim)
+    if (!geometry_exists(nw_req, epl_req) || 64 * nw_req * epl_req < dim)
       throw std::invalid_argument("unsupported waves_per_chain / elems_per_lane for this num_params");
     g.nw = nw_req;
     g.epl = epl_req;
@@ -114,7 +89,7 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_mod
   const int npref = light_model ? 7 : 8;
   for (int i = 0; i < npref; ++i) {
     const int* p = pref[i];
-    if (64 * p[0] * p[1] >= dim && geometry_exists(p[0], p[1], &g.start_regs)) {
+    if (64 * p[0] * p[1] >= dim && geometry_exists(p[0], p[1])) {
       g.nw = p[0];
       g.epl = p[1];
       return g;
@@ -122,10 +97,10 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_mod
   }
   // fast builds carry a reduced table: take the smallest entry that fits
   int best = 1 << 30;
-#define WN_X(NW, EPL, SR)                                  \
+#define WN_X(NW, EPL)                                      \
   if (64 * NW * EPL >= dim && 64 * NW * EPL < best) {      \
     best = 64 * NW * EPL;                                  \
-    g = Geometry{NW, EPL, SR, false, 0};                   \
+    g = Geometry{NW, EPL, false};                          \
   }
   WN_FOR_EACH_GEOMETRY(WN_X)
 #undef WN_X
@@ -133,13 +108,9 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_mod
   return g;
 }
 
-inline int default_workgroups_per_cu(const Geometry& g, bool three_waves_per_simd = false) {
-  if (g.lds_wpe > 0) return std::max(1, 4 * g.lds_wpe / g.nw);  // fill the register budget the kernel was built for
+inline int default_workgroups_per_cu(const Geometry& g, int waves_per_simd) {
   if (g.mem) return g.nw >= 16 ? 1 : 16 / g.nw;  // streaming: latency is hidden by resident waves
-  if (three_waves_per_simd && g.epl == 8) return std::max(1, 12 / g.nw);  // kernels built for 3 waves per SIMD
-  if (g.epl == 16) return 4;  // 256 VGPRs + AGPRs: one wave per SIMD
-  if (g.nw == 1 && g.epl <= 4) return 12;  // small kernels: registers allow it (measured on the D=128 funnel: +7 %)
-  return g.nw >= 8 ? 1 : 8 / g.nw;
+  return std::max(1, 4 * waves_per_simd / g.nw);  // fill the register budget the kernel is built for
 }
 inline int padded_dim(const Geometry& g, int dim) {
   const int lanes = 64 * g.nw;
@@ -151,7 +122,9 @@ inline int padded_dim(const Geometry& g, int dim) {
 #define WN_DECLARE_MODEL(tag)                                                                              \
   void launch_transition_##tag(const Geometry&, int grid, size_t smem, hipStream_t, const Params&);        \
   void launch_init_##tag(const Geometry&, int grid, size_t smem, hipStream_t, const InitParams&);          \
-  void prepare_##tag(const Geometry&, size_t smem);
+  void prepare_##tag(const Geometry&, size_t smem);                                                        \
+  int register_pool_##tag(const Geometry&);                                                                \
+  int waves_per_simd_##tag(const Geometry&);
 WN_DECLARE_MODEL(std_normal)
 WN_DECLARE_MODEL(diag_normal)
 WN_DECLARE_MODEL(funnel)
@@ -170,6 +143,24 @@ inline void launch_init(int model, const Geometry& g, int grid, size_t smem, hip
     case kStdNormal: launch_init_std_normal(g, grid, smem, s, q); break;
     case kDiagNormal: launch_init_diag_normal(g, grid, smem, s, q); break;
     case kFunnel: launch_init_funnel(g, grid, smem, s, q); break;
+    default: throw std::invalid_argument("unknown device model id");
+  }
+}
+// pool vectors the register kernel of this model / geometry keeps in VGPRs (0 for the streaming kernels)
+inline int register_pool(int model, const Geometry& g) {
+  switch (model) {
+    case kStdNormal: return register_pool_std_normal(g);
+    case kDiagNormal: return register_pool_diag_normal(g);
+    case kFunnel: return register_pool_funnel(g);
+    default: throw std::invalid_argument("unknown device model id");
+  }
+}
+// wavefronts per SIMD the register kernel of this model / geometry is compiled for (its VGPR budget)
+inline int waves_per_simd(int model, const Geometry& g) {
+  switch (model) {
+    case kStdNormal: return waves_per_simd_std_normal(g);
+    case kDiagNormal: return waves_per_simd_diag_normal(g);
+    case kFunnel: return waves_per_simd_funnel(g);
     default: throw std::invalid_argument("unknown device model id");
   }
 }

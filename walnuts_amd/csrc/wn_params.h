@@ -71,9 +71,9 @@ struct Params {
   // scratch
   double* arena;         // [slots][pool_global][Dp]
   int64_t arena_stride;  // doubles per slot
-  int32_t lds_state;     // 0, or 3: inverse mass + restart theta/rho vectors kept in LDS (LDS_STATE kernels)
+  int32_t pool_reg;      // vector buffers living in the kernel's register pool (<= the RP it was built with)
   int32_t pool_lds;      // vector buffers living in LDS
-  int32_t pool_total;    // LDS + arena buffers
+  int32_t pool_total;    // LDS + register + arena buffers
   uint32_t* work_counter;
 };
 

@@ -1,7 +1,8 @@
 // wn_traj.h -- the GPU-resident Walnuts transition for one chain per workgroup (gfx950).
 //
-// Layout of this file: device models; TrajBase (the tree logic, shared); TrajReg (vectors in VGPRs, D <= 8192);
-// TrajMem (vectors streamed from HBM, any D); the two persistent kernels.
+// Layout of this file: device models; TrajBase (reductions, span-pool bookkeeping, random-number order, adaptation
+// scalars, and the tree loop of the streaming backend); TrajMem (vectors streamed from HBM, any D); the persistent
+// chain loop.  The register backend (vectors in VGPRs, D <= 8192) is TrajChip in wn_chip.h.
 //
 // One workgroup of NW wavefronts owns one chain at a time.  Lane l of the
 // workgroup (L = 64*NW lanes) owns the 16-byte element pairs (k*L + l),
@@ -41,8 +42,9 @@
 
 namespace wn {
 
-// reduction scratch in LDS: two parity halves of (2 per wavefront + 1 carried scalar)
-constexpr int kRedDoubles(int nw) { return 2 * (2 * nw + 1); }
+// reduction scratch in LDS: two parity halves of (4 per wavefront + 1 carried scalar)
+constexpr int kRedStride(int nw) { return 4 * nw + 1; }
+constexpr int kRedDoubles(int nw) { return 2 * kRedStride(nw); }
 
 // ---- wave-uniform helpers ----------------------------------------------------
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -282,6 +284,7 @@ struct TrajBase {
   int chain;
   int Dp;
   unsigned long long free_mask;
+  unsigned long long onchip_mask;  // pool buffers that never leave the chip (all of them for the legacy backends)
   int red_parity;
   double carry;       // scalar computed by wavefront 0 that the next sum2 hands to the other wavefronts
   bool carry_armed;
@@ -296,6 +299,23 @@ struct TrajBase {
 
   __device__ __forceinline__ Self& self() { return *static_cast<Self*>(this); }
 
+  // Launch parameters read once or twice per transition (plane pointers, stream keys, adaptation constants) are
+  // fetched from the kernel-argument segment where they are used instead of being held in scalar registers for
+  // the whole kernel: the compiler otherwise hoists all ~100 dwords of Params to the kernel entry and spills
+  // them to VGPR lanes (185-236 spilled SGPRs, 13 % of the VALU stream, before this).  The empty asm hides the
+  // pointer's origin at every use so that the loads cannot be hoisted or merged across calls.  Only the
+  // transition kernels, whose single kernel argument IS the Params struct, may call this.
+#if defined(WN_CPU_SIM)
+  __device__ __forceinline__ const Params& cold() const { return P; }
+#else
+  typedef const __attribute__((address_space(4))) Params ColdParams;
+  __device__ __forceinline__ ColdParams& cold() const {
+    ColdParams* p = (ColdParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+  }
+#endif
+
   __device__ __forceinline__ TrajBase(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
                                       WN_LDS double* bc, double* ar)
       : P(p), lds_pool(pool), meta(m), red(r), bcast(bc), arena(ar) {
@@ -306,6 +326,7 @@ struct TrajBase {
     red_parity = 0;
     carry = 0.0;
     carry_armed = false;
+    onchip_mask = ~0ull;
   }
 
 #if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
@@ -342,6 +363,19 @@ struct TrajBase {
     return v;
   }
 
+  // Re-derive the lane identity behind an optimisation barrier.  Everything computed from it (addresses, padding
+  // masks, the counter words of the random stream) is then rebuilt where it is used instead of being hoisted out
+  // of the persistent chain loop to the kernel entry and held -- or spilled -- for the whole kernel.
+  __device__ __forceinline__ void refresh_ids() {
+#if !defined(WN_CPU_SIM)
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    tid = t;
+    lane = t & 63;
+    wave = uni(t >> 6);
+#endif
+  }
+
   // ---- reductions -----------------------------------------------------------------
   __device__ __forceinline__ void sum2(double& a, double& b) {
 #if defined(WN_CPU_SIM)
@@ -358,7 +392,7 @@ struct TrajBase {
     }
 #endif
     if (NW > 1) {
-      WN_LDS double* r = red + red_parity * (NW * 2 + 1);
+      WN_LDS double* r = red + red_parity * kRedStride(NW);
       if (lane == 0) r[wave * 2] = packed;
       if (lane == 32) r[wave * 2 + 1] = packed;
       if (carry_armed && tid == 0) r[NW * 2] = carry;  // wavefront 0's scalar rides along (see lse_on_leader)
@@ -377,6 +411,57 @@ struct TrajBase {
     carry_armed = false;
     a = uni(a);
     b = uni(b);
+  }
+  // four sums behind one exchange (a leaf's two energies and the two level-0 U-turn products): two packed
+  // butterflies interleave, one barrier
+  __device__ __forceinline__ void sum4(double& a, double& b, double& c, double& d) {
+#if defined(WN_CPU_SIM)
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    d = wave_sum(d);
+    const double p1 = lane < 32 ? a : b, p2 = lane < 32 ? c : d;
+#else
+    const double p1 = wave_sum_pair(a, b), p2 = wave_sum_pair(c, d);
+    if (NW == 1) {
+      a = uni(p1);
+      b = lane_value(p1, 32);
+      c = uni(p2);
+      d = lane_value(p2, 32);
+      carry_armed = false;
+      return;
+    }
+#endif
+    if (NW > 1) {
+      WN_LDS double* r = red + red_parity * kRedStride(NW);
+      if (lane == 0) {
+        r[wave * 4] = p1;
+        r[wave * 4 + 2] = p2;
+      }
+      if (lane == 32) {
+        r[wave * 4 + 1] = p1;
+        r[wave * 4 + 3] = p2;
+      }
+      __syncthreads();
+      double ta = r[0], tb = r[1], tc = r[2], td = r[3];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        ta = ta + r[w * 4];
+        tb = tb + r[w * 4 + 1];
+        tc = tc + r[w * 4 + 2];
+        td = td + r[w * 4 + 3];
+      }
+      a = ta;
+      b = tb;
+      c = tc;
+      d = td;
+      red_parity ^= 1;
+    }
+    carry_armed = false;
+    a = uni(a);
+    b = uni(b);
+    c = uni(c);
+    d = uni(d);
   }
   // log_sum_exp for the merge that follows a U-turn test: a hundred instructions of wave-uniform scalar maths.  Only
   // wavefront 0 evaluates it, BEFORE the test, and the value travels to the other wavefronts of the chain in the LDS
@@ -408,7 +493,9 @@ struct TrajBase {
       err = 1;
       return 0;
     }
-    const int b = uni(63 - __builtin_clzll(free_mask));
+    // the highest free on-chip buffer (LDS / register pool); with none left, the lowest of the HBM arena
+    const unsigned long long on = free_mask & onchip_mask;
+    const int b = on != 0ull ? uni(63 - __builtin_clzll(on)) : uni(__builtin_ctzll(free_mask));
     free_mask &= ~(1ull << b);
     return b;
   }
@@ -442,11 +529,12 @@ struct TrajBase {
   __device__ __forceinline__ void refill_draws(int base) {
     draw_base = base;
     const int j = base + lane;
+    const auto& Q = cold();
     double u;
-    if (P.rng_mode == kRngBuffer) {
-      u = j < P.u_stride ? P.u_buf[static_cast<long long>(chain) * P.u_stride + j] : 0.5;
+    if (Q.rng_mode == kRngBuffer) {
+      u = j < Q.u_stride ? Q.u_buf[static_cast<long long>(chain) * Q.u_stride + j] : 0.5;
     } else {
-      u = wnd::stream_uniform(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamTree,
+      u = wnd::stream_uniform(Q.seed, Q.chain_offset + chain, Q.transition, wnd::kStreamTree,
                               static_cast<uint32_t>(j));
     }
     if (lane < kDrawCache) {
@@ -466,17 +554,18 @@ struct TrajBase {
   // adam.hpp:70-86
   __device__ __forceinline__ void adam_observe(double alpha) {
     WN_LDS double* a = meta->adam;
+    const auto& Q = cold();
     double theta = a[0], m = a[1], v = a[2], t = a[3], b1p = a[4], b2p = a[5];
     t += 1;
-    b1p *= P.adam_b1;
-    b2p *= P.adam_b2;
-    const double grad = P.adam_target - alpha;
-    m = P.adam_b1 * m + (1 - P.adam_b1) * grad;
-    v = P.adam_b2 * v + (1 - P.adam_b2) * grad * grad;
+    b1p *= Q.adam_b1;
+    b2p *= Q.adam_b2;
+    const double grad = Q.adam_target - alpha;
+    m = Q.adam_b1 * m + (1 - Q.adam_b1) * grad;
+    v = Q.adam_b2 * v + (1 - Q.adam_b2) * grad * grad;
     const double m_hat = m / (1 - b1p);
     const double v_hat = v / (1 - b2p);
-    const double lr_t = P.adam_lr / wnd::dpow_pos(t, P.adam_decay);
-    const double denom = __builtin_sqrt(v_hat) + P.adam_eps;
+    const double lr_t = Q.adam_lr / wnd::dpow_pos(t, Q.adam_decay);
+    const double denom = __builtin_sqrt(v_hat) + Q.adam_eps;
     theta -= lr_t * m_hat / denom;
     if (lane == 0) {
       a[0] = theta; a[1] = m; a[2] = v; a[3] = t; a[4] = b1p; a[5] = b2p;
@@ -485,37 +574,39 @@ struct TrajBase {
 
   // per-chain tuning parameters of this transition (adaptive_walnuts.hpp:235-245 / walnuts.hpp:686-689)
   __device__ __forceinline__ void load_tuning(bool warm) {
+    const auto& Q = cold();
     if (warm) {
-      w_draw0 = uni(P.est_weight[2 * chain]);
-      w_score0 = uni(P.est_weight[2 * chain + 1]);
+      w_draw0 = uni(Q.est_weight[2 * chain]);
+      w_score0 = uni(Q.est_weight[2 * chain + 1]);
       if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) meta->adam[i] = P.adam[6 * chain + i];
+        for (int i = 0; i < 6; ++i) meta->adam[i] = Q.adam[6 * chain + i];
       }
-      step = uni(wnd::dexp(P.adam[6 * chain]));  // adam.hpp:93
+      step = uni(wnd::dexp(Q.adam[6 * chain]));  // adam.hpp:93
       // adaptive_walnuts.hpp:152-157
-      const double mean_micro = P.mm_state[2 * chain] / P.mm_state[2 * chain + 1];
-      const long long est = static_cast<long long>(__builtin_round(mean_micro / P.macro_target));
-      min_micro = uni(static_cast<int>(est > P.cfg_min_micro ? est : P.cfg_min_micro));
+      const double mean_micro = Q.mm_state[2 * chain] / Q.mm_state[2 * chain + 1];
+      const long long est = static_cast<long long>(__builtin_round(mean_micro / Q.macro_target));
+      min_micro = uni(static_cast<int>(est > Q.cfg_min_micro ? est : Q.cfg_min_micro));
     } else {
-      step = uni(P.step_size[chain]);
-      min_micro = uni(P.min_micro[chain]);
+      step = uni(Q.step_size[chain]);
+      min_micro = uni(Q.min_micro[chain]);
     }
   }
   // per-chain scalar results of this transition
   __device__ __forceinline__ void store_scalars(bool warm, int depth, double lpsel) {
     if (tid == 0) {
+      const auto& Q = cold();
       if (warm) {
-        const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(P.warmup_iter));
-        P.est_weight[2 * chain] = discount * w_draw0 + 1;
-        P.est_weight[2 * chain + 1] = discount * w_score0 + 1;
-        P.mm_state[2 * chain] += static_cast<double>(1ll << depth);  // observe(1 << depth)
-        P.mm_state[2 * chain + 1] += 1.0;
+        const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(Q.warmup_iter));
+        Q.est_weight[2 * chain] = discount * w_draw0 + 1;
+        Q.est_weight[2 * chain + 1] = discount * w_score0 + 1;
+        Q.mm_state[2 * chain] += static_cast<double>(1ll << depth);  // observe(1 << depth)
+        Q.mm_state[2 * chain + 1] += 1.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) P.adam[6 * chain + i] = meta->adam[i];
+        for (int i = 0; i < 6; ++i) Q.adam[6 * chain + i] = meta->adam[i];
       }
       if (!warm) {  // ChainWorker: logp_stats_.observe(lp), sampler.hpp:87-88 / online_moments.hpp:34-40
-        double* w = P.lp_stats + 3ll * chain;
+        double* w = Q.lp_stats + 3ll * chain;
         const double n = w[0] + 1;
         const double delta = lpsel - w[1];
         const double mean = w[1] + delta / n;
@@ -523,10 +614,10 @@ struct TrajBase {
         w[1] = mean;
         w[2] += delta * (lpsel - mean);
       }
-      P.logp_out[chain] = lpsel;
-      P.depth_out[chain] = err ? -1 : depth;
-      P.grad_evals[chain] += n_grad;
-      P.rng_draws[chain] = n_draw;
+      Q.logp_out[chain] = lpsel;
+      Q.depth_out[chain] = err ? -1 : depth;
+      Q.grad_evals[chain] += n_grad;
+      Q.rng_draws[chain] = n_draw;
     }
   }
 
@@ -748,402 +839,6 @@ struct TrajBase {
     // ---- selected state out (walnuts.hpp:560-562), estimator update (adaptive_walnuts.hpp:247-248) ----
     self().finish_transition(a_sel, row, warm);
     store_scalars(warm, depth, a_lpsel);
-  }
-};
-
-// ---------------------------------------------------------------------------------------------------
-// TrajReg: every vector of the moving end lives in VGPRs (EPL elements per lane), the span pool in LDS +
-// an HBM arena.  A leapfrog micro step touches no memory.
-// ---------------------------------------------------------------------------------------------------
-// LDS_STATE: the inverse mass and the restart position / momentum live in three workgroup-private LDS vectors
-// instead of VGPRs (the whole span pool then sits in the HBM arena).  Measured: LDS-resident pool vectors buy
-// ~10 %, a third resident wavefront per SIMD buys more, and 48 fewer VGPRs is what makes it fit.
-template <class Model, int NW, int EPL, bool START_REGS, bool LDS_STATE = false>
-struct TrajReg : TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model, NW> {
-  using Base = TrajBase<TrajReg<Model, NW, EPL, START_REGS, LDS_STATE>, Model, NW>;
-  using typename Base::Meta;
-  using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::chain;
-  using Base::Dp; using Base::aux; using Base::n_grad; using Base::max_error; using Base::min_micro;
-  using Base::w_draw0; using Base::w_score0; using Base::meta;
-  static constexpr int L = Base::L;
-  static constexpr int NP = EPL / 2;
-  static constexpr bool kHasStartState = START_REGS || LDS_STATE;
-  static constexpr bool kZeroCopy = false;
-  static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
-
-  double th[EPL], rh[EPL], g[EPL], im[EPL], mp[EPL];
-  // gradient of the moving end at element j.  Where it is just -theta (standard normal) or one multiply (diagonal
-  // normal) nothing is stored, parked or reloaded for it: `g` is dead, its pool buffers are bookkeeping only, and
-  // 2*EPL registers are free.
-  static constexpr bool kNoGrad = Model::kCheapGrad;
-  __device__ __forceinline__ double G(int j) const { return kNoGrad ? Model::grad_elem(th[j], mp[j]) : g[j]; }
-  // restart state.  Its gradient is re-evaluated on a retry (a pure function of th0) when that is a couple of
-  // element-wise operations; a model whose gradient needs a reduction and an exponential (the funnel, where retries
-  // are frequent) keeps the copy the reference keeps (walnuts.hpp:326)
-  static constexpr bool kKeepRestartGrad = START_REGS && !LDS_STATE && !Model::kElementwise;
-  double th0[EPL], rh0[EPL], g0[EPL];
-  int start_buf[3];
-  WN_LDS double* st_im;   // LDS_STATE: inverse mass / restart theta / restart rho vectors
-  WN_LDS double* st_th0;
-  WN_LDS double* st_rh0;
-
-  __device__ __forceinline__ TrajReg(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
-                                     WN_LDS double* bc, double* ar)
-      : Base(p, pool, m, r, bc, ar) {
-    // the state vectors sit in front of the LDS part of the pool (persistent_loop reserves them)
-    st_im = pool - 3 * p.dim_padded;
-    st_th0 = pool - 2 * p.dim_padded;
-    st_rh0 = pool - 1 * p.dim_padded;
-  }
-
-  // run f(inv_mass array): from VGPRs, or streamed out of LDS
-  template <class F>
-  __device__ __forceinline__ void with_im(F f) {
-    if (LDS_STATE) {
-      double t[EPL];
-      lds_load(st_im, t);
-      f(t);
-    } else {
-      f(im);
-    }
-  }
-
-  // ---- model context -----------------------------------------------------------
-  __device__ __forceinline__ int index(int j) const { return ((j >> 1) * L + tid) * 2 + (j & 1); }
-  __device__ __forceinline__ bool valid(int j) const { return index(j) < P.dim; }
-
-  // ---- vector buffers -------------------------------------------------------------
-  __device__ __forceinline__ void vload(const double* base, double (&v)[EPL]) const {
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const v2f64 t = *reinterpret_cast<const v2f64*>(base + (k * L + tid) * 2);
-      v[2 * k] = t[0];
-      v[2 * k + 1] = t[1];
-    }
-  }
-  __device__ __forceinline__ void vstore(double* base, const double (&v)[EPL]) const {
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      v2f64 t;
-      t[0] = v[2 * k];
-      t[1] = v[2 * k + 1];
-      *reinterpret_cast<v2f64*>(base + (k * L + tid) * 2) = t;
-    }
-  }
-  __device__ __forceinline__ void lds_load(const WN_LDS double* base, double (&v)[EPL]) const {
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const v2f64 t = *reinterpret_cast<const WN_LDS v2f64*>(base + (k * L + tid) * 2);
-      v[2 * k] = t[0];
-      v[2 * k + 1] = t[1];
-    }
-  }
-  __device__ __forceinline__ void lds_store(WN_LDS double* base, const double (&v)[EPL]) const {
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      v2f64 t;
-      t[0] = v[2 * k];
-      t[1] = v[2 * k + 1];
-      *reinterpret_cast<WN_LDS v2f64*>(base + (k * L + tid) * 2) = t;
-    }
-  }
-  __device__ __forceinline__ void pool_load(int b, double (&v)[EPL]) const {
-    if (b < P.pool_lds) {
-      lds_load(lds_pool + b * Dp, v);
-    } else {
-      vload(arena + static_cast<long long>(b - P.pool_lds) * Dp, v);
-    }
-  }
-  __device__ __forceinline__ void pool_store(int b, const double (&v)[EPL]) const {
-    if (b < P.pool_lds) {
-      lds_store(lds_pool + b * Dp, v);
-    } else {
-      vstore(arena + static_cast<long long>(b - P.pool_lds) * Dp, v);
-    }
-  }
-  __device__ __forceinline__ void put(int b, Comp c) {
-    switch (c) {
-      case kTh: pool_store(b, th); break;
-      case kRh: pool_store(b, rh); break;
-      case kG:
-        if (!kNoGrad) pool_store(b, g);
-        break;
-      case kTh0:
-        if (LDS_STATE) {
-          double t[EPL];
-          lds_load(st_th0, t);
-          pool_store(b, t);
-        } else {
-          pool_store(b, th0);
-        }
-        break;
-      default:
-        if (LDS_STATE) {
-          double t[EPL];
-          lds_load(st_rh0, t);
-          pool_store(b, t);
-        } else {
-          pool_store(b, rh0);
-        }
-        break;
-    }
-  }
-  __device__ __forceinline__ void get(int b, Comp c) {
-    switch (c) {
-      case kTh: pool_load(b, th); break;
-      case kRh: pool_load(b, rh); break;
-      default:
-        if (!kNoGrad) pool_load(b, g);
-        break;
-    }
-  }
-
-  // ---- Hamiltonian pieces ------------------------------------------------------------
-  __device__ __forceinline__ double model_eval() {
-    ++n_grad;
-    double part = 0.0;
-    Model::eval(*this, th, g, mp, aux, part);
-    return part;
-  }
-  // joint log density of the moving end: logp_pos + logp_momentum (util.hpp:220-223)
-  __device__ __forceinline__ void energy(double lp_partial, double& logp_pos, double& logp_joint) {
-    double ke = 0.0;
-    with_im([&](const double (&m)[EPL]) {
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) ke += m[j] * (rh[j] * rh[j]);
-    });
-    this->sum2(lp_partial, ke);
-    // wave-uniform results go back to scalar registers: they live long and would otherwise hold VGPR pairs
-    logp_pos = uni(Model::finish(lp_partial, aux, P.dim));
-    logp_joint = uni(logp_pos + (-0.5 * ke));
-  }
-  // n leapfrog micro steps on the VGPR state (walnuts.hpp:328-333); returns the
-  // last evaluation's log-density partial
-  __device__ __forceinline__ double leapfrog(double h, int n) {
-    const double half = 0.5 * h;
-    double part = 0.0;
-    for (int s = 0; s < n; ++s) {
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) rh[j] += half * G(j);
-      with_im([&](const double (&m)[EPL]) {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) th[j] += h * m[j] * rh[j];
-      });
-      part = model_eval();
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) rh[j] += half * G(j);
-    }
-    return part;
-  }
-
-  // walnuts.hpp:218-235 on the VGPR state
-  __device__ __forceinline__ bool within_tolerance(double h, int n, double logp_entry) {
-    const double part = leapfrog(h, n);
-    double lp, lj;
-    energy(part, lp, lj);
-    return fabs(lj - logp_entry) <= max_error;
-  }
-
-  // walnuts.hpp:254-279.  The accepted end state is parked in three pool buffers
-  // while coarser reverse paths are tried from (theta', -rho', grad').
-  __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
-    if (n == 1) return true;
-    const int k0 = this->alloc(), k1 = this->alloc(), k2 = kNoGrad ? -1 : this->alloc();  // short-lived: LDS first
-    pool_store(k0, th);
-    pool_store(k1, rh);
-    if (!kNoGrad) pool_store(k2, g);
-    bool result = true;
-    bool first = true;
-    while (n >= 2 * min_micro) {
-      if (!first) {
-        pool_load(k0, th);
-        if (!kNoGrad) pool_load(k2, g);
-      }
-      first = false;
-      double keep[EPL];
-      pool_load(k1, keep);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) rh[j] = -keep[j];
-      n /= 2;
-      h *= 2;
-      if (within_tolerance(h, n, logp_joint)) {
-        result = false;
-        break;
-      }
-    }
-    pool_load(k0, th);
-    pool_load(k1, rh);
-    if (!kNoGrad) pool_load(k2, g);
-    this->release(k0);
-    this->release(k1);
-    this->release(k2);
-    return result;
-  }
-
-  // the macro step's restart state (walnuts.hpp:324-326)
-  __device__ __forceinline__ void macro_begin() {
-    if (LDS_STATE) {
-      lds_store(st_th0, th);
-      lds_store(st_rh0, rh);
-    } else if (START_REGS) {
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        th0[j] = th[j];
-        rh0[j] = rh[j];
-        if (kKeepRestartGrad) g0[j] = g[j];
-      }
-    } else {
-      pool_store(start_buf[0], th);
-      pool_store(start_buf[1], rh);
-      if (!kNoGrad) pool_store(start_buf[2], g);
-    }
-  }
-  __device__ __forceinline__ void macro_retry() {
-    if (LDS_STATE || START_REGS) {
-      if (LDS_STATE) {
-        lds_load(st_th0, th);
-        lds_load(st_rh0, rh);
-      } else {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-          th[j] = th0[j];
-          rh[j] = rh0[j];
-        }
-      }
-      if (kKeepRestartGrad) {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) g[j] = g0[j];
-      } else if (!kNoGrad) {
-        // the restart gradient is a pure function of the restart position: same bits as the copy the
-        // reference keeps (walnuts.hpp:326), without holding a third vector for the rare retry
-        double unused = 0.0;
-        Model::eval(*this, th, g, mp, aux, unused);
-      }
-    } else {
-      pool_load(start_buf[0], th);
-      pool_load(start_buf[1], rh);
-      if (!kNoGrad) pool_load(start_buf[2], g);
-    }
-  }
-  __device__ __forceinline__ void macro_commit() {}
-
-  // walnuts.hpp:192-201: the VGPR state is the outer end of the newer span; (a, b) = (theta, rho) of
-  // the far end it is tested against.
-  __device__ __forceinline__ bool uturn_vectors(const double (&a)[EPL], const double (&b)[EPL], bool fwd) {
-    double p_hot = 0.0, p_far = 0.0;
-    // a - th == -(th - a) exactly: one subtraction, then a wave-uniform sign flip on the high word
-    const uint64_t flip = fwd ? 0ull : 0x8000000000000000ull;
-    with_im([&](const double (&m)[EPL]) {
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        const double diff = wnd::as_f64(wnd::as_u64(th[j] - a[j]) ^ flip);
-        const double sd = m[j] * diff;
-        p_hot += rh[j] * sd;
-        p_far += b[j] * sd;
-      }
-    });
-    this->sum2(p_hot, p_far);
-    return p_hot < 0 || p_far < 0;
-  }
-  __device__ __forceinline__ bool uturn_start(bool fwd) {
-    if (LDS_STATE) {
-      double a[EPL], b[EPL];
-      lds_load(st_th0, a);
-      lds_load(st_rh0, b);
-      return uturn_vectors(a, b, fwd);
-    }
-    return uturn_vectors(th0, rh0, fwd);
-  }
-  __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
-    double a[EPL], b[EPL];
-    pool_load(bth, a);
-    pool_load(brh, b);
-    return uturn_vectors(a, b, fwd);
-  }
-
-  // load the chain, refresh the momentum (walnuts.hpp:528-529), evaluate the initial point (:532)
-  __device__ __forceinline__ double begin_transition(long long row, bool warm) {
-    vload(P.theta + row, th);
-    if (Model::kUsesParams) vload(P.model_params, mp);
-    double chol[EPL];
-    if (warm) {
-      // adaptive_walnuts.hpp:235-236 with MassEstimator::inv_mass_estimate :89-94
-      const double wd = w_draw0, ws = w_score0;
-      double ds[EPL], ss[EPL];
-      vload(P.est_draw_ssd + row, ds);
-      vload(P.est_score_ssd + row, ss);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        im[j] = __builtin_sqrt((ds[j] / wd) / (ss[j] / ws));
-        chol[j] = __builtin_sqrt(1.0 / im[j]);
-      }
-    } else {
-      vload(P.inv_mass + row, im);
-      vload(P.chol_mass + row, chol);  // 1/sqrt(inv_mass), walnuts.hpp:647, computed once at freeze
-    }
-    if (P.rng_mode == kRngBuffer) {
-      double z[EPL];
-      vload(P.z_buf + row, z);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) rh[j] = chol[j] * z[j];
-    } else {
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        double z0, z1;
-        const uint32_t pair = static_cast<uint32_t>(k * L + tid);
-        wnd::stream_normal_pair(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamMomentum, pair, z0, z1);
-        rh[2 * k] = valid(2 * k) ? chol[2 * k] * z0 : 0.0;
-        rh[2 * k + 1] = valid(2 * k + 1) ? chol[2 * k + 1] * z1 : 0.0;
-      }
-    }
-    if (LDS_STATE) lds_store(st_im, im);
-    if (!START_REGS && !LDS_STATE) {
-      start_buf[0] = this->alloc_cold();
-      start_buf[1] = this->alloc_cold();
-      start_buf[2] = this->alloc_cold();
-    }
-    return model_eval();
-  }
-
-  __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
-    pool_load(a_sel, th);
-    vstore(P.theta + row, th);
-    if (P.draws_out != nullptr) {
-      double* out = P.draws_out + static_cast<long long>(chain) * P.draws_stride;
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        if (valid(j)) out[index(j)] = th[j];
-      }
-    }
-    if (warm) {
-      // adaptive_walnuts.hpp:247-248: observe (theta_sel, grad_sel).  grad_sel is a pure
-      // function of theta_sel, so it is re-evaluated instead of being carried through the tree.
-      const long long keep_grad = n_grad;
-      (void)model_eval();
-      n_grad = keep_grad;
-      const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(P.warmup_iter));
-      const double wd = discount * w_draw0 + 1;
-      const double ws = discount * w_score0 + 1;
-      double mean[EPL], ssd[EPL];
-      vload(P.est_draw_mean + row, mean);
-      vload(P.est_draw_ssd + row, ssd);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {  // online_moments.hpp:184-191 (lazy delta => (y - mean_new)^2)
-        mean[j] += (th[j] - mean[j]) / wd;
-        ssd[j] = discount * ssd[j] + (th[j] - mean[j]) * (th[j] - mean[j]);
-      }
-      vstore(P.est_draw_mean + row, mean);
-      vstore(P.est_draw_ssd + row, ssd);
-      vload(P.est_score_mean + row, mean);
-      vload(P.est_score_ssd + row, ssd);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        mean[j] += (G(j) - mean[j]) / ws;
-        ssd[j] = discount * ssd[j] + (G(j) - mean[j]) * (G(j) - mean[j]);
-      }
-      vstore(P.est_score_mean + row, mean);
-      vstore(P.est_score_ssd + row, ssd);
-    }
   }
 };
 
@@ -1493,7 +1188,7 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   WN_DYN_SMEM(smem);
   // layout: [lds_state * Dp] state vectors | [pool_lds * Dp] pool vectors | per-wave Meta | reduction scratch |
   // broadcast word
-  WN_LDS double* pool = (WN_LDS double*)smem + P.lds_state * P.dim_padded;
+  WN_LDS double* pool = (WN_LDS double*)smem;
   WN_LDS double* tail = pool + P.pool_lds * P.dim_padded;
   WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(tail + (threadIdx.x >> 6) * kMetaDoubles);
   WN_LDS double* red = tail + NW * kMetaDoubles;
@@ -1526,32 +1221,10 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
 #endif
 }
 
-// Without a gradient vector (standard / diagonal normal) the 8-elements-per-lane kernels are built for three wavefronts per SIMD:
-// the 31 VGPRs that spill to scratch cost less than the third wave hides (measured: 2.95 -> 2.55 ms per step on the
-// headline workload with 6 chains per CU).
-template <class Model, int EPL>
-constexpr int min_waves_per_simd() {
-  return (Model::kCheapGrad && EPL == 8) ? 3 : 1;
-}
-template <class Model, int NW, int EPL, bool START_REGS>
-__global__ __launch_bounds__(64 * NW, (min_waves_per_simd<Model, EPL>())) void transition_kernel(const Params P) {
-  persistent_loop<TrajReg<Model, NW, EPL, START_REGS>, NW>(P);
-}
-
-// the LDS_STATE variant: register budget for WPE wavefronts per SIMD
-template <class Model, int NW, int EPL, int WPE>
-__global__ __launch_bounds__(64 * NW, WPE) void transition_kernel_lds(const Params P) {
-  persistent_loop<TrajReg<Model, NW, EPL, true, true>, NW>(P);
-}
-
 template <class Model, int NW>
 __global__ __launch_bounds__(64 * NW) void transition_kernel_mem(const Params P) {
   persistent_loop<TrajMem<Model, NW>, NW>(P);
 }
-
-// kept as an alias: the init kernels build on the register backend
-template <class Model, int NW, int EPL, bool START_REGS>
-using Traj = TrajReg<Model, NW, EPL, START_REGS>;
 
 inline size_t transition_smem_bytes(int nw, int lds_vectors, int dim_padded) {
   return (static_cast<size_t>(lds_vectors) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + kRedDoubles(nw) + 2) *

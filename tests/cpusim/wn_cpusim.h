@@ -7,6 +7,7 @@
 // build: device parity is established by the `-m gpu` tests only.
 #pragma once
 
+#include <algorithm>
 #include <atomic>
 #include <barrier>
 #include <chrono>
@@ -40,21 +41,25 @@ namespace wnsim {
 struct Block {
   unsigned nthreads = 0;
   std::unique_ptr<std::barrier<>> bar;
+  std::vector<std::unique_ptr<std::barrier<>>> wave_bar;  // cross-lane operations are wavefront-scoped
   std::vector<uint64_t> xchg;
   double* smem = nullptr;
 };
 inline thread_local Block* blk = nullptr;
 inline thread_local dim3 tidx, bidx, gdim, bdim;
 inline void sync() { blk->bar->arrive_and_wait(); }
+inline void wave_sync() { blk->wave_bar[tidx.x >> 6]->arrive_and_wait(); }
+// a cross-lane move inside one wavefront (only that wavefront's lanes need to arrive: one wavefront of a
+// workgroup may run scalar work the others skip)
 template <class T>
 T exchange(T v, unsigned src_tid) {
   static_assert(sizeof(T) <= 8, "exchange moves at most 8 bytes");
   uint64_t raw = 0;
   std::memcpy(&raw, &v, sizeof(T));
   blk->xchg[tidx.x] = raw;
-  sync();
+  wave_sync();
   const uint64_t r = blk->xchg[src_tid];
-  sync();
+  wave_sync();
   T out;
   std::memcpy(&out, &r, sizeof(T));
   return out;
@@ -72,6 +77,8 @@ void launch(K kernel, dim3 grid, dim3 block, size_t smem_bytes, A... args) {
     B.nthreads = block.x;
     B.bar = std::make_unique<std::barrier<>>(static_cast<std::ptrdiff_t>(block.x));
     B.xchg.assign(block.x, 0);
+    for (unsigned w = 0; w * 64 < block.x; ++w)
+      B.wave_bar.push_back(std::make_unique<std::barrier<>>(static_cast<std::ptrdiff_t>(std::min(64u, block.x - w * 64))));
     const size_t bytes = ((smem_bytes + 63) / 64 + 1) * 64;
     B.smem = static_cast<double*>(std::aligned_alloc(64, bytes));
     std::memset(B.smem, 0xCD, bytes);

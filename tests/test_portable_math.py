@@ -66,13 +66,13 @@ def test_exp_log_bitwise_equal_to_oracle_copy_and_close_to_libm(shim, oracle):
         a, b = shim.p_exp(x), L.wno_math_exp(x)
         assert a == b or (np.isnan(a) and np.isnan(b))
         ref = np.exp(x)
-        assert abs(a - ref) <= 1.0 * np.spacing(ref) or ref == 0.0
+        assert abs(a - ref) <= 2.0 * np.spacing(ref) or ref == 0.0   # table-driven exp: within 2 ulp of libm
     ys = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0.5, 2.0, 20000), [1.0, 5e-324, 1e308]])
     for y in ys:
         a, b = shim.p_log(y), L.wno_math_log(y)
         assert a == b
         ref = np.log(y)
-        assert abs(a - ref) <= 1.0 * np.spacing(abs(ref)) + 1e-320
+        assert abs(a - ref) <= 2.0 * np.spacing(abs(ref)) + 1e-320   # table-driven log: within 2 ulp of libm
     assert shim.p_exp(0.0) == 1.0 and shim.p_log(1.0) == 0.0
     assert shim.p_log(0.0) == -np.inf and np.isnan(shim.p_log(-1.0)) and shim.p_exp(1000.0) == np.inf
     assert shim.p_pow(49.0, 0.5) == 7.0 and shim.p_pow(3.0, 0.0) == 1.0

@@ -63,6 +63,16 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
 
   double th[2][EPL], rh[2][EPL], g[2][EPL];  // the two sets of the moving end (g is dead when kNoGrad)
   double im[EPL], mp[EPL];                    // inverse mass diagonal, model parameters
+  // The accumulated span's other end.  When the gradient is recomputed from theta (kNoGrad) the pair (theta, rho)
+  // has registers of its own instead of two pool buffers: the top-level U-turn test reads it in place, turning
+  // around is a register swap, and the pool's LDS vectors all serve the span stack.
+#if defined(WN_NO_OTHER_REGS)
+  static constexpr bool kOtherRegs = false;
+#else
+  static constexpr bool kOtherRegs = kNoGrad;
+#endif
+  static constexpr int kOther = -4;           // "this vector is the other end's theta" (kOtherRegs)
+  double oth[EPL], orh[EPL];
   typename RegColumn<RA>::type bank_a[EPL];   // register tier of the span pool: element j of slot k is bank_a[j][k]
   typename RegColumn<RB>::type bank_b[EPL];
   int n_lds, n_reg;                           // pool buffers [0, n_lds) live in LDS, [n_lds, n_lds + n_reg) in the banks
@@ -101,6 +111,33 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       t[1] = v[2 * k + 1];
       *reinterpret_cast<v2f64*>(base + (k * L + tid) * 2) = t;
     }
+  }
+  // the chain's own planes are read once and written once per transition: streamed past the L2 (nt) so that they
+  // do not evict the arena vectors a deep tree spills there
+  __device__ __forceinline__ void vload_stream(const double* base, double (&v)[EPL]) const {
+#if defined(WN_CPU_SIM)
+    vload(base, v);
+#else
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const v2f64 t = __builtin_nontemporal_load(reinterpret_cast<const v2f64*>(base + (k * L + tid) * 2));
+      v[2 * k] = t[0];
+      v[2 * k + 1] = t[1];
+    }
+#endif
+  }
+  __device__ __forceinline__ void vstore_stream(double* base, const double (&v)[EPL]) const {
+#if defined(WN_CPU_SIM)
+    vstore(base, v);
+#else
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      v2f64 t;
+      t[0] = v[2 * k];
+      t[1] = v[2 * k + 1];
+      __builtin_nontemporal_store(t, reinterpret_cast<v2f64*>(base + (k * L + tid) * 2));
+    }
+#endif
   }
   __device__ __forceinline__ void lds_load(const WN_LDS double* base, double (&v)[EPL]) const {
 #pragma unroll
@@ -308,7 +345,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       finish_energy(part, ke, logp_pos, logp_joint);
       if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
         // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
-        if (P.warmup && wave == 0) this->adam_observe(wnd::dexp(-fabs(logp_start - logp_joint)));
+        if (P.warmup && wave == 0) this->adam_observe(wnd::dexp(-fabs(logp_start - logp_joint), this->uniform_tab()));
       }
       WN_PHASE(kPhRestart);
       if (fabs(logp_start - logp_joint) <= max_error) {
@@ -359,14 +396,28 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       this->sum2(part, ke);
       finish_energy(part, ke, lp_pos, lj);
     }
+    this->prefetch_next_chain();
     kill_register_pool();
     // The accumulated span (walnuts.hpp:34-131) is: the moving end (set 0), the other end parked in the pool,
     // the selected position and three scalars.  Both ends are the initial point to begin with.
-    int o_th = this->alloc_cold(), o_rh = this->alloc_cold(), o_g = kNoGrad ? -1 : this->alloc_cold();
-    pool_store(o_th, th[0]);
-    pool_store(o_rh, rh[0]);
-    if (!kNoGrad) pool_store(o_g, g[0]);
-    int a_sel = o_th;
+    int o_th = -1, o_rh = -1, o_g = -1;
+    int a_sel;
+    if (kOtherRegs) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        oth[j] = th[0][j];
+        orh[j] = rh[0][j];
+      }
+      a_sel = kOther;
+    } else {
+      o_th = this->alloc_cold();
+      o_rh = this->alloc_cold();
+      o_g = kNoGrad ? -1 : this->alloc_cold();
+      pool_store(o_th, th[0]);
+      pool_store(o_rh, rh[0]);
+      if (!kNoGrad) pool_store(o_g, g[0]);
+      a_sel = o_th;
+    }
     double lj_hot = lj, lj_other = lj, a_logsum = lj, a_lpsel = lp_pos;
     bool both = true, hot_fw = true;
 
@@ -379,18 +430,34 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
         both = false;
       } else if (fwd != hot_fw) {
         // the walk turns around: the moving end and the parked end change places
-        double a[EPL], b[EPL];
-        pool_load(o_th, a);
-        pool_load(o_rh, b);
-        if (o_th == a_sel) o_th = this->alloc_cold();  // the selected position keeps its buffer
-        pool_store(o_th, th[0]);
-        pool_store(o_rh, rh[0]);
+        if (kOtherRegs) {
+          if (a_sel == kOther) {  // the selected position was the other end's: it gets a buffer of its own
+            a_sel = this->alloc_cold();
+            pool_store(a_sel, oth);
+          }
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-          th[0][j] = a[j];
-          rh[0][j] = b[j];
+          for (int j = 0; j < EPL; ++j) {
+            const double t0 = th[0][j], t1 = rh[0][j];
+            th[0][j] = oth[j];
+            rh[0][j] = orh[j];
+            oth[j] = t0;
+            orh[j] = t1;
+          }
+        } else {
+          double a[EPL], b[EPL];
+          pool_load(o_th, a);
+          pool_load(o_rh, b);
+          if (o_th == a_sel) o_th = this->alloc_cold();  // the selected position keeps its buffer
+          pool_store(o_th, th[0]);
+          pool_store(o_rh, rh[0]);
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) {
+            th[0][j] = a[j];
+            rh[0][j] = b[j];
+          }
         }
         if (!kNoGrad) {
+          double a[EPL];
           pool_load(o_g, a);
           pool_store(o_g, g[0]);
 #pragma unroll
@@ -442,7 +509,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
           // level-0 merge, combine<Barker> (walnuts.hpp:370-386): old = the even leaf (set 1), new = the odd leaf (set 0)
           WN_PHASE(kPhCombine);
           {
-            const double total = uni(log_sum_exp(e_lj, leaf_lj));
+            const double total = uni(log_sum_exp(e_lj, leaf_lj, this->uniform_tab()));
             if (pair_turned) {  // walnuts.hpp:490-492
               ok = false;
               break;
@@ -506,10 +573,17 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       double total;
       if (nleaf == 1) {
         turned = top_turned;
-        total = uni(log_sum_exp(a_logsum, c_logsum));
+        total = uni(log_sum_exp(a_logsum, c_logsum, this->uniform_tab()));
       } else {
         this->lse_on_leader(a_logsum, c_logsum);
-        turned = uturn_pool(o_th, o_rh, fwd);
+        if (kOtherRegs) {
+          double p_hot, p_far;
+          uturn_partials<0>(oth, orh, fwd, p_hot, p_far);
+          this->sum2(p_hot, p_far);
+          turned = p_hot < 0 || p_far < 0;
+        } else {
+          turned = uturn_pool(o_th, o_rh, fwd);
+        }
         total = uni(carry);
       }
       const bool update = this->log_uniform01() < c_logsum - a_logsum;  // Metropolis
@@ -518,7 +592,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       this->release_unless(c_in_rh, -3, -3, -3);
       if (update) {
         c_sel = materialize(c_sel, false);
-        if (a_sel != o_th) this->release(a_sel);
+        if (a_sel != o_th) this->release(a_sel);  // (release ignores the symbolic kOther)
         a_sel = c_sel;
         a_lpsel = c_lpsel;
       } else {
@@ -539,27 +613,27 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
   // load the chain, refresh the momentum (walnuts.hpp:528-529), evaluate the initial point (:532)
   __device__ __forceinline__ double begin_transition(long long row, bool warm) {
     const auto& Q = this->cold();
-    vload(Q.theta + row, th[0]);
+    vload_stream(Q.theta + row, th[0]);
     if (Model::kUsesParams) vload(Q.model_params, mp);
     double chol[EPL];
     if (warm) {
       // adaptive_walnuts.hpp:235-236 with MassEstimator::inv_mass_estimate :89-94
       const double wd = w_draw0, ws = w_score0;
       double ds[EPL], ss[EPL];
-      vload(Q.est_draw_ssd + row, ds);
-      vload(Q.est_score_ssd + row, ss);
+      vload_stream(Q.est_draw_ssd + row, ds);
+      vload_stream(Q.est_score_ssd + row, ss);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
         im[j] = __builtin_sqrt((ds[j] / wd) / (ss[j] / ws));
         chol[j] = __builtin_sqrt(1.0 / im[j]);
       }
     } else {
-      vload(Q.inv_mass + row, im);
-      vload(Q.chol_mass + row, chol);  // 1/sqrt(inv_mass), walnuts.hpp:647, computed once at freeze
+      vload_stream(Q.inv_mass + row, im);
+      vload_stream(Q.chol_mass + row, chol);  // 1/sqrt(inv_mass), walnuts.hpp:647, computed once at freeze
     }
     if (Q.rng_mode == kRngBuffer) {
       double z[EPL];
-      vload(Q.z_buf + row, z);
+      vload_stream(Q.z_buf + row, z);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) rh[0][j] = chol[j] * z[j];
     } else {
@@ -569,7 +643,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       for (int k = 0; k < NP; ++k) {
         double z0, z1;
         const uint32_t pair = static_cast<uint32_t>(k * L + tid);
-        wnd::stream_normal_pair(seed, key_chain, key_tr, wnd::kStreamMomentum, pair, z0, z1);
+        wnd::stream_normal_pair(seed, key_chain, key_tr, wnd::kStreamMomentum, pair, z0, z1, this->gather_tab());
         rh[0][2 * k] = valid(2 * k) ? chol[2 * k] * z0 : 0.0;
         rh[0][2 * k + 1] = valid(2 * k + 1) ? chol[2 * k + 1] * z1 : 0.0;
       }
@@ -579,14 +653,23 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
 
   __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
     const auto& Q = this->cold();
-    pool_load(a_sel, th[0]);
-    vstore(Q.theta + row, th[0]);
+    if (kOtherRegs && a_sel == kOther) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) th[0][j] = oth[j];
+    } else {
+      pool_load(a_sel, th[0]);
+    }
+    vstore_stream(Q.theta + row, th[0]);
     double* draws = Q.draws_out;
     if (draws != nullptr) {
       double* out = draws + static_cast<long long>(chain) * Q.draws_stride;
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
+#if defined(WN_CPU_SIM)
         if (valid(j)) out[index(j)] = th[0][j];
+#else
+        if (valid(j)) __builtin_nontemporal_store(th[0][j], &out[index(j)]);
+#endif
       }
     }
     if (warm) {
@@ -599,24 +682,24 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       const double wd = discount * w_draw0 + 1;
       const double ws = discount * w_score0 + 1;
       double mean[EPL], ssd[EPL];
-      vload(Q.est_draw_mean + row, mean);
-      vload(Q.est_draw_ssd + row, ssd);
+      vload_stream(Q.est_draw_mean + row, mean);
+      vload_stream(Q.est_draw_ssd + row, ssd);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {  // online_moments.hpp:184-191 (lazy delta => (y - mean_new)^2)
         mean[j] += (th[0][j] - mean[j]) / wd;
         ssd[j] = discount * ssd[j] + (th[0][j] - mean[j]) * (th[0][j] - mean[j]);
       }
-      vstore(Q.est_draw_mean + row, mean);
-      vstore(Q.est_draw_ssd + row, ssd);
-      vload(Q.est_score_mean + row, mean);
-      vload(Q.est_score_ssd + row, ssd);
+      vstore_stream(Q.est_draw_mean + row, mean);
+      vstore_stream(Q.est_draw_ssd + row, ssd);
+      vload_stream(Q.est_score_mean + row, mean);
+      vload_stream(Q.est_score_ssd + row, ssd);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
         mean[j] += (G<0>(j) - mean[j]) / ws;
         ssd[j] = discount * ssd[j] + (G<0>(j) - mean[j]) * (G<0>(j) - mean[j]);
       }
-      vstore(Q.est_score_mean + row, mean);
-      vstore(Q.est_score_ssd + row, ssd);
+      vstore_stream(Q.est_score_mean + row, mean);
+      vstore_stream(Q.est_score_ssd + row, ssd);
     }
   }
 };

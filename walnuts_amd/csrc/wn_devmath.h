@@ -8,11 +8,14 @@
 // with -ffp-contract=off, which makes every result reproducible bit for bit on
 // the host: that is what lets tests/ compare whole trajectories exactly.
 //
-// Polynomial schemes and coefficients: Sun fdlibm 5.3 (exp, log, sin/cos
-// kernels).  Generator: Philox4x32-10 (Salmon et al., SC'11).
+// exp / log: table-driven schemes written for short dependency chains (below).
+// sin/cos kernels: Sun fdlibm 5.3 polynomial schemes and coefficients.
+// Generator: Philox4x32-10 (Salmon et al., SC'11).
 #pragma once
 
 #include <stdint.h>
+
+#include "wn_math_tables.h"
 
 #if defined(__HIPCC__) && !defined(WN_CPU_SIM)
 #include <hip/hip_runtime.h>
@@ -46,74 +49,108 @@ WND_HD double as_f64(uint64_t u) {
 
 WND_HD double two_to(int k) { return as_f64(static_cast<uint64_t>(k + 1023) << 52); }
 
-WND_HD double dexp(double x) {
-  constexpr double kLn2Hi = 6.93147180369123816490e-01;
-  constexpr double kLn2Lo = 1.90821492927058770002e-10;
-  constexpr double kInvLn2 = 1.44269504088896338700e+00;
-  if (x != x) return x;
-  if (x > 7.09782712893383973096e+02) return __builtin_inf();
-  if (x < -7.45133219101941108420e+02) return 0.0;
-  const double kf = __builtin_floor(x * kInvLn2 + 0.5);
+// ---------------------------------------------------------------------------
+// exp and log: table-driven, division-free, short dependency chains.
+//
+// On the device these run on wave-uniform values in the middle of the tree loop (log_sum_exp at every merge,
+// util.hpp:174-183; the Barker / Metropolis comparisons; Adam), where one wavefront's dependent fp64 chain is
+// exposed latency: measured on MI355X, log_sum_exp built on the fdlibm schemes (two divisions, Horner chains,
+// ~75 dependent operations) was 17 % of the headline step time.  Here: 64-entry 2^(j/64) table + degree-5
+// polynomial for exp, 49-entry (1/c, log c) table + degree-8 polynomial for log, Estrin-style grouping --
+// about 35 dependent operations for log_sum_exp.  Every step is a plain binary64 +,-,* or an integer
+// operation, so the host reproduces the bits (oracle/wn_oracle_math.h holds the checker's own copy).
+// Accuracy against libm: within 2 ulp (tests/test_portable_math.py).
+//
+// `Tab` supplies the table entries: exp2(j), rcp(i), logc(i) (wn_math_tables.h on the host, VGPR lanes on the
+// device -- see wn_traj.h LaneTables).
+// ---------------------------------------------------------------------------
+// Both functions evaluate the main path for every lane (arguments outside the domain are clamped first) and patch
+// the special values in at the end: the table look-up of a per-lane call is a cross-lane gather, which every lane
+// of the wavefront has to take part in.
+template <class Tab>
+WND_HD double dexp(double x, const Tab& tab) {
+  constexpr double kInvStep = 9.23324826168936567e+01;   // 64 / ln 2
+  constexpr double kStepHi = 1.08304246095940471e-02;    // ln 2 / 64, upper 28 bits (k * kStepHi is exact)
+  constexpr double kStepLo = 8.66550983900947049e-11;
+  constexpr double kOver = 7.09782712893383973096e+02, kUnder = -7.45133219101941108420e+02;
+  const double xc = (x != x) ? 0.0 : (x > kOver ? kOver : (x < kUnder ? kUnder : x));
+  const double kf = __builtin_floor(xc * kInvStep + 0.5);
   const int k = static_cast<int>(kf);
-  const double hi = x - kf * kLn2Hi;
-  const double lo = kf * kLn2Lo;
-  const double r = hi - lo;
-  const double t = r * r;
-  double p = 4.13813679705723846039e-08;
-  p = -1.65339022054652515390e-06 + t * p;
-  p = 6.61375632143793436117e-05 + t * p;
-  p = -2.77777777770155933842e-03 + t * p;
-  p = 1.66666666666666019037e-01 + t * p;
-  const double c = r - t * p;
-  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-  if (k == 0) return y;
-  const int ka = k / 2;
-  const int kb = k - ka;
-  return (y * two_to(ka)) * two_to(kb);
+  const double r = (xc - kf * kStepHi) - kf * kStepLo;   // |r| <= ln2/128
+  const double t = tab.exp2(k & 63);
+  const int e = k >> 6;
+  const double r2 = r * r;
+  // exp(r) - 1 = r + r^2/2 + r^3/6 + r^4/24 + r^5/120   (r^6/720 < 4e-17)
+  const double lo = 0.5 + r * 1.66666666666666657e-01;
+  const double hi = 4.16666666666666644e-02 + r * 8.33333333333333322e-03;
+  const double p = r + r2 * (lo + r2 * hi);
+  double y = t + t * p;
+  const int ea = e / 2;
+  const int eb = e - ea;
+  if (e != 0) y = (y * two_to(ea)) * two_to(eb);
+  if (x > kOver) y = __builtin_inf();
+  if (x < kUnder) y = 0.0;
+  if (x != x) y = x;
+  return y;
 }
 
-WND_HD double dlog(double x) {
+template <class Tab>
+WND_HD double dlog(double x, const Tab& tab) {
   constexpr double kLn2Hi = 6.93147180369123816490e-01;
   constexpr double kLn2Lo = 1.90821492927058770002e-10;
-  if (x != x) return x;
-  if (x < 0.0) return __builtin_nan("");
-  if (x == 0.0) return -__builtin_inf();
-  if (x == __builtin_inf()) return x;
-  int k = 0;
   uint64_t bits = as_u64(x);
-  if ((bits >> 52) == 0) {
-    x = x * 18014398509481984.0;  // 2^54
-    bits = as_u64(x);
-    k = -54;
-  }
-  k += static_cast<int>(bits >> 52) - 1023;
+  const bool tiny = ((bits >> 52) & 0x7ff) == 0;    // subnormal (or zero): scale by 2^54
+  if (tiny) bits = as_u64(x * 18014398509481984.0);
+  int k = (tiny ? -54 : 0) + (static_cast<int>((bits >> 52) & 0x7ff) - 1023);
   const uint64_t frac = bits & 0x000fffffffffffffULL;
-  if (frac >= 0x6a09e667f3bcdULL) {
-    k += 1;
-    x = as_f64(frac | (static_cast<uint64_t>(1022) << 52));
-  } else {
-    x = as_f64(frac | (static_cast<uint64_t>(1023) << 52));
-  }
-  const double f = x - 1.0;
-  const double s = f / (2.0 + f);
-  const double z = s * s;
-  const double w = z * z;
-  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-  const double t2 =
-      z * (6.666666666666735130e-01 +
-           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
-  const double R = t2 + t1;
-  const double hfsq = 0.5 * f * f;
+  // s in [0.75, 1.5): the mantissa, halved when it is 1.5 or more
+  const bool upper = frac >= 0x0008000000000000ULL;
+  k += upper ? 1 : 0;
+  const double s = as_f64(frac | (static_cast<uint64_t>(upper ? 1022 : 1023) << 52));
+  // nearest multiple of 1/64: c = i/64, 48 <= i <= 96; s - c is exact, |s - c| <= 1/128
+  const int i = static_cast<int>(s * 64.0 + 0.5);
+  const double c = static_cast<double>(i) * 0.015625;
+  const double u = (s - c) * tab.rcp(i - 48);
+  const double lc = tab.logc(i - 48);
+  // log(1 + u) = u - u^2 (1/2 - u/3 + u^2/4 - u^3/5 + u^4/6 - u^5/7 + u^6/8),  |u| < 0.0105
+  const double q = u * u;
+  const double a0 = 0.5 - u * 3.33333333333333315e-01;
+  const double a1 = 0.25 - u * 2.00000000000000011e-01;
+  const double a2 = 1.66666666666666657e-01 - u * 1.42857142857142849e-01;
+  const double q2 = q * q;
+  const double pl = (a0 + q * a1) + q2 * (a2 + q * 0.125);
+  const double l1 = u - q * pl;
   const double dk = static_cast<double>(k);
-  return dk * kLn2Hi - ((hfsq - (s * (hfsq + R) + dk * kLn2Lo)) - f);
+  double y = (dk * kLn2Hi + lc) + (l1 + dk * kLn2Lo);
+  if (x == __builtin_inf()) y = x;
+  if (x == 0.0) y = -__builtin_inf();
+  if (x < 0.0) y = __builtin_nan("");
+  if (x != x) y = x;
+  return y;
 }
+
+// the tables as plain arrays (host: tests, engine set-up; device: constant memory for the rarely used call sites)
+struct ArrayTables {
+  const unsigned long long* e2;
+  const unsigned long long* rc;
+  const unsigned long long* lc;
+  WND_HD double exp2(int j) const { return as_f64(e2[j]); }
+  WND_HD double rcp(int i) const { return as_f64(rc[i]); }
+  WND_HD double logc(int i) const { return as_f64(lc[i]); }
+};
+
+WND_HD ArrayTables array_tables() { return ArrayTables{wn_tab_exp2_bits, wn_tab_rcp_bits, wn_tab_logc_bits}; }
+// forms that read the tables from memory: host code and the element-wise set-up kernels
+WND_HD double dexp(double x) { return dexp(x, array_tables()); }
+WND_HD double dlog(double x) { return dlog(x, array_tables()); }
 
 // x^y for x > 0; the path's only use is Adam's t^decay (adam.hpp:83)
-WND_HD double dpow_pos(double x, double y) {
+template <class Tab>
+WND_HD double dpow_pos(double x, double y, const Tab& tab) {
   if (y == 0.0) return 1.0;
   if (y == 1.0) return x;
   if (y == 0.5) return __builtin_sqrt(x);
-  return dexp(y * dlog(x));
+  return dexp(y * dlog(x, tab), tab);
 }
 
 // sin(pi a), cos(pi a), a in [0, 2)
@@ -169,6 +206,8 @@ WND_HD U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0
 
 enum : uint32_t { kStreamMomentum = 0, kStreamTree = 1, kStreamInitPos = 2, kStreamInitStep = 3 };
 
+WND_HD double dpow_pos(double x, double y) { return dpow_pos(x, y, array_tables()); }
+
 // 64 bits -> open-interval uniform, exact in binary64
 WND_HD double open01(uint32_t lo, uint32_t hi) {
   const uint64_t v = (static_cast<uint64_t>(hi) << 32) | lo;
@@ -182,16 +221,26 @@ WND_HD double stream_uniform(uint64_t seed, uint32_t chain, uint32_t transition,
 }
 
 // standard normals for vector elements (2*pair, 2*pair+1): Box-Muller
+template <class Tab>
 WND_HD void stream_normal_pair(uint64_t seed, uint32_t chain, uint32_t transition, uint32_t stream, uint32_t pair,
-                               double& z0, double& z1) {
+                               double& z0, double& z1, const Tab& tab) {
   const U4 o = philox(pair, transition, chain, stream, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
   const double u1 = open01(o.x, o.y);
   const double u2 = open01(o.z, o.w);
-  const double rad = __builtin_sqrt(-2.0 * dlog(u1));
+#if defined(WN_ABLATE_BM)
+  z0 = (u1 - 0.5) * 3.4641016151377544;
+  z1 = (u2 - 0.5) * 3.4641016151377544;
+  return;
+#endif
+  const double rad = __builtin_sqrt(-2.0 * dlog(u1, tab));
   double sn, cs;
   dsincospi(2.0 * u2, sn, cs);
   z0 = rad * cs;
   z1 = rad * sn;
+}
+WND_HD void stream_normal_pair(uint64_t seed, uint32_t chain, uint32_t transition, uint32_t stream, uint32_t pair,
+                               double& z0, double& z1) {
+  stream_normal_pair(seed, chain, transition, stream, pair, z0, z1, array_tables());
 }
 
 }  // namespace wnd

@@ -116,14 +116,38 @@ __device__ __forceinline__ double lane_value(double v, int src_lane) {
 }
 #endif
 
+// The exp / log tables (wn_devmath.h) as one entry per lane of three VGPR pairs.  A wave-uniform argument looks its
+// entries up with v_readlane (a few cycles, no memory), per-lane arguments with a lane gather.
+struct LaneTables {
+  double e2, rc, lc;
+  __device__ __forceinline__ void load(int lane) {
+    e2 = wnd::as_f64(wn_tab_exp2_bits[lane & 63]);
+    rc = wnd::as_f64(wn_tab_rcp_bits[lane < 49 ? lane : 48]);
+    lc = wnd::as_f64(wn_tab_logc_bits[lane < 49 ? lane : 48]);
+  }
+};
+struct UniformTab {  // the argument is the same in every lane
+  const LaneTables& t;
+  __device__ __forceinline__ double exp2(int j) const { return lane_value(t.e2, j); }
+  __device__ __forceinline__ double rcp(int i) const { return lane_value(t.rc, i); }
+  __device__ __forceinline__ double logc(int i) const { return lane_value(t.lc, i); }
+};
+struct GatherTab {  // every lane has its own argument
+  const LaneTables& t;
+  __device__ __forceinline__ double exp2(int j) const { return __shfl(t.e2, j, 64); }
+  __device__ __forceinline__ double rcp(int i) const { return __shfl(t.rc, i, 64); }
+  __device__ __forceinline__ double logc(int i) const { return __shfl(t.lc, i, 64); }
+};
+
 // util.hpp:174-183.  One of exp(x1-m), exp(x2-m) is exp(0) == 1 exactly, so only the other one is
 // evaluated; the sum is commutative, hence the same bits as the two-exp form.
-__device__ __forceinline__ double log_sum_exp(double x1, double x2) {
+template <class Tab>
+__device__ __forceinline__ double log_sum_exp(double x1, double x2, const Tab& tab) {
   const double m = fmax(x1, x2);
   if (x1 != x1 || x2 != x2) return __builtin_nan("");
   if (__builtin_isinf(m) || (x1 + x2) != (x1 + x2)) return fmax(x1, x2);
   const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
-  return m + wnd::dlog(1.0 + wnd::dexp(d));
+  return m + wnd::dlog(1.0 + wnd::dexp(d, tab), tab);
 }
 
 // ---- target densities (device form of the LogpGrad contract, concepts.hpp:258-262) ----
@@ -205,7 +229,7 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
 #pragma unroll
     for (int j = 0; j < EPL; ++j) sp += (cx.index(j) == 0) ? 0.0 : th[j] * th[j];
     const double S = cx.sum1(sp);
-    const double ev = wnd::dexp(-v);
+    const double ev = wnd::dexp(-v, cx.uniform_tab());
     const double hd = 0.5 * static_cast<double>(cx.dim() - 1);
     const double hev = 0.5 * ev;
 #pragma unroll
@@ -296,6 +320,9 @@ struct TrajBase {
   double w_draw0, w_score0;  // estimator weights at entry (read once: another wave's lane 0 rewrites them at exit)
   int min_micro;
   typename Model::Aux aux;
+  LaneTables tabs;
+  __device__ __forceinline__ UniformTab uniform_tab() const { return UniformTab{tabs}; }
+  __device__ __forceinline__ GatherTab gather_tab() const { return GatherTab{tabs}; }
 
   __device__ __forceinline__ Self& self() { return *static_cast<Self*>(this); }
 
@@ -327,6 +354,7 @@ struct TrajBase {
     carry = 0.0;
     carry_armed = false;
     onchip_mask = ~0ull;
+    tabs.load(lane);
   }
 
 #if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
@@ -361,6 +389,15 @@ struct TrajBase {
     const double v = bcast[0];
     __syncthreads();
     return v;
+  }
+
+  // The fetch of the workgroup's NEXT chain from the shared counter is issued here, once the current chain's own
+  // loads have been consumed (memory operations retire in order: issued any earlier, the atomic's 1-2 us round trip
+  // would stand in front of them), and is collected by persistent_loop after the transition.
+  int fetched;
+  __device__ __forceinline__ void prefetch_next_chain() {
+    fetched = 0;
+    if (tid == 0) fetched = static_cast<int>(atomicAdd(P.work_counter, 1u) + gridDim.x);
   }
 
   // Re-derive the lane identity behind an optimisation barrier.  Everything computed from it (addresses, padding
@@ -467,7 +504,7 @@ struct TrajBase {
   // wavefront 0 evaluates it, BEFORE the test, and the value travels to the other wavefronts of the chain in the LDS
   // exchange the test's reduction does anyway -- their SIMDs run other chains' waves meanwhile.
   __device__ __forceinline__ void lse_on_leader(double x1, double x2) {
-    if (NW == 1 || wave == 0) carry = log_sum_exp(x1, x2);
+    if (NW == 1 || wave == 0) carry = log_sum_exp(x1, x2, uniform_tab());
     carry_armed = NW > 1;
   }
   __device__ __forceinline__ double sum1(double a) {
@@ -537,9 +574,10 @@ struct TrajBase {
       u = wnd::stream_uniform(Q.seed, Q.chain_offset + chain, Q.transition, wnd::kStreamTree,
                               static_cast<uint32_t>(j));
     }
+    const double lu = wnd::dlog(u, gather_tab());  // every lane takes part in the table gather
     if (lane < kDrawCache) {
       meta->u[lane] = u;
-      meta->lu[lane] = wnd::dlog(u);
+      meta->lu[lane] = lu;
     }
   }
   __device__ __forceinline__ int next_draw_slot() {
@@ -564,7 +602,7 @@ struct TrajBase {
     v = Q.adam_b2 * v + (1 - Q.adam_b2) * grad * grad;
     const double m_hat = m / (1 - b1p);
     const double v_hat = v / (1 - b2p);
-    const double lr_t = Q.adam_lr / wnd::dpow_pos(t, Q.adam_decay);
+    const double lr_t = Q.adam_lr / wnd::dpow_pos(t, Q.adam_decay, uniform_tab());
     const double denom = __builtin_sqrt(v_hat) + Q.adam_eps;
     theta -= lr_t * m_hat / denom;
     if (lane == 0) {
@@ -582,7 +620,7 @@ struct TrajBase {
 #pragma unroll
         for (int i = 0; i < 6; ++i) meta->adam[i] = Q.adam[6 * chain + i];
       }
-      step = uni(wnd::dexp(Q.adam[6 * chain]));  // adam.hpp:93
+      step = uni(wnd::dexp(Q.adam[6 * chain], uniform_tab()));  // adam.hpp:93
       // adaptive_walnuts.hpp:152-157
       const double mean_micro = Q.mm_state[2 * chain] / Q.mm_state[2 * chain + 1];
       const long long est = static_cast<long long>(__builtin_round(mean_micro / Q.macro_target));
@@ -636,7 +674,7 @@ struct TrajBase {
       self().energy(part, logp_pos, logp_joint);
       if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
         // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
-        if (P.warmup && wave == 0) adam_observe(wnd::dexp(-fabs(logp_start - logp_joint)));
+        if (P.warmup && wave == 0) adam_observe(wnd::dexp(-fabs(logp_start - logp_joint), uniform_tab()));
       }
       if (fabs(logp_start - logp_joint) <= max_error) {
         WN_PHASE(kPhReversible);
@@ -677,6 +715,7 @@ struct TrajBase {
       const double part = self().begin_transition(row, warm);
       self().energy(part, lp_pos, lj);
     }
+    prefetch_next_chain();
     int a_bk[3], a_fw[3];
     if constexpr (Self::kZeroCopy) {
       a_bk[0] = a_fw[0] = self().put_new(kTh);
@@ -1113,7 +1152,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
         z2[1] = z0[1];
       } else {
         wnd::stream_normal_pair(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamMomentum,
-                                static_cast<uint32_t>(k * L + tid), z2[0], z2[1]);
+                                static_cast<uint32_t>(k * L + tid), z2[0], z2[1], this->gather_tab());
       }
       double rh2[2];
 #pragma unroll
@@ -1200,21 +1239,23 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
 #if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
   t.phase_begin();
 #endif
-  for (;;) {
+  // The workgroup's first chain is its own index; the following ones come from the shared counter, and the fetch
+  // for chain n+1 is issued while chain n is being processed, so that its round trip (a device-scope atomic, 1-2 us
+  // under load) overlaps the tree instead of standing between two transitions.
+  int c = static_cast<int>(blockIdx.x);
+  int slot = 0;
+  while (c < P.num_chains) {
     WN_PHASE_OUTER(kPhIdle);
-    int c;
+    t.run(c);  // issues t.prefetch_next_chain() on the way
     if (NW == 1) {
-      int mine = 0;
-      if (threadIdx.x == 0) mine = static_cast<int>(atomicAdd(P.work_counter, 1u));
-      c = uni(mine);
+      c = uni(t.fetched);
     } else {
-      if (threadIdx.x == 0) *next_chain = static_cast<int>(atomicAdd(P.work_counter, 1u));
+      // two alternating words: a wavefront that races ahead to the next hand-over writes the other one
+      if (threadIdx.x == 0) next_chain[slot] = t.fetched;
       __syncthreads();
-      c = uni(*next_chain);
-      __syncthreads();
+      c = uni(next_chain[slot]);
+      slot ^= 1;
     }
-    if (c >= P.num_chains) break;
-    t.run(c);
   }
 #if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
   t.phase_end();

@@ -58,7 +58,7 @@ WND_HD double two_to(int k) { return as_f64(static_cast<uint64_t>(k + 1023) << 5
 // ~75 dependent operations) was 17 % of the headline step time.  Here: 64-entry 2^(j/64) table + degree-5
 // polynomial for exp, 49-entry (1/c, log c) table + degree-8 polynomial for log, Estrin-style grouping --
 // about 35 dependent operations for log_sum_exp.  Every step is a plain binary64 +,-,* or an integer
-// operation, so the host reproduces the bits (oracle/wn_oracle_math.h holds the checker's own copy).
+// operation, so the host reproduces the bits (the test suite keeps its own copy of both functions).
 // Accuracy against libm: within 2 ulp (tests/test_portable_math.py).
 //
 // `Tab` supplies the table entries: exp2(j), rcp(i), logc(i) (wn_math_tables.h on the host, VGPR lanes on the

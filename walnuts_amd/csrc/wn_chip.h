@@ -629,7 +629,11 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       }
     } else {
       vload_stream(Q.inv_mass + row, im);
-      vload_stream(Q.chol_mass + row, chol);  // 1/sqrt(inv_mass), walnuts.hpp:647, computed once at freeze
+      // 1/sqrt(inv_mass), walnuts.hpp:647: the expression freeze_kernel stores in the chol_mass plane, re-evaluated
+      // here (one division and one square root per element and transition) instead of streaming a third plane:
+      // 8 KB of the 40 KB a 1024-dimensional chain moves per transition
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) chol[j] = 1.0 / __builtin_sqrt(im[j]);
     }
     if (Q.rng_mode == kRngBuffer) {
       double z[EPL];

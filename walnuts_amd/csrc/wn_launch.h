@@ -79,14 +79,14 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_mod
     g.epl = epl_req;
     return g;
   }
-  // measured on MI355X (profiles/): wave-uniform tree logic is replicated per wavefront, so few waves with
-  // many elements per lane win until VGPR pressure caps residency
-  // ... except that a model whose gradient needs a reduction and keeps a gradient vector (the funnel) is better off
-  // with ONE wavefront per chain up to 1024 dimensions: no cross-wave barriers, half the replicated scalar work
-  static const int pref_light[][2] = {{1, 2}, {1, 4}, {1, 8}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
-  static const int pref_heavy[][2] = {{1, 2}, {1, 4}, {1, 8}, {1, 16}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
-  const int(*pref)[2] = light_model ? pref_light : pref_heavy;
-  const int npref = light_model ? 7 : 8;
+  // measured on MI355X (profiles/): the wave-uniform tree logic is replicated in every wavefront of a chain and
+  // every reduction of a multi-wavefront chain is an LDS exchange behind a barrier, so ONE wavefront per chain wins
+  // as long as the vectors fit its registers (16 elements per lane = 1024 dimensions: 2.43 ms against 2.57 ms for
+  // two wavefronts on the headline workload); beyond that, as few wavefronts as possible
+  (void)light_model;
+  static const int pref_all[][2] = {{1, 2}, {1, 4}, {1, 8}, {1, 16}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
+  const int(*pref)[2] = pref_all;
+  const int npref = 8;
   for (int i = 0; i < npref; ++i) {
     const int* p = pref[i];
     if (64 * p[0] * p[1] >= dim && geometry_exists(p[0], p[1])) {

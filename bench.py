@@ -1,21 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- leapfrog grad-evals/sec of the GPU-resident Walnuts engine (BASELINE.json metric).
 
-A "step" is one MCMC transition (walnuts.hpp:520-563) of EVERY chain: one launch of the persistent
-transition kernel.  Default workload = BASELINE.json's headline: 65 536 chains x 1 024-dim standard normal
-per GPU, default SamplingConfig, parameters adapted by `--adapt-iters` on-device warmup transitions
-(untimed), then W untimed + K timed sampling transitions.  Inputs are generated on the device (counter-based
-stream) and are resident in HBM when the timed region starts.
+A "step" is one MCMC transition (walnuts.hpp:520-563) of EVERY chain: one launch of the persistent transition
+kernel per GPU.  Default workload = BASELINE.json's headline: 65 536 chains x 1 024-dim standard normal, default
+SamplingConfig, parameters adapted by `--adapt-iters` on-device warmup transitions (untimed), then W untimed + K
+timed sampling transitions.  Inputs are generated on the device (counter-based stream) and are resident in HBM
+when the timed region starts.
 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
+Multi-GPU (`--scaling`): "strong" (default, the north star's target: the 65 536 chains are SHARDED over the N
+GPUs) or "weak" (`--chains` per GPU).  `--config 5` = BASELINE config #5: 262 144 chains sharded over the GPUs.
+The path's only exchange is the all-gather of each iteration's draws (RCCL over xGMI), overlapped with the next
+transition.
+
 Rank 0 prints ONE JSON line.  `value` = gradient evaluations of all chains on all ranks in the timed region
-/ max-over-ranks wall time.  `roofline.achieved` = 56*D bytes per gradient evaluation (read
-theta, rho, grad, inverse mass, write theta, rho, grad) x gradient evaluations per launch / average HIP-event
-duration of the transition kernel on the stream it is launched on.  `cpu_baseline` = the oracle (a CPU port
-of the reference algorithm, reference arithmetic order, libm) on the host cores for a bounded sample.
+/ max-over-ranks wall time.
+
+`roofline` describes the dominant kernel, timed with HIP events on the stream it is launched on:
+  * register kernels (D <= 8192: the trajectory end never leaves the chip): bound "fp64-valu".  `achieved` = useful
+    fp64 flops (10*D per gradient evaluation) / kernel time against the 78.6 TFLOP/s fp64 vector
+    peak; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/pmc_traffic.json FOR
+    THIS BUILD of walnuts_amd/csrc (entries carry the source hash; a stale entry is refused), `traffic_frac` = that
+    / kernel time / 8 TB/s.  The 56*D "algorithmic" byte figure of the metric definition is reported under
+    `algorithmic` only: those bytes never reach HBM, so their rate is not a bandwidth.
+  * streaming kernels (D > 8192): bound "hbm", `achieved` = algorithmic 56*D bytes per gradient evaluation / time.
+`parity_gate`: 64 chains replayed transition by transition on the CPU oracle in REFERENCE order
+(sequential sums, libm) from the device's own states with the same random streams: max relative difference of
+the selected position per transition, tree agreement, and the count of decisions within 1e-12 of a threshold.
+`cpu_baseline` = that oracle (a CPU port of the reference algorithm) timed on the host cores for a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,7 +42,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TF = 78.6   # fp64 vector peak (half the 157.3 TFLOP/s fp32 vector peak of the same guide)
+FLOPS_PER_GRAD_EVAL_PER_DIM = 10.0   # leapfrog 7*D + model 3*D
+HEADLINE_CHAINS = 65536
+CONFIG5_CHAINS = 262144
 
 
 def parse():
@@ -34,7 +54,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--chains", type=int, default=65536, help="chains PER GPU (weak scaling)")
+    ap.add_argument("--chains", type=int, default=HEADLINE_CHAINS,
+                    help="total chains (strong scaling) or chains per GPU (weak scaling)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: --chains is the job's total, sharded over the GPUs (north star); weak: per GPU")
+    ap.add_argument("--config", type=int, default=0, help="5 = BASELINE config #5 (262 144 chains, sharded)")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--model", default="std_normal", choices=["std_normal", "diag_normal", "ill_normal", "funnel"],
                     help="diag_normal: sigma_d = 1 + (d mod 16) (config #4); ill_normal: sigma_d = d + 1 (config #2, "
@@ -51,7 +75,10 @@ def parse():
     ap.add_argument("--gather-every", type=int, default=1,
                     help="all-gather the draws of every k-th transition (1 = every draw, the north star's exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-parity-gate", action="store_true")
+    ap.add_argument("--gate-chains", type=int, default=64)
+    ap.add_argument("--gate-transitions", type=int, default=8)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (gloo only to exercise the N>1 code path when ranks share one GPU)")
     ap.add_argument("--phase", default="sampling", choices=["sampling", "warmup"],
@@ -71,62 +98,162 @@ def model_setup(name, D):
     return wa.MODEL_DIAG_NORMAL, np.array([(1.0 + (d % 16)) ** 2 for d in range(D)])
 
 
-def measured_traffic(args, D):
+def oracle_model(name):
+    import wno
+
+    return {"std_normal": wno.MODEL_STD_NORMAL, "diag_normal": wno.MODEL_DIAG_NORMAL,
+            "ill_normal": wno.MODEL_DIAG_NORMAL, "funnel": wno.MODEL_FUNNEL}[name]
+
+
+def csrc_sha():
+    """Hash of the kernel sources this library was built from (what a recorded PMC measurement is valid for)."""
+    d = os.path.join(ROOT, "walnuts_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".inc")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(args, D, chains_local):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes recorded under profiles/ (counters
-    are collected in their own runs, never inside a timed bench run); None when this workload was not profiled."""
+    are collected in their own runs, never inside a timed bench run).  Only an entry recorded for THIS source hash of
+    walnuts_amd/csrc counts; anything else is reported as stale and not used."""
     try:
         entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except OSError:
-        return None, None
+        return None, "no profiles/pmc_traffic.json"
+    sha = csrc_sha()
+    stale = None
     for e in entries:
-        if (e["model"], e["chains"], e["dim"], e["phase"]) == (args.model, args.chains, D, args.phase):
-            return e["bytes_per_launch"], e["source"]
-    return None, None
+        if (e["model"], e["chains"], e["dim"], e["phase"]) == (args.model, chains_local, D, args.phase):
+            if e.get("csrc_sha") == sha:
+                return e["bytes_per_launch"], e["source"]
+            stale = f"stale PMC entry refused (recorded for csrc {e.get('csrc_sha')}, this build is {sha})"
+    return None, stale or "this workload was not profiled"
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a
+    256-thread host is often limited to a few cores; os.cpu_count() does not know)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(args, D):
-    """The oracle timed on the host cores: reference arithmetic order (left-to-right sums, libm), one thread per
-    chain block.  Bounded: 8 chains per core, ~args.cpu_seconds of sampling transitions."""
+    """The oracle timed on the host cores: reference arithmetic order (left-to-right sums, libm), persistent worker
+    threads, chains dealt out dynamically.  Bounded: 8 chains per core for ~args.cpu_seconds of sampling transitions
+    on all cores, then 8 chains on ONE core for a third of that."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wno
 
-    cores = os.cpu_count() or 1
-    chains = 8 * cores
-    om = {"std_normal": wno.MODEL_STD_NORMAL, "diag_normal": wno.MODEL_DIAG_NORMAL, "ill_normal": wno.MODEL_DIAG_NORMAL,
-          "funnel": wno.MODEL_FUNNEL}[args.model]
+    cores = host_cores()
     _, params = model_setup(args.model, D)
-    cfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=0)
-    e = wno.Engine(om, D, chains, cfg, params=params)
-    e.init_positions(args.seed, 0, 2.0)
-    e.init_masses_from_grad(1e-5)
-    e.set_step_sizes(1.0)
-    e.adapt_step(args.seed, 0)
-    e.seed_chains(args.seed + 1, 0)
-    adapt = min(args.adapt_iters, 100)
-    for _ in range(adapt):
-        e.warmup_step(cores)
-    if args.phase == "sampling":
-        e.freeze()
-        step = lambda: e.sample_step(cores)
-    else:
-        step = lambda: e.warmup_step(cores)
-    step()
-    g0 = int(e.grad_evals().sum())
-    t0 = time.perf_counter()
-    n = 0
-    while True:
+
+    def run(chains, threads, seconds):
+        cfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=0)
+        e = wno.Engine(oracle_model(args.model), D, chains, cfg, params=params)
+        e.init_positions(args.seed, 0, 2.0)
+        e.init_masses_from_grad(1e-5)
+        e.set_step_sizes(1.0)
+        e.adapt_step(args.seed, 0)
+        e.seed_chains(args.seed + 1, 0)
+        adapt = min(args.adapt_iters, 100)
+        for _ in range(adapt):
+            e.warmup_step(threads)
+        if args.phase == "sampling":
+            e.freeze()
+            step = lambda: e.sample_step(threads)
+        else:
+            step = lambda: e.warmup_step(threads)
         step()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= args.cpu_seconds or n >= 100000:
-            break
-    g1 = int(e.grad_evals().sum())
-    return {"value": (g1 - g0) / dt, "unit": "grad-evals/s", "cores": cores, "kind": "port",
-            "per_core": (g1 - g0) / dt / cores,
-            "sample": f"{chains} chains x {D}-dim {args.model}, {adapt} adaptive warmup transitions then {n} "
-                      f"{args.phase} transitions in {dt:.1f} s on {cores} threads (oracle: CPU port of the reference "
-                      "algorithm, sequential sums + libm; the reference Eigen build is unavailable: Eigen is not "
-                      "vendored, CMakeLists.txt:28-41)"}
+        g0 = int(e.grad_evals().sum())
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            step()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 100000:
+                break
+        return (int(e.grad_evals().sum()) - g0) / dt, adapt, n, dt
+
+    v_all, adapt, n, dt = run(8 * cores, cores, args.cpu_seconds)
+    v_one, _, n1, dt1 = run(8, 1, max(2.0, args.cpu_seconds / 3))
+    return {"value": v_all, "unit": "grad-evals/s", "cores": cores, "kind": "port",
+            "per_core": v_all / cores, "one_core": v_one,
+            "sample": f"{8 * cores} chains x {D}-dim {args.model}, {adapt} adaptive warmup transitions then {n} "
+                      f"{args.phase} transitions in {dt:.1f} s on {cores} persistent threads; one_core: 8 chains, "
+                      f"{n1} transitions in {dt1:.1f} s on 1 thread (oracle: CPU port of the reference algorithm, "
+                      "sequential sums + libm; the reference Eigen build is unavailable: Eigen is not vendored, "
+                      "CMakeLists.txt:28-41)"}
+
+
+def parity_gate(args, D, cfg_kwargs):
+    """SURVEY.md section 8d "parity gate in the same run": a subset of chains replayed on the CPU restatement in
+    REFERENCE order (left-to-right sums, libm exp/log) with the identical random stream, one transition at a time
+    from the device's own state.  Reports the max relative difference of the selected position per transition (north
+    star: <= 1e-10), how many chains built the identical tree, and how many decisions sat within 1e-12 (relative) of
+    their threshold -- |H0-H1| <= max_error (walnuts.hpp:339), the U-turn signs (:199-200), log u < delta (:379) --
+    i.e. where a different summation order could have flipped the tree."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import walnuts_amd as wa
+    import wno
+
+    Cg, T = args.gate_chains, args.gate_transitions
+    model_id, params = model_setup(args.model, D)
+    dev = wa.DeviceEngine(model_id, D, Cg, wa.default_config(**cfg_kwargs), params=params)
+    ocfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=0)
+    orc = wno.Engine(oracle_model(args.model), D, Cg, ocfg, params=params)
+    orc.set_tie_tolerance(1e-12)
+    dev.init_positions(args.seed, 0, 2.0)
+    dev.init_masses_from_grad(1e-5)
+    dev.set_step_sizes(1.0)
+    dev.adapt_step(args.seed, 0)
+    dev.seed_chains(args.seed + 1, 0)
+    orc.seed_chains(args.seed + 1, 0)
+    adapt = min(args.adapt_iters, 40)
+    for _ in range(adapt):
+        dev.warmup_step()
+    dev.freeze()
+    dev.synchronize()
+    inv_mass, steps, mm = dev.inv_mass(), dev.step_sizes(), dev.min_micro()
+    rel, rel_lp, same_tree = [], [], []
+    for t in range(T):
+        pos = dev.positions()
+        orc.set_positions(pos)
+        orc.set_sampler_state(inv_mass, steps, mm)
+        orc.set_transition_index(adapt + t)
+        g_dev0, g_orc0 = dev.grad_evals().copy(), orc.grad_evals().copy()
+        dev.sample_step()
+        orc.sample_step(host_cores())
+        dev.synchronize()
+        a, b = dev.positions(), orc.positions()
+        same = (dev.depths() == orc.depths()) & ((dev.grad_evals() - g_dev0) == (orc.grad_evals() - g_orc0))
+        r = np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-300)
+        rel.append(float(r[same].max()) if same.any() else float("nan"))
+        # the selected position is a leaf of element-wise leapfrog arithmetic (bit-identical whenever the tree is);
+        # its log density is a sum over D and shows the two summation orders
+        la, lb = dev.logp(), orc.logp()
+        rl = np.abs(la - lb) / np.maximum(np.abs(lb), 1e-300)
+        rel_lp.append(float(rl[same].max()) if same.any() else float("nan"))
+        same_tree.append(int(same.sum()))
+    ties = orc.near_ties()
+    worst = float(np.nanmax(rel))
+    return {"chains": Cg, "transitions": T, "order": "reference (sequential sums, libm) vs device",
+            "max_rel_diff_per_transition": rel, "max_rel_diff": worst,
+            "max_rel_diff_logp_per_transition": rel_lp, "max_rel_diff_logp": float(np.nanmax(rel_lp)),
+            "within_1e-10": bool(worst <= 1e-10 and np.nanmax(rel_lp) <= 1e-10),
+            "chains_with_identical_tree_per_transition": same_tree,
+            "tree_mismatches": int(Cg * T - sum(same_tree)),
+            "near_ties_1e-12": {k: {"near": v[0], "decisions": v[1]} for k, v in ties.items()}}
 
 
 def main():
@@ -134,6 +261,7 @@ def main():
     import torch
 
     import walnuts_amd as wa
+    from walnuts_amd.distributed import DrawGather, shard_chains
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -154,30 +282,39 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    D, C = args.dim, args.chains
+    D = args.dim
+    if args.config == 5:
+        args.scaling, args.chains = "strong", CONFIG5_CHAINS
+    if args.scaling == "strong":
+        total_chains = args.chains
+        chain0, C = shard_chains(total_chains, rank, world)
+    else:
+        C = args.chains
+        total_chains = C * world
+        chain0 = rank * C
     model_id, params = model_setup(args.model, D)
     # the transition kernel is persistent and would hold every CU for the whole step; with more than one GPU a
     # few CUs stay free so that RCCL's all-gather of the previous draws really runs underneath it
     reserved = args.reserved_cus if args.reserved_cus >= 0 else (16 if world > 1 else 0)
-    cfg = wa.default_config(device=local_rank, waves_per_chain=args.waves_per_chain, elems_per_lane=args.elems_per_lane,
-                            workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors,
-                            reserved_cus=reserved, reg_vectors=args.reg_vectors)
+    cfg_kwargs = dict(device=local_rank, waves_per_chain=args.waves_per_chain, elems_per_lane=args.elems_per_lane,
+                      workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors,
+                      reg_vectors=args.reg_vectors)
+    cfg = wa.default_config(reserved_cus=reserved, **cfg_kwargs)
     eng = wa.DeviceEngine(model_id, D, C, cfg, params=params)
     if world > 1:
         # kernels on torch's current stream: RCCL collectives on the draws are then ordered after them by torch
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    chain0 = rank * C
     # InitConfigBuilder on the device: positions ~ N(0, 2^2) (init_radius, pyfunc.py:57), masses from the
-    # gradient with smoothing 1e-5, step-size search from step_size_init = 1.0
+    # gradient with smoothing 1e-5, step-size search from step_size_init = 1.0.  Streams are keyed by the GLOBAL
+    # chain id, so the result does not depend on the sharding.
     eng.init_positions(args.seed, chain0, 2.0)
     eng.init_masses_from_grad(1e-5)
     eng.set_step_sizes(1.0)
     eng.adapt_step(args.seed, chain0)
     eng.seed_chains(args.seed + 1, chain0)
 
-    from walnuts_amd.distributed import DrawGather
-
-    gather = DrawGather(dist, world, C, D, "cuda", torch.float64)
+    gather = DrawGather(dist, world, rank, total_chains, D, "cuda", torch.float64,
+                        counts=None if args.scaling == "strong" else [C] * world)
 
     def one_step(i, timed_phase):
         plane = gather.buffer(i)
@@ -227,10 +364,38 @@ def main():
 
     if rank == 0:
         avg_kernel_ms = float(np.mean(ktimes)) if len(ktimes) else float("nan")
-        bytes_per_launch = 56.0 * D * grad_evals / max(args.steps, 1)  # this rank's launches
-        achieved = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = measured_traffic(args, D)
+        kernel_s = avg_kernel_ms * 1e-3
+        evals_per_launch = grad_evals / max(args.steps, 1)   # this rank's launches
+        algorithmic_bytes = 56.0 * D * evals_per_launch
+        algorithmic_gbps = algorithmic_bytes / kernel_s / 1e9
         streaming = bool(eng.streaming)
+        traffic, traffic_source = measured_traffic(args, D, C)
+        if streaming:
+            roofline = {"bound": "hbm", "achieved": algorithmic_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": algorithmic_gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                        "traffic_source": traffic_source,
+                        "traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                        "kernel": "wn::transition_kernel_mem", "avg_launch_ms": avg_kernel_ms,
+                        "algorithmic_bytes_per_launch": algorithmic_bytes,
+                        "note": "algorithmic bytes = 56*D per grad-eval; the streaming kernels move theta, rho and the "
+                                "inverse mass per micro step and recompute the element-wise gradient (40*D); part of the "
+                                "counter traffic is served by the 256 MiB Infinity Cache"}
+        else:
+            flops = FLOPS_PER_GRAD_EVAL_PER_DIM * D * evals_per_launch
+            tf = flops / kernel_s / 1e12
+            roofline = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": tf / FP64_VALU_PEAK_TF, "traffic": traffic, "traffic_source": traffic_source,
+                        "traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                        "kernel": "wn::transition_kernel_chip", "avg_launch_ms": avg_kernel_ms,
+                        "algorithmic": {"bytes_per_launch": algorithmic_bytes, "GBps_equivalent": algorithmic_gbps,
+                                        "ratio_to_hbm_peak": algorithmic_gbps / HBM_PEAK_GBPS,
+                                        "note": "56*D bytes per grad-eval by the metric's definition; the trajectory "
+                                                "end lives in VGPRs and the span pool in LDS, so these bytes never "
+                                                "reach HBM and this is not a bandwidth"},
+                        "note": "useful fp64 flops = 10*D per grad-eval (no FMA contraction: element-wise results carry "
+                                "the reference's bits); the kernel is bound by dependent-latency and issue of the fp64 "
+                                "vector pipe, not by HBM"}
+            assert roofline["frac"] <= 1.0 and (roofline["traffic_frac"] or 0.0) <= 1.0
         out = {
             "metric": "leapfrog grad-evals/sec (all chains)",
             "value": total_grad_evals / elapsed,
@@ -240,14 +405,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{C} chains x {D}-dim {args.model} per GPU, default SamplingConfig, "
+                "workload": f"{total_chains} chains x {D}-dim {args.model} ({C} on this GPU), default SamplingConfig, "
                             f"{args.adapt_iters} on-device adaptive warmup transitions then timed {args.phase} transitions",
-                "chains_per_gpu": C, "global_chains": C * world, "dim": D, "model": args.model,
+                "chains_per_gpu": C, "global_chains": total_chains, "dim": D, "model": args.model,
                 "phase": args.phase, "parallelism": f"chains sharded over {world} GPU(s)"
                                                     + (f", {'RCCL' if args.backend == 'nccl' else 'gloo'} all-gather of draws every "
                                                        f"{args.gather_every} step(s)" if world > 1 else ""),
@@ -255,18 +420,12 @@ def main():
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
                              "reserved_cus": reserved},
                 "grad_evals_per_transition_per_chain": grad_evals / max(args.steps, 1) / C,
+                "csrc_sha": csrc_sha(),
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "wn::transition_kernel_mem" if streaming else "wn::transition_kernel",
-                         "avg_launch_ms": avg_kernel_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": ("algorithmic bytes = 56*D per grad-eval; the streaming kernels move theta, rho and the "
-                                  "inverse mass per micro step and recompute the element-wise gradient"
-                                  if streaming else
-                                  "algorithmic bytes = 56*D per grad-eval; the trajectory end lives in VGPRs and the "
-                                  "span pool in LDS, so measured HBM traffic is far below the algorithmic figure")},
+            "roofline": roofline,
         }
+        if world == 1 and not args.no_parity_gate:
+            out["parity_gate"] = parity_gate(args, D, cfg_kwargs)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, D)
         print(json.dumps(out), flush=True)

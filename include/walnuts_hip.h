@@ -268,6 +268,17 @@ WALNUTS_HIP_EXPORT int wn_summary_effective_sample_size(wn_chains* chains, doubl
 WALNUTS_HIP_EXPORT int wn_summary_monte_carlo_standard_error(wn_chains* chains, double* out /*[D]*/,
                                                              WalnutpyError** err);
 
+/* ---- the reference's summary entry points, same symbols and arguments (walnutpy.cpp:333-369) -------------
+ * draws: the stacked chains as Eigen::Map<const MatrixXd>(draws, num_draws, num_params) reads them
+ * (walnutpy.cpp:89), i.e. COLUMN-major num_draws x num_params; lengths[num_chains] sum to num_draws;
+ * out[num_params].  Computed on the device by wn_summary_* (upload, summarise, copy back). */
+WALNUTS_HIP_EXPORT int walnutpie_ess(const double* draws, int num_draws, int num_params, const int* lengths,
+                                     int num_chains, double* out, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int walnutpie_r_hat(const double* draws, int num_draws, int num_params, const int* lengths,
+                                       int num_chains, double* out, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int walnutpie_mcse(const double* draws, int num_draws, int num_params, const int* lengths,
+                                      int num_chains, double* out, WalnutpyError** err);
+
 #ifdef __cplusplus
 }
 #endif

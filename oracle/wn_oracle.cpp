@@ -14,6 +14,10 @@
 #include "wn_oracle_math.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -358,6 +362,17 @@ struct Ctx {
   int64_t grad_evals = 0;
   std::vector<TraceRec>* trace = nullptr;
   double last_alpha = 0;
+  // Near-tie audit (SURVEY.md section 8d "parity gate"): how many of this transition's decisions sat within
+  // tie_tol (relative to the magnitude of the compared quantities) of their threshold -- the only places where
+  // a different summation order or a last-ulp exp/log can change the tree.
+  // [0] |H0 - H1| <= max_error (walnuts.hpp:339, :234)  [1] U-turn signs (:199-200)  [2] log u < delta (:379)
+  double tie_tol = 0.0;
+  int64_t ties[3] = {0, 0, 0};
+  int64_t decisions[3] = {0, 0, 0};
+  void audit(int kind, double margin, double scale) {
+    ++decisions[kind];
+    if (tie_tol > 0 && std::fabs(margin) <= tie_tol * std::max(1.0, scale)) ++ties[kind];
+  }
 };
 
 inline void leap(Ctx& c, double step, double half, double* th, double* rho, double* g, double& logp_pos) {
@@ -377,6 +392,7 @@ bool within_tolerance(Ctx& c, double step, size_t num_steps, double logp_next, d
   double logp = logp_next;
   for (size_t n = 0; n < num_steps; ++n) leap(c, step, half, th, rho, g, logp_next);
   logp_next += logp_momentum(c.red, c.D, rho, c.im);
+  c.audit(0, std::abs(logp_next - logp) - c.max_error, std::max(std::fabs(logp), std::fabs(logp_next)));
   return std::abs(logp_next - logp) <= c.max_error;
 }
 
@@ -414,6 +430,7 @@ bool macro_step(Ctx& c, bool forward, const Vec& th0, const Vec& rho0, const Vec
       if (c.adam) c.adam->observe(min_accept);
     }
     bool ok = std::fabs(logp - logp_next) <= c.max_error;
+    c.audit(0, std::fabs(logp - logp_next) - c.max_error, std::max(std::fabs(logp), std::fabs(logp_next)));
     bool rev = false;
     if (ok) rev = reversible(c, step, num_steps, logp_next, th, rho, g);
     if (c.trace) {
@@ -427,13 +444,24 @@ bool macro_step(Ctx& c, bool forward, const Vec& th0, const Vec& rho0, const Vec
 }
 
 // walnuts.hpp:192-201 with order_forward_backward :153-160
-bool uturn(const Ctx& c, bool forward, const Span& s1, const Span& s2) {
+bool uturn(Ctx& c, bool forward, const Span& s1, const Span& s2) {
   const Span& bk = forward ? s1 : s2;
   const Span& fw = forward ? s2 : s1;
   const double* im = c.im;
   auto sd = [&](size_t i) { return im[i] * (fw.th_fw[i] - bk.th_bk[i]); };
   double d_fw = c.red.sum(c.D, [&](size_t i) { return fw.rho_fw[i] * sd(i); });
   double d_bk = c.red.sum(c.D, [&](size_t i) { return bk.rho_bk[i] * sd(i); });
+  if (c.tie_tol > 0) {  // scale of each product: the sum of the magnitudes of its terms
+    double a_fw = 0, a_bk = 0;
+    for (size_t i = 0; i < c.D; ++i) {
+      a_fw += std::fabs(fw.rho_fw[i] * sd(i));
+      a_bk += std::fabs(bk.rho_bk[i] * sd(i));
+    }
+    c.audit(1, d_fw, a_fw);
+    c.audit(1, d_bk, a_bk);
+  } else {
+    c.decisions[1] += 2;
+  }
   return d_fw < 0 || d_bk < 0;
 }
 
@@ -442,7 +470,9 @@ Span combine(Ctx& c, bool metropolis, bool forward, Span&& s_old, Span&& s_new) 
   double total = log_sum_exp(c.mo, s_old.logsum, s_new.logsum);
   double denom = metropolis ? s_old.logsum : total;
   double update_logprob = s_new.logsum - denom;
-  bool update = c.mo.log(c.rng->uniform01()) < update_logprob;
+  const double log_u = c.mo.log(c.rng->uniform01());
+  bool update = log_u < update_logprob;
+  c.audit(2, log_u - update_logprob, std::max(std::fabs(s_new.logsum), std::fabs(denom)));
   Span& sel = update ? s_new : s_old;
   Span out;
   out.th_sel = std::move(sel.th_sel);
@@ -573,6 +603,7 @@ struct Chain {
   std::mt19937_64 eng64;
   std::mt19937 eng32;
   std::vector<TraceRec> trace;
+  int64_t ties[3] = {0, 0, 0}, decisions[3] = {0, 0, 0};
   // WelfordAccumulator of the sampling log densities (online_moments.hpp:22-86, sampler.hpp:87-88)
   double lp_n = 0, lp_mean = 0, lp_m2 = 0;
   void observe_lp(double x) {
@@ -597,6 +628,7 @@ struct wno_engine {
   std::vector<Chain> chains;
   bool adapt_ready = false;
   bool trace_on = false;
+  double tie_tol = 0.0;
   int64_t iteration = 0;
   Vec var_z, var_u;  // pending host-supplied variates (one transition)
   size_t var_nu = 0;
@@ -644,7 +676,14 @@ struct wno_engine {
     c.adam = adam;
     c.trace = trace_on ? &ch.trace : nullptr;
     if (trace_on) ch.trace.clear();
+    c.tie_tol = tie_tol;
     return c;
+  }
+  static void collect_audit(Chain& ch, const Ctx& c) {
+    for (int k = 0; k < 3; ++k) {
+      ch.ties[k] += c.ties[k];
+      ch.decisions[k] += c.decisions[k];
+    }
   }
 
   void warmup_chain(Chain& ch) {  // adaptive_walnuts.hpp:234-251
@@ -657,6 +696,7 @@ struct wno_engine {
     transition(c, chol.data(), static_cast<size_t>(cfg.max_trajectory_doublings), ch.theta, ch.depth, ch.grad_sel,
                ch.logp);
     ch.grad_evals += c.grad_evals;
+    collect_audit(ch, c);
     ch.last_scalar_draws = lease.r->scalar_draws;
     ch.est.observe(ch.theta.data(), ch.grad_sel.data(), ch.iteration);
     ch.mm.observe(static_cast<size_t>(1) << ch.depth);
@@ -682,10 +722,79 @@ struct wno_engine {
     transition(c, ch.chol.data(), static_cast<size_t>(cfg.max_trajectory_doublings), ch.theta, ch.depth,
                ch.grad_sel, ch.logp);
     ch.grad_evals += c.grad_evals;
+    collect_audit(ch, c);
     ch.last_scalar_draws = lease.r->scalar_draws;
     ch.observe_lp(ch.logp);
     ++ch.transitions;
   }
+
+  // Worker threads live as long as the engine (one spawn per run, not per transition): a step hands them one
+  // job and waits; chains are dealt out in blocks of a few through an atomic cursor, so a slow chain does not
+  // hold up a whole pre-assigned range.
+  struct Pool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(size_t)> job;
+    std::atomic<size_t> cursor{0};
+    size_t total = 0, block = 1, generation = 0, running = 0;
+    bool stop = false;
+    void work() {
+      for (;;) {
+        const size_t lo = cursor.fetch_add(block);
+        if (lo >= total) break;
+        const size_t hi = std::min(total, lo + block);
+        for (size_t i = lo; i < hi; ++i) job(i);
+      }
+    }
+    void loop() {
+      size_t seen = 0;
+      for (;;) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv_go.wait(lk, [&] { return stop || generation != seen; });
+          if (stop) return;
+          seen = generation;
+        }
+        work();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (--running == 0) cv_done.notify_all();
+        }
+      }
+    }
+    void ensure(size_t n) {
+      if (workers.size() == n) return;
+      shutdown();
+      stop = false;
+      for (size_t t = 0; t < n; ++t) workers.emplace_back([this] { loop(); });
+    }
+    void run(size_t n_items, size_t blk, std::function<void(size_t)> f) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(f);
+        total = n_items;
+        block = blk;
+        cursor = 0;
+        running = workers.size();
+        ++generation;
+      }
+      cv_go.notify_all();
+      std::unique_lock<std::mutex> lk(mu);
+      cv_done.wait(lk, [&] { return running == 0; });
+    }
+    void shutdown() {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+      }
+      cv_go.notify_all();
+      for (auto& w : workers) w.join();
+      workers.clear();
+    }
+    ~Pool() { shutdown(); }
+  };
+  std::unique_ptr<Pool> pool;
 
   template <class F>
   void for_chains(int num_threads, F f) {
@@ -693,15 +802,11 @@ struct wno_engine {
       for (auto& ch : chains) f(ch);
       return;
     }
-    size_t nt = std::min<size_t>(static_cast<size_t>(num_threads), C);
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; ++t) {
-      th.emplace_back([&, t] {
-        size_t lo = C * t / nt, hi = C * (t + 1) / nt;
-        for (size_t i = lo; i < hi; ++i) f(chains[i]);
-      });
-    }
-    for (auto& x : th) x.join();
+    const size_t nt = std::min<size_t>(static_cast<size_t>(num_threads), C);
+    if (!pool) pool = std::make_unique<Pool>();
+    pool->ensure(nt);
+    const size_t blk = std::max<size_t>(1, C / (nt * 4));
+    pool->run(C, blk, [&](size_t i) { f(chains[i]); });
   }
 };
 
@@ -892,6 +997,40 @@ void wno_sample_step(wno_engine* e, int num_threads) {
   e->for_chains(num_threads, [&](Chain& ch) { e->sample_chain(ch); });
   e->var_nu = 0;
   ++e->iteration;
+}
+
+/* frozen sampler parameters handed in as they are (a WalnutsSampler constructed from them, walnuts.hpp:637-660):
+ * inverse mass [C*D], step size [C], min micro steps [C] */
+void wno_set_sampler_state(wno_engine* e, const double* inv_mass, const double* step, const int64_t* min_micro) {
+  for (size_t c = 0; c < e->C; ++c) {
+    Chain& ch = e->chains[c];
+    ch.inv_mass.assign(inv_mass + c * e->D, inv_mass + (c + 1) * e->D);
+    ch.chol.resize(e->D);
+    for (size_t i = 0; i < e->D; ++i) ch.chol[i] = 1.0 / std::sqrt(ch.inv_mass[i]);
+    ch.step = step[c];
+    ch.min_micro = static_cast<size_t>(min_micro[c]);
+    if (ch.rng) ch.rng->reset_distributions();
+    ch.frozen = true;
+  }
+}
+/* the counter-based streams are keyed by the transition index: make the next transition number `t` */
+void wno_set_transition_index(wno_engine* e, uint32_t t) {
+  for (auto& ch : e->chains) ch.transitions = t;
+}
+
+/* near-tie audit: tolerance (0 = off), and totals over all chains since the last reset:
+ * out[0..2] = decisions within the tolerance of their threshold (energy error, U-turn sign, acceptance draw),
+ * out[3..5] = decisions taken */
+void wno_set_tie_tolerance(wno_engine* e, double tol) { e->tie_tol = tol; }
+void wno_get_near_ties(wno_engine* e, int64_t* out, int reset) {
+  for (int k = 0; k < 6; ++k) out[k] = 0;
+  for (auto& ch : e->chains) {
+    for (int k = 0; k < 3; ++k) {
+      out[k] += ch.ties[k];
+      out[3 + k] += ch.decisions[k];
+      if (reset) ch.ties[k] = ch.decisions[k] = 0;
+    }
+  }
 }
 
 void wno_get_positions(const wno_engine* e, double* out) {

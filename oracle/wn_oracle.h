@@ -94,6 +94,16 @@ void wno_warmup_step(wno_engine* e, int num_threads); /* AdaptiveWalnuts::operat
 void wno_freeze(wno_engine* e);                       /* AdaptiveWalnuts::sampler() */
 void wno_sample_step(wno_engine* e, int num_threads); /* WalnutsSampler::operator() for all chains */
 
+/* frozen sampler parameters handed in as they are: inverse mass [C*D], step [C], min micro steps [C] */
+void wno_set_sampler_state(wno_engine* e, const double* inv_mass, const double* step, const int64_t* min_micro);
+/* counter-based streams are keyed by the transition index: make the next transition number `t` */
+void wno_set_transition_index(wno_engine* e, uint32_t t);
+/* near-tie audit: tolerance relative to the compared magnitudes (0 = off); totals over
+ * all chains: out[0..2] = near ties (energy error walnuts.hpp:339, U-turn signs :199-200, acceptance :379),
+ * out[3..5] = decisions taken */
+void wno_set_tie_tolerance(wno_engine* e, double tol);
+void wno_get_near_ties(wno_engine* e, int64_t* out, int reset);
+
 /* ---- state -------------------------------------------------------------- */
 void wno_get_positions(const wno_engine* e, double* out /*[C*D]*/);
 void wno_get_grad_select(const wno_engine* e, double* out /*[C*D]*/);

@@ -115,6 +115,10 @@ def lib():
     L.wno_math_exp.argtypes = [dbl]
     L.wno_math_log.restype = dbl
     L.wno_math_log.argtypes = [dbl]
+    L.wno_set_sampler_state.argtypes = [vp, _dp, _dp, C.POINTER(C.c_int64)]
+    L.wno_set_transition_index.argtypes = [vp, u32]
+    L.wno_set_tie_tolerance.argtypes = [vp, dbl]
+    L.wno_get_near_ties.argtypes = [vp, C.POINTER(C.c_int64), i32]
     _lib = L
     return L
 
@@ -197,6 +201,26 @@ class Engine:
 
     def sample_step(self, threads: int = 1):
         self.L.wno_sample_step(self.h, threads)
+
+    def set_sampler_state(self, inv_mass, step, min_micro):
+        """Frozen sampler parameters handed in as they are (inverse mass [C, D], step [C], min micro steps [C])."""
+        im = np.ascontiguousarray(inv_mass, dtype=np.float64).reshape(self.C, self.D)
+        st = np.ascontiguousarray(np.broadcast_to(step, (self.C,)), dtype=np.float64)
+        mm = np.ascontiguousarray(np.broadcast_to(min_micro, (self.C,)), dtype=np.int64)
+        self.L.wno_set_sampler_state(self.h, im.ctypes.data_as(_dp), st.ctypes.data_as(_dp),
+                                     mm.ctypes.data_as(C.POINTER(C.c_int64)))
+
+    def set_transition_index(self, t: int):
+        self.L.wno_set_transition_index(self.h, int(t))
+
+    def set_tie_tolerance(self, tol: float):
+        self.L.wno_set_tie_tolerance(self.h, float(tol))
+
+    def near_ties(self, reset: bool = True):
+        """-> dict kind -> (decisions within the tolerance of their threshold, decisions taken)."""
+        out = (C.c_int64 * 6)()
+        self.L.wno_get_near_ties(self.h, out, 1 if reset else 0)
+        return {k: (int(out[i]), int(out[3 + i])) for i, k in enumerate(("energy_error", "uturn_sign", "acceptance"))}
 
     # --- state
     def _vec(self, fn, shape, dtype=np.float64, ptr=_dp):

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --steps 4 --warmup 1 --adapt-iters 100 $*"
+ARGS="--no-cpu-baseline --no-parity-gate --steps 4 --warmup 1 --adapt-iters 100 $*"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
@@ -32,6 +32,22 @@ for n, (v, d) in vals.items():
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
     print(f"HBM traffic per launch = (2*FETCH_SIZE + WRITE_SIZE) KB = {(2*f+w)*1024/1e9:.3f} GB  (gfx950: FETCH_SIZE counts wide reads at 1/2)")
+import argparse, hashlib, json, os
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="std_normal"); ap.add_argument("--chains", type=int, default=65536)
+ap.add_argument("--dim", type=int, default=1024); ap.add_argument("--phase", default="sampling")
+known, _ = ap.parse_known_args("$ARGS".split())
+d = os.path.join("$ROOT", "walnuts_amd", "csrc")
+h = hashlib.sha256()
+for f in sorted(os.listdir(d)):
+    if f.endswith((".h", ".hip", ".inc")) or f == "Makefile":
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    json.dump({"model": known.model, "chains": known.chains, "dim": known.dim, "phase": known.phase,
+               "csrc_sha": h.hexdigest()[:16], "bytes_per_launch": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
+               "source": "profiles/r02/pmc_$TAG.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, last "
+                         "(steady-state) dispatch, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 note in MI355X_MICROARCH.md"},
+              open("$OUT/traffic.json", "w"))
 if "SQ_WAVE_CYCLES" in vals:
     wc = vals["SQ_WAVE_CYCLES"][0]
     for n in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):

@@ -23,7 +23,7 @@ from walnuts_amd.distributed import DrawGather, shard_chains, global_rhat, globa
 SIM = simbuild.build()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-D, TOTAL, ITERS = 6, 4, 3
+D, TOTAL, ITERS = 6, int(os.environ.get("WN_TEST_TOTAL", "4")), 3
 first, count = shard_chains(TOTAL, rank, world)
 pos = np.random.default_rng(3).normal(size=(TOTAL, D))
 
@@ -33,7 +33,7 @@ def make(first, count):
     return e
 
 eng = make(first, count)
-gather = DrawGather(dist, world, count, D, "cpu", torch.float64)
+gather = DrawGather(dist, world, rank, TOTAL, D, "cpu", torch.float64)
 seen = []
 spread = None
 for it in range(ITERS):
@@ -89,16 +89,27 @@ def test_shard_chains_partition():
             nxt += count
 
 
-@pytest.mark.timeout(900)
-def test_two_rank_gloo_run_matches_single_rank(tmp_path):
+def _run_world(tmp_path, world, total):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   WN_TEST_TOTAL=str(total), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=800)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DISTRIBUTED_OK" in outs[0]
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gloo_run_matches_single_rank(tmp_path):
+    _run_world(tmp_path, 2, 4)
+
+
+@pytest.mark.timeout(900)
+def test_four_rank_gloo_run_with_uneven_shards_matches_single_rank(tmp_path):
+    # 6 chains over 4 ranks: shards of 2, 2, 1, 1 -- the gathered block is still the single-rank run's, in order
+    _run_world(tmp_path, 4, 6)

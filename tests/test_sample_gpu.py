@@ -1,0 +1,69 @@
+"""GPU tier: the boundary pieces of walnutpie_sample_device on the device -- draw sink through a small staging
+buffer at the headline chain count, SIGINT -> error type `interrupt`, the reference's summary symbols."""
+import os
+import signal
+
+import numpy as np
+import pytest
+
+import summary_parity as sp
+import walnuts_amd as wa
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(gpu):
+    return gpu
+
+
+def test_sigint_ends_the_device_call_with_keyboard_interrupt():
+    before = signal.getsignal(signal.SIGINT)
+    seen = []
+
+    def on_print(text):
+        seen.append(text)
+        if len(seen) == 8:
+            os.kill(os.getpid(), signal.SIGINT)
+
+    with pytest.raises(KeyboardInterrupt):
+        wa.walnuts_device(wa.MODEL_STD_NORMAL, num_params=64, num_chains=4, seed=3, min_warmup_iter=400,
+                          max_warmup_iter=400, min_sampling_iter=10, max_sampling_iter=10, refresh=1,
+                          print_callback=on_print)
+    assert len(seen) < 4 * 4, "the call must stop at the next iteration boundary"
+    assert signal.getsignal(signal.SIGINT) is before
+    out = wa.walnuts_device(wa.MODEL_STD_NORMAL, num_params=64, num_chains=4, seed=3, min_warmup_iter=5,
+                            max_warmup_iter=5, min_sampling_iter=5, max_sampling_iter=5)
+    assert np.all(np.isfinite(np.asarray(out[0])))
+
+
+def test_draw_sink_streams_the_headline_chain_count_through_a_small_staging_buffer(monkeypatch):
+    """65 536 chains x 1 024 params x 16 draws = 8.6 GB of draws through two staging blocks of two iterations each
+    (2.1 GB together): what the whole [C][T][D] block of a default 1 000-draw run could not do in 288 GB of HBM.
+    Every row must arrive, in the caller's [C][T][D] layout, and equal what a small batch of the same chains gets."""
+    C, D, T = 65536, 1024, 16
+    monkeypatch.setenv("WALNUTS_AMD_DRAW_STAGING_BYTES", str(2 * 2 * C * D * 8))
+    kw = dict(num_params=D, seed=21, min_warmup_iter=3, max_warmup_iter=3, min_sampling_iter=T, max_sampling_iter=T,
+              init_inv_metric=np.ones(D), step_size_init=0.5)
+    rng = np.random.default_rng(4)
+    inits = rng.normal(size=(C, D))
+    big = wa.walnuts_device(wa.MODEL_STD_NORMAL, num_chains=C, inits=inits, **kw)
+    assert len(big) == C and all(b.shape == (T, D) for b in big[:8])
+    for c in (0, 1, 777, C - 1):
+        x = np.asarray(big[c])
+        assert np.all(np.isfinite(x)) and np.any(x[1:] != x[:-1]), c   # every row arrived, and the chain moved
+    # chain-id keyed streams: the first 64 chains of the big run are a 64-chain run with the same job seed ...
+    # (walnutpy.cpp:82 keys the streams by seed + id + num_chains, so the small run compensates with its id)
+    small = wa.walnuts_device(wa.MODEL_STD_NORMAL, num_chains=64, inits=inits[:64], id=1 + C - 64, **kw)
+    for c in range(64):
+        assert np.array_equal(np.asarray(big[c]), np.asarray(small[c])), c
+
+
+def test_reference_summary_symbols_on_the_device(oracle):
+    rng = np.random.default_rng(3)
+    chains = sp.ar_chains(rng, 6, 130, [230, 170, 290, 201, 199, 333], rng.uniform(0, 0.95, size=130))
+    s = wa.Summarizer(chains)
+    assert np.array_equal(s.ess(), sp.wnso.effective_sample_size(chains))
+    assert np.array_equal(s.r_hat(), sp.wnso.r_hat(chains))
+    assert np.array_equal(s.mcse(), sp.wnso.monte_carlo_standard_error(chains))
+    assert np.allclose(s.mean(), np.mean(np.concatenate(chains), axis=0))

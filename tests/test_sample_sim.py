@@ -1,0 +1,79 @@
+"""CPU tier: the host logic of walnutpie_sample_device that round 2 added -- the chunked draw sink, the SIGINT
+guard (python/src/walnutpie/interrupts.hpp:34-102 -> error type `interrupt`) and the reference's three summary
+symbols (walnutpy.cpp:333-369) -- under the test-only workgroup emulation."""
+import os
+import signal
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpusim"))
+import build as simbuild  # noqa: E402
+import summary_parity as sp  # noqa: E402
+import walnuts_amd as wa  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return simbuild.build()
+
+
+def _run(sim, **kw):
+    args = dict(num_params=5, num_chains=3, seed=11, min_warmup_iter=4, max_warmup_iter=4, min_sampling_iter=7,
+                max_sampling_iter=7, save_warmup=True, save_inv_metric=True, lib_path=sim, refresh=0)
+    args.update(kw)
+    return wa.walnuts_device(wa.MODEL_STD_NORMAL, **args)
+
+
+@pytest.mark.timeout(600)
+def test_chunked_draw_sink_equals_one_block(sim, monkeypatch):
+    whole = _run(sim)
+    # staging blocks of 2 iterations (3 chains x 5 params x 8 bytes x 2 iterations x 2 blocks), then of 1
+    for budget in (3 * 5 * 8 * 2 * 2, 1):
+        monkeypatch.setenv("WALNUTS_AMD_DRAW_STAGING_BYTES", str(budget))
+        parts = _run(sim)
+        for a, b in zip(whole, parts):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+            assert np.array_equal(a.warmup.warmup_draws, b.warmup.warmup_draws)
+            assert a.warmup.stepsize == b.warmup.stepsize
+    assert np.asarray(whole[0]).shape == (7, 5) and whole[0].warmup.warmup_draws.shape == (4, 5)
+
+
+@pytest.mark.timeout(600)
+def test_sigint_ends_the_call_with_keyboard_interrupt(sim):
+    before = signal.getsignal(signal.SIGINT)
+    seen = []
+
+    def on_print(text):
+        seen.append(text)
+        if len(seen) == 2:
+            os.kill(os.getpid(), signal.SIGINT)   # what Ctrl-C does while the library call is running
+
+    with pytest.raises(KeyboardInterrupt):
+        _run(sim, max_warmup_iter=50, min_warmup_iter=50, refresh=1, print_callback=on_print)
+    assert 2 <= len(seen) <= 3 * 2 + 3, "the call must stop at the next iteration boundary"
+    assert signal.getsignal(signal.SIGINT) is before, "the previous SIGINT disposition must be restored"
+    _run(sim)  # and the library is usable afterwards
+
+
+@pytest.mark.timeout(600)
+def test_reference_summary_symbols(sim, oracle):
+    rng = np.random.default_rng(3)
+    chains = sp.ar_chains(rng, 3, 4, [23, 17, 29], np.array([0.9, 0.1, 0.5, 0.0]))
+    s = wa.Summarizer(chains, lib_path=sim)
+    assert np.array_equal(s.ess(), sp.wnso.effective_sample_size(chains))
+    assert np.array_equal(s.r_hat(), sp.wnso.r_hat(chains))
+    assert np.array_equal(s.mcse(), sp.wnso.monte_carlo_standard_error(chains))
+    # MarkovChainsUnified's own validation (summary.hpp:277-281): config error
+    import ctypes as C
+    lib = wa.load_library(sim)
+    draws = np.asfortranarray(np.concatenate(chains))
+    lengths = np.array([23, 17, 30], dtype=np.intc)
+    out, err = np.zeros(4), C.c_void_p()
+    rc = lib.walnutpie_ess(draws.ctypes.data_as(C.POINTER(C.c_double)), draws.shape[0], 4,
+                           lengths.ctypes.data_as(C.POINTER(C.c_int)), 3, out.ctypes.data_as(C.POINTER(C.c_double)),
+                           C.byref(err))
+    assert rc == -1 and lib.walnutpie_get_error_type(err) == 1
+    assert b"sum of chain_sizes" in lib.walnutpie_get_error_message(err)
+    lib.walnutpie_destroy_error(err)

@@ -11,4 +11,4 @@ from .engine import (MODEL_DIAG_NORMAL, MODEL_FUNNEL, MODEL_STD_NORMAL, DeviceEn
                      default_config)
 from .device import WalnutsOutputArray, WarmupInfo, walnuts_device  # noqa: F401
 from . import summary  # noqa: F401,E402
-from .summary import MarkovChains  # noqa: F401,E402
+from .summary import MarkovChains, Summarizer  # noqa: F401,E402

@@ -57,6 +57,9 @@ SYMBOLS = [
      [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
       _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
       _dp, _dp, _i32, PRINT_CALLBACK, _errpp]),
+    ("walnutpie_ess", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
+    ("walnutpie_r_hat", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
+    ("walnutpie_mcse", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("wn_default_config", None, [C.POINTER(Config)]),
     ("wn_engine_create", _i32, [C.POINTER(_vp), _i32, _i32, _dp, _sz, C.POINTER(Config), _errpp]),
     ("wn_engine_destroy", None, [_vp]),

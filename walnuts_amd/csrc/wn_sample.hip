@@ -16,6 +16,9 @@
 #include "wn_hip.h"
 
 #include <cmath>
+#include <csignal>
+#include <cstdlib>
+#include <cstring>
 #include <iomanip>
 #include <random>
 #include <sstream>
@@ -56,6 +59,115 @@ void finite_positive(double v, const char* name) {  // validate.hpp: validate_fi
 void probability(double v, const char* name) {  // validate.hpp: validate_probability
   if (!(v > 0 && v < 1)) throw std::invalid_argument(std::string(name) + " must be in (0, 1)");
 }
+
+// python/src/walnutpie/interrupts.hpp:34-102: while a sampling call runs, SIGINT sets a flag instead of killing
+// the process (SA_RESETHAND: a second Ctrl-C gets the previous disposition back); the previous handler is restored
+// on the way out.  The reference's controllers poll the flag (adapt.hpp:227, sampler.hpp:154); here it is polled
+// between the launches of two iterations, and a raised flag ends the call with error type `interrupt`
+// (errors.hpp:42-47: an empty message).
+struct InterruptException {};
+volatile std::sig_atomic_t wn_interrupted = 0;
+class InterruptGuard {
+ public:
+  InterruptGuard() {
+    wn_interrupted = 0;
+    std::memset(&custom_, 0, sizeof(custom_));
+    sigemptyset(&custom_.sa_mask);
+    sigaddset(&custom_.sa_mask, SIGINT);
+    custom_.sa_flags = SA_RESETHAND;
+    custom_.sa_handler = &InterruptGuard::on_signal;
+    sigaction(SIGINT, &custom_, &before_);
+  }
+  ~InterruptGuard() { sigaction(SIGINT, &before_, nullptr); }
+  InterruptGuard(const InterruptGuard&) = delete;
+  InterruptGuard& operator=(const InterruptGuard&) = delete;
+  void throw_if_interrupted() const {
+    if (wn_interrupted) throw InterruptException{};
+  }
+
+ private:
+  static void on_signal(int) { wn_interrupted = 1; }
+  struct sigaction before_, custom_;
+};
+
+// The draw sink (handlers.hpp:63-116 writes every draw straight into the caller's buffer, whatever its size).
+// The device writes the draws of up to `span` consecutive iterations of all chains into one of two staging blocks
+// [C][span][D]; a full block goes to the caller's out[C][rows][D] as ONE strided copy on a second stream while the
+// next iterations fill the other block, so the device never holds more than two blocks of draws and
+// [C][T][D] may exceed HBM (65 536 chains x 1 000 draws x 1 024 = 537 GB).
+class DrawSink {
+ public:
+  DrawSink(size_t chains, size_t rows, size_t dim, double* out, hipStream_t compute)
+      : C_(chains), rows_(rows), D_(dim), out_(out), compute_(compute) {
+    if (C_ * rows_ * D_ == 0) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t{1} << 30;
+    size_t budget = free_b / 4;  // both blocks together: a quarter of what the engine left
+    if (const char* env = std::getenv("WALNUTS_AMD_DRAW_STAGING_BYTES")) budget = std::strtoull(env, nullptr, 10);
+    const size_t per_iter = C_ * D_ * sizeof(double);
+    span_ = std::max<size_t>(1, std::min(rows_, budget / 2 / per_iter));
+    for (int b = 0; b < 2; ++b) {
+      if (hipMalloc(reinterpret_cast<void**>(&block_[b]), C_ * span_ * D_ * sizeof(double)) != hipSuccess)
+        throw std::runtime_error("cannot allocate the device draw staging buffer");
+      if (hipEventCreateWithFlags(&filled_[b], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&drained_[b], hipEventDisableTiming) != hipSuccess)
+        throw std::runtime_error("cannot create the draw-sink events");
+    }
+    if (hipStreamCreateWithFlags(&copy_, hipStreamNonBlocking) != hipSuccess)
+      throw std::runtime_error("cannot create the draw-sink stream");
+  }
+  ~DrawSink() {
+    for (int b = 0; b < 2; ++b) {
+      if (block_[b]) (void)hipFree(block_[b]);
+      if (filled_[b]) (void)hipEventDestroy(filled_[b]);
+      if (drained_[b]) (void)hipEventDestroy(drained_[b]);
+    }
+    if (copy_) (void)hipStreamDestroy(copy_);
+  }
+  size_t stride() const { return span_ * D_; }  // doubles between two chains' rows in a staging block
+  // where the next iteration's draws go (device pointer of chain 0's row)
+  double* next_row() {
+    if (fill_ == 0 && busy_[cur_]) {  // the block still feeds a copy: the kernels must not overwrite it yet
+      if (hipStreamWaitEvent(compute_, drained_[cur_], 0) != hipSuccess) throw std::runtime_error("draw sink: wait failed");
+      busy_[cur_] = false;
+    }
+    return block_[cur_] + fill_ * D_;
+  }
+  // the iteration launched into next_row() is queued on the compute stream
+  void row_done() {
+    ++fill_;
+    ++written_;
+    if (fill_ == span_) flush();
+  }
+  size_t written() const { return written_; }
+  // everything written so far is in the caller's buffer when this returns
+  void finish() {
+    if (fill_ > 0) flush();
+    if (copy_ && hipStreamSynchronize(copy_) != hipSuccess) throw std::runtime_error("copying draws to the host failed");
+  }
+
+ private:
+  void flush() {
+    const size_t first = written_ - fill_;
+    if (hipEventRecord(filled_[cur_], compute_) != hipSuccess ||
+        hipStreamWaitEvent(copy_, filled_[cur_], 0) != hipSuccess ||
+        hipMemcpy2DAsync(out_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_], span_ * D_ * sizeof(double),
+                         fill_ * D_ * sizeof(double), C_, hipMemcpyDeviceToHost, copy_) != hipSuccess ||
+        hipEventRecord(drained_[cur_], copy_) != hipSuccess)
+      throw std::runtime_error("copying draws to the host failed");
+    busy_[cur_] = true;
+    cur_ ^= 1;
+    fill_ = 0;
+  }
+  size_t C_, rows_, D_;
+  double* out_;
+  hipStream_t compute_, copy_ = nullptr;
+  double* block_[2] = {nullptr, nullptr};
+  hipEvent_t filled_[2] = {nullptr, nullptr}, drained_[2] = {nullptr, nullptr};
+  bool busy_[2] = {false, false};
+  size_t span_ = 1, fill_ = 0, written_ = 0;
+  int cur_ = 0;
+};
 
 struct Printer {  // python/src/walnutpie/handlers.hpp:17-59
   PRINT_CALLBACK print;
@@ -198,24 +310,14 @@ static int sample_device_impl(
       WN_CALL(wn_engine_seed(e, static_cast<uint64_t>(seed) + id + num_chains, 0u, &call_err_));
     }
 
-    // draws stay on the device in the caller's layout and come back in one copy
-    double* d_out = nullptr;
-    struct Free {
-      double** p;
-      ~Free() {
-        if (*p) (void)hipFree(*p);
-      }
-    } free_out{&d_out};
-    if (num_chains * draws_offset > 0) {
-      if (hipMalloc(reinterpret_cast<void**>(&d_out), num_chains * draws_offset * sizeof(double)) != hipSuccess)
-        throw std::runtime_error("cannot allocate the device draw buffer");
-    }
+    InterruptGuard interrupt;  // walnutpy.cpp: interrupt::walnutpy_interrupt_handler on the stack of the call
+    DrawSink sink(num_chains, rows, D, out, reinterpret_cast<hipStream_t>(wn_engine_stream(e)));
     Printer printer{print, static_cast<size_t>(refresh)};
-    size_t written = 0;
     for (int it = 1; it <= max_warmup_iter; ++it) {  // AdaptWorker loop, adapt.hpp:116-127
-      double* dst = save_warmup ? d_out + written * D : nullptr;
-      WN_CALL(wn_engine_warmup_step(e, dst, static_cast<int64_t>(draws_offset), &call_err_));
-      if (save_warmup) ++written;
+      interrupt.throw_if_interrupted();
+      double* dst = save_warmup ? sink.next_row() : nullptr;
+      WN_CALL(wn_engine_warmup_step(e, dst, static_cast<int64_t>(sink.stride()), &call_err_));
+      if (save_warmup) sink.row_done();
       printer.progress(num_chains);
       // controller_loop (adapt.hpp:172-229) on the snapshots published every publish_stride = 5 iterations
       if (it >= min_warmup_iter && it < max_warmup_iter && it % 5 == 0) {
@@ -224,17 +326,23 @@ static int sample_device_impl(
         if (rel_mass <= mass_converge_tol && rel_step <= step_size_converge_tol) break;
       }
     }
-    const size_t written_warmup = written;
+    const size_t written_warmup = sink.written();
     WN_CALL(wn_engine_freeze(e, &call_err_));  // on_warmup_complete, handlers.hpp:91-101
     printer.in_warmup = false;
     if (stepsize_out != nullptr) WN_CALL(wn_engine_get_step_sizes(e, stepsize_out, &call_err_));
     if (inv_metric_out != nullptr) WN_CALL(wn_engine_get_inv_mass(e, inv_metric_out, &call_err_));
     for (int it = 1; it <= max_sampling_iter; ++it) {  // ChainWorker loop, sampler.hpp:82-93
-      WN_CALL(wn_engine_sample_step(e, d_out + written * D, static_cast<int64_t>(draws_offset), &call_err_));
-      ++written;
+      interrupt.throw_if_interrupted();
+      WN_CALL(wn_engine_sample_step(e, sink.next_row(), static_cast<int64_t>(sink.stride()), &call_err_));
+      sink.row_done();
       printer.progress(num_chains);
-      // controller_loop (sampler.hpp:117-158): R-hat of the log density once every chain has min_iter draws
-      if (it >= min_sampling_iter && it >= 2 && it < max_sampling_iter && num_chains > 1) {
+      // controller_loop (sampler.hpp:117-158): R-hat of the log density once every chain has min_iter draws.  The
+      // reference's controller looks on a 1 ms timer, not after every draw: here every `rhat_stride` iterations
+      // (each look is a handful of small launches and a blocking read-back that would otherwise serialise every
+      // transition with the host).
+      constexpr int rhat_stride = 5;
+      if (it >= min_sampling_iter && it >= 2 && it < max_sampling_iter && num_chains > 1 &&
+          (it - min_sampling_iter) % rhat_stride == 0) {
         double rhat = 0;
         WN_CALL(wn_engine_rhat(e, &rhat, &call_err_));
         if (print != nullptr && refresh != 0) {
@@ -246,18 +354,17 @@ static int sample_device_impl(
         if (rhat <= rhat_converge_tol) break;
       }
     }
+    const size_t written = sink.written();
     WN_CALL(wn_engine_check(e, &call_err_));
-    if (num_chains * draws_offset > 0) {
-      if (hipMemcpyAsync(out, d_out, num_chains * draws_offset * sizeof(double), hipMemcpyDeviceToHost,
-                         reinterpret_cast<hipStream_t>(wn_engine_stream(e))) != hipSuccess ||
-          hipStreamSynchronize(reinterpret_cast<hipStream_t>(wn_engine_stream(e))) != hipSuccess)
-        throw std::runtime_error("copying draws to the host failed");
-    }
+    sink.finish();
+    interrupt.throw_if_interrupted();
     for (size_t c = 0; c < num_chains; ++c) {  // walnutpy.cpp:215-218
       final_lengths[c] = static_cast<int>(written_warmup);
       final_lengths[c + num_chains] = static_cast<int>(written - written_warmup);
     }
     return 0;
+  } catch (const InterruptException&) {
+    if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error("", interrupt));
   } catch (const std::invalid_argument& ex) {
     if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error(ex.what(), config));
   } catch (const std::exception& ex) {
@@ -290,4 +397,61 @@ static int sample_device_impl(
 extern "C" int walnutpie_sample_device(WN_SAMPLE_PARAMS) { return sample_device_impl(false, WN_SAMPLE_ARGS); }
 extern "C" int walnutpie_sample_device_reference_streams(WN_SAMPLE_PARAMS) {
   return sample_device_impl(true, WN_SAMPLE_ARGS);
+}
+
+// ---- walnutpie_ess / walnutpie_r_hat / walnutpie_mcse (walnutpy.cpp:333-369) ----------------------------------
+// The reference's ctypes layer binds these three with (draws, num_draws, num_params, lengths, num_chains, out, err);
+// `draws` is what Eigen::Map<const MatrixXd>(draws, num_draws, num_params) reads (walnutpy.cpp:89): a COLUMN-major
+// num_draws x num_params matrix of the stacked chains.  Same symbols and arguments here: the draws are uploaded in
+// the device layout, summarised by wn_summary_* (wn_summary.hip) and the num_params results copied back.
+namespace {
+template <class F>
+int summary_shim(const double* draws, int num_draws, int num_params, const int* lengths, int num_chains, double* out,
+                 WalnutpyError** err, F summarise) {
+  try {
+    if (draws == nullptr || lengths == nullptr || out == nullptr) throw std::invalid_argument("null argument");
+    if (num_draws < 0 || num_params < 1 || num_chains < 1) throw std::invalid_argument("sizes must be positive");
+    std::vector<int64_t> sizes(static_cast<size_t>(num_chains));
+    int64_t total = 0;
+    for (int m = 0; m < num_chains; ++m) {
+      sizes[m] = lengths[m];
+      total += lengths[m];
+    }
+    if (total != num_draws)  // MarkovChainsUnified, summary.hpp:266-280
+      throw std::invalid_argument("The number of rows in draws and sum of chain_sizes must be equal.");
+    const size_t N = static_cast<size_t>(num_draws), D = static_cast<size_t>(num_params);
+    std::vector<double> rows(N * D);  // [draw][param]
+    for (size_t d = 0; d < D; ++d)
+      for (size_t n = 0; n < N; ++n) rows[n * D + d] = draws[d * N + n];
+    wn_chains* ch = nullptr;
+    WN_CALL(wn_chains_upload(&ch, rows.data(), D, sizes.data(), static_cast<size_t>(num_chains), 0, &call_err_));
+    struct Guard {
+      wn_chains* c;
+      ~Guard() { wn_chains_destroy(c); }
+    } guard{ch};
+    WN_CALL(summarise(ch, out, &call_err_));
+    return 0;
+  } catch (const std::invalid_argument& ex) {
+    if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error(ex.what(), config));
+  } catch (const std::exception& ex) {
+    if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error(ex.what(), generic));
+  } catch (...) {
+    if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error("Unknown error", generic));
+  }
+  return -1;
+}
+}  // namespace
+
+extern "C" int walnutpie_ess(const double* draws, int num_draws, int num_params, const int* lengths, int num_chains,
+                             double* out, WalnutpyError** err) {
+  return summary_shim(draws, num_draws, num_params, lengths, num_chains, out, err, wn_summary_effective_sample_size);
+}
+extern "C" int walnutpie_r_hat(const double* draws, int num_draws, int num_params, const int* lengths, int num_chains,
+                               double* out, WalnutpyError** err) {
+  return summary_shim(draws, num_draws, num_params, lengths, num_chains, out, err, wn_summary_r_hat);
+}
+extern "C" int walnutpie_mcse(const double* draws, int num_draws, int num_params, const int* lengths, int num_chains,
+                              double* out, WalnutpyError** err) {
+  return summary_shim(draws, num_draws, num_params, lengths, num_chains, out, err,
+                      wn_summary_monte_carlo_standard_error);
 }

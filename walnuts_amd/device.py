@@ -96,6 +96,7 @@ def walnuts_device(
     refresh: int = 0,
     reference_streams: bool = False,
     lib_path: Optional[str] = None,
+    print_callback=None,
 ) -> list:
     lib = _ffi.load_library(lib_path)
     if inits is not None:
@@ -125,7 +126,11 @@ def walnuts_device(
     inv_metric_out = np.zeros((num_chains, num_params), dtype=np.float64) if save_inv_metric else None
 
     def _print(msg, length, bad):
-        print(msg[:length].decode("utf-8", "replace"), end="", flush=True)
+        text = msg[:length].decode("utf-8", "replace")
+        if print_callback is not None:
+            print_callback(text)
+        else:
+            print(text, end="", flush=True)
 
     cb = _ffi.PRINT_CALLBACK(_print)
     dp = _ffi._dp

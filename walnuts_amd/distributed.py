@@ -21,14 +21,22 @@ def shard_chains(total_chains: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 class DrawGather:
-    """Double-buffered asynchronous all-gather of the per-iteration draw plane [C_local, D]."""
+    """Double-buffered asynchronous all-gather of the per-iteration draw plane.
 
-    def __init__(self, dist, world: int, chains_local: int, dim: int, device, dtype):
+    Rank r writes its shard's draws into `buffer(it)` ([rows, D]; rows = the largest shard, so that every rank
+    contributes an equally sized block -- `all_gather_into_tensor` needs that -- and uneven shards cost only padding
+    rows).  `result(it)` is the gathered [total_chains, D] block in global chain order."""
+
+    def __init__(self, dist, world: int, rank: int, total_chains: int, dim: int, device, dtype, counts=None):
         import torch
 
-        self.dist, self.world = dist, world
-        self.local = [torch.empty((chains_local, dim), dtype=dtype, device=device) for _ in range(2)]
-        self.gathered = ([torch.empty((world * chains_local, dim), dtype=dtype, device=device) for _ in range(2)]
+        self.dist, self.world, self.rank = dist, world, rank
+        self.counts = list(counts) if counts is not None else [shard_chains(total_chains, r, world)[1]
+                                                                for r in range(world)]
+        self.rows = max(self.counts)
+        self.even = all(c == self.rows for c in self.counts)
+        self.local = [torch.empty((self.rows, dim), dtype=dtype, device=device) for _ in range(2)]
+        self.gathered = ([torch.empty((world * self.rows, dim), dtype=dtype, device=device) for _ in range(2)]
                          if world > 1 else None)
         self.pending: List[Optional[object]] = [None, None]
 
@@ -49,12 +57,18 @@ class DrawGather:
         return self.gathered[b]
 
     def result(self, it: int):
-        """Gathered draws of iteration `it` ([world*C_local, D]; the local plane when world == 1)."""
+        """Gathered draws of iteration `it` in global chain order ([total_chains, D])."""
+        import torch
+
         b = it & 1
         if self.pending[b] is not None:
             self.pending[b].wait()
             self.pending[b] = None
-        return self.local[b] if self.world == 1 else self.gathered[b]
+        if self.world == 1:
+            return self.local[b][: self.counts[0]]
+        if self.even:
+            return self.gathered[b]
+        return torch.cat([self.gathered[b][r * self.rows: r * self.rows + c] for r, c in enumerate(self.counts)])
 
     def drain(self):
         for b in (0, 1):

@@ -128,3 +128,47 @@ def effective_sample_size(chains: MarkovChains) -> np.ndarray:
 
 def monte_carlo_standard_error(chains: MarkovChains) -> np.ndarray:
     return chains._vec(chains.lib.wn_summary_monte_carlo_standard_error, (chains.dims(),))
+
+
+class Summarizer:
+    """The reference's ``walnutpie.Summarizer`` (python/src/walnutpie/summary.py:11-150) on the device library: the
+    simple statistics in numpy, ``ess`` / ``r_hat`` / ``mcse`` through the same three C symbols the reference's
+    ctypes layer binds (``walnutpie_ess``, ``walnutpie_r_hat``, ``walnutpie_mcse``, walnutpy.cpp:333-369).  Those
+    read ``draws`` as Eigen::Map<const MatrixXd>(draws, num_draws, num_params) does, i.e. column-major, so the
+    stacked draws are handed over in Fortran order."""
+
+    def __init__(self, draws, lib_path: Optional[str] = None):
+        mats = [np.asarray(c, dtype=np.float64) for c in draws]
+        self._stacked = np.concatenate(mats)
+        self._num_draws, self._num_params = self._stacked.shape
+        self._lengths = np.array([c.shape[0] for c in mats], dtype=np.intc)
+        self._num_chains = len(mats)
+        self.lib = _ffi.load_library(lib_path)
+
+    def mean(self):
+        return np.mean(self._stacked, axis=0)
+
+    def variance(self):
+        return np.var(self._stacked, axis=0, ddof=1)
+
+    def standard_deviation(self):
+        return np.std(self._stacked, axis=0, ddof=1)
+
+    def _call(self, fn):
+        col_major = np.asfortranarray(self._stacked)
+        out = np.zeros((self._num_params,))
+        err = C.c_void_p()
+        rc = fn(col_major.ctypes.data_as(_dp), self._num_draws, self._num_params,
+                self._lengths.ctypes.data_as(C.POINTER(C.c_int)), self._num_chains, out.ctypes.data_as(_dp),
+                C.byref(err))
+        _ffi.check(self.lib, rc, err)
+        return out
+
+    def ess(self) -> np.ndarray:
+        return self._call(self.lib.walnutpie_ess)
+
+    def r_hat(self) -> np.ndarray:
+        return self._call(self.lib.walnutpie_r_hat)
+
+    def mcse(self) -> np.ndarray:
+        return self._call(self.lib.walnutpie_mcse)

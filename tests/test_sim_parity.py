@@ -180,3 +180,26 @@ def test_emulated_sample_device_output_buffer_check(sim):
     assert msg.startswith("Output buffer too small. Expected at least 2 chains of 10 doubles, got 10")
     assert lib.walnutpie_get_error_type(err) == 0  # generic (std::runtime_error), walnutpy.cpp:153-160
     lib.walnutpie_destroy_error(err)
+
+
+@pytest.mark.timeout(600)
+def test_emulated_device_errors_are_sticky(sim, oracle):
+    # host-fed uniforms that run out inside a transition: reported by wn_engine_check, and NOT forgotten when a
+    # later transition of the same engine is clean (the per-transition report, depth -1, is overwritten)
+    D, Cn = 6, 2
+    dev = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, Cn, wa.default_config(sim), lib_path=sim)
+    rng = np.random.default_rng(2)
+    dev.set_positions(rng.normal(size=(Cn, D)))
+    dev.set_step_sizes(0.4)
+    dev.seed_chains(1, 0)
+    dev.freeze()
+    dev.sample_step()
+    dev.check()                                   # nothing wrong so far
+    dev.set_variates(rng.normal(size=(Cn, D)), rng.uniform(size=(Cn, 1)))   # one uniform: not enough for a tree
+    dev.sample_step()
+    with pytest.raises(RuntimeError, match="host-fed uniforms"):
+        dev.check()
+    dev.sample_step()                             # counter-based stream again: a clean transition
+    assert np.all(dev.depths() >= 1)
+    with pytest.raises(RuntimeError, match="host-fed uniforms"):
+        dev.check()

@@ -209,14 +209,6 @@ static __global__ void fill_kernel(double* p, long long n, double v) {
        i += static_cast<long long>(gridDim.x) * blockDim.x)
     p[i] = v;
 }
-// number of chains whose last transition ran out of span-pool buffers (depth_out == -1)
-static __global__ void count_failed_kernel(const int32_t* depth, int n, unsigned long long* out) {
-  unsigned long long acc = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += depth[i] < 0 ? 1u : 0u;
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
-}
-
 static __global__ void sum_i64_kernel(const int64_t* v, int n, unsigned long long* out) {
   unsigned long long acc = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)

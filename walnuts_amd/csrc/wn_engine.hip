@@ -53,7 +53,7 @@ struct wn_engine {
   DevBuf<double> lp_stats, mon_partial, mon_out, mon_colsum, mon_rel_mass, mon_rel_step;
   DevBuf<int32_t> min_micro, depth, rng_draws;
   DevBuf<int64_t> grad_evals;
-  DevBuf<uint32_t> counter;
+  DevBuf<uint32_t> counter, error_flags;
   DevBuf<unsigned long long> scratch64;
 
   uint64_t seed = 0;
@@ -67,9 +67,11 @@ struct wn_engine {
   int u_stride = 0;
   std::unique_ptr<ReferenceStreams> ref_streams;
 
-  // one HIP event pair per transition launch since the last timing reset
+  // HIP event pairs around the transition launches: a fixed ring (the last kEventRing launches since the last
+  // timing reset can be read back), created once
+  static constexpr size_t kEventRing = 1024;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  size_t events_used = 0;
+  size_t events_used = 0;  // launches since the last timing reset
   bool own_stream = true;
 
   ~wn_engine() {
@@ -81,13 +83,14 @@ struct wn_engine {
   }
 
   std::pair<hipEvent_t, hipEvent_t>& next_events() {
-    if (events_used == events.size()) {
+    const size_t slot = events_used++ % kEventRing;
+    if (slot == events.size()) {
       hipEvent_t a, b;
       HIP_OK(hipEventCreate(&a));
       HIP_OK(hipEventCreate(&b));
       events.emplace_back(a, b);
     }
-    return events[events_used++];
+    return events[slot];
   }
 
   void use_device() { HIP_OK(hipSetDevice(device)); }
@@ -122,21 +125,17 @@ struct wn_engine {
     hipLaunchKernelGGL(wn::fill_kernel, dim3(blocks), dim3(256), 0, stream, b.p, static_cast<long long>(b.n), v);
     HIP_OK(hipGetLastError());
   }
-  // throws if any chain's last transition exhausted the span pool (reported by the kernel as depth -1)
+  // throws if ANY transition of any chain since the engine was created reported a device-side error: the kernels
+  // OR their error bits into one word that later transitions never clear
   void check_transitions() {
     use_device();
-    HIP_OK(hipMemsetAsync(scratch64.p, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(wn::count_failed_kernel, dim3(std::min<size_t>(256, (C + 255) / 256)), dim3(256), 0, stream, depth.p, static_cast<int>(C),
-                       scratch64.p);
-    HIP_OK(hipGetLastError());
-    unsigned long long bad = 0;
-    HIP_OK(hipMemcpyAsync(&bad, scratch64.p, sizeof(bad), hipMemcpyDeviceToHost, stream));
+    uint32_t flags = 0;
+    HIP_OK(hipMemcpyAsync(&flags, error_flags.p, sizeof(flags), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
-    if (bad != 0) {
-      std::stringstream ss;
-      ss << bad << " chain(s) exhausted the span pool; raise max pool or lower max_trajectory_doublings";
-      throw std::runtime_error(ss.str());
-    }
+    if (flags & wn::kErrPoolExhausted)
+      throw std::runtime_error("a chain exhausted the span pool: its draws are not valid (lower max_trajectory_doublings)");
+    if (flags & wn::kErrVariatesExhausted)
+      throw std::runtime_error("a transition consumed more host-fed uniforms than wn_engine_set_variates supplied");
   }
 
   void ensure_adapters() {
@@ -203,6 +202,7 @@ struct wn_engine {
     P.pool_lds = pool_lds;
     P.pool_total = pool_total;
     P.work_counter = counter.p;
+    P.error_flags = error_flags.p;
     return P;
   }
 
@@ -333,6 +333,8 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.rng_draws.alloc(num_chains);
   e.grad_evals.alloc(num_chains);
   e.counter.alloc(1);
+  e.error_flags.alloc(1);
+  HIP_OK(hipMemsetAsync(e.error_flags.p, 0, sizeof(uint32_t), e.stream));
   e.lp_stats.alloc(3 * num_chains);
   e.mon_partial.alloc(2 * wn::kMonitorBlocks);
   e.mon_out.alloc(4);
@@ -449,10 +451,12 @@ int wn_engine_create(wn_engine** out, int model, int num_params, const double* m
 void wn_engine_destroy(wn_engine* e) { delete e; }
 
 int wn_engine_set_positions(wn_engine* e, const double* positions, WalnutpyError** err) {
-  return guarded(err, [&] { e->upload_rows(e->theta, positions, 0.0); });
+  return guarded(err, [&] {
+    if (e == nullptr || positions == nullptr) throw std::invalid_argument("null argument"); e->upload_rows(e->theta, positions, 0.0); });
 }
 int wn_engine_set_masses(wn_engine* e, const double* masses, WalnutpyError** err) {
   return guarded(err, [&] {
+    if (e == nullptr || masses == nullptr) throw std::invalid_argument("null argument");
     for (size_t i = 0; i < e->C * static_cast<size_t>(e->D); ++i)
       if (!(masses[i] > 0) || !std::isfinite(masses[i])) throw std::invalid_argument("masses must be positive and finite");
     e->fill(e->mass, 1.0);
@@ -462,6 +466,7 @@ int wn_engine_set_masses(wn_engine* e, const double* masses, WalnutpyError** err
 }
 int wn_engine_set_step_sizes(wn_engine* e, const double* steps, WalnutpyError** err) {
   return guarded(err, [&] {
+    if (e == nullptr || steps == nullptr) throw std::invalid_argument("null argument");
     for (size_t i = 0; i < e->C; ++i)
       if (!(steps[i] > 0) || !std::isfinite(steps[i])) throw std::invalid_argument("step size must be positive and finite");
     e->use_device();
@@ -496,7 +501,8 @@ int wn_engine_average_masses(wn_engine* e, WalnutpyError** err) {
   });
 }
 int wn_engine_get_masses(wn_engine* e, double* out, WalnutpyError** err) {
-  return guarded(err, [&] { e->download_rows(e->mass, out); });
+  return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download_rows(e->mass, out); });
 }
 int wn_engine_adapt_step(wn_engine* e, uint64_t seed, uint32_t chain_offset, WalnutpyError** err) {
   return guarded(err, [&] { run_init(*e, false, false, true, 1.0, 0.0, 0, 0, seed, chain_offset); });
@@ -546,6 +552,7 @@ int wn_engine_seed_reference_streams(wn_engine* e, uint64_t seed, WalnutpyError*
 int wn_engine_set_variates(wn_engine* e, const double* normals, const double* uniforms, int u_per_chain,
                            WalnutpyError** err) {
   return guarded(err, [&] {
+    if (e == nullptr || normals == nullptr || uniforms == nullptr) throw std::invalid_argument("null argument");
     if (u_per_chain < 1) throw std::invalid_argument("u_per_chain must be positive");
     e->use_device();
     if (e->z_buf.n == 0) e->z_buf.alloc(e->C * static_cast<size_t>(e->Dp));
@@ -569,6 +576,7 @@ int wn_engine_warmup_step(wn_engine* e, double* draws_dev, int64_t draws_stride,
 }
 int wn_engine_freeze(wn_engine* e, WalnutpyError** err) {
   return guarded(err, [&] {
+    if (e == nullptr) throw std::invalid_argument("null argument");
     e->ensure_adapters();
     e->use_device();
     const int blocks = static_cast<int>(std::min<size_t>((e->C * e->Dp + 255) / 256, 4096));
@@ -595,14 +603,17 @@ int wn_engine_synchronize(wn_engine* e, WalnutpyError** err) {
   });
 }
 int wn_engine_check(wn_engine* e, WalnutpyError** err) {
-  return guarded(err, [&] { e->check_transitions(); });
+  return guarded(err, [&] {
+    if (e == nullptr) throw std::invalid_argument("null argument"); e->check_transitions(); });
 }
 
 int wn_engine_get_positions(wn_engine* e, double* out, WalnutpyError** err) {
-  return guarded(err, [&] { e->download_rows(e->theta, out); });
+  return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download_rows(e->theta, out); });
 }
 int wn_engine_get_inv_mass(wn_engine* e, double* out, WalnutpyError** err) {
   return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument");
     if (!e->frozen) {
       e->ensure_adapters();
       e->use_device();
@@ -616,6 +627,7 @@ int wn_engine_get_inv_mass(wn_engine* e, double* out, WalnutpyError** err) {
 }
 int wn_engine_get_step_sizes(wn_engine* e, double* out, WalnutpyError** err) {
   return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument");
     if (e->frozen) {
       e->download(e->step_size, out, e->C);
     } else if (e->adapters_ready) {
@@ -628,10 +640,12 @@ int wn_engine_get_step_sizes(wn_engine* e, double* out, WalnutpyError** err) {
   });
 }
 int wn_engine_get_logp(wn_engine* e, double* out, WalnutpyError** err) {
-  return guarded(err, [&] { e->download(e->logp, out, e->C); });
+  return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download(e->logp, out, e->C); });
 }
 int wn_engine_get_min_micro(wn_engine* e, int32_t* out, WalnutpyError** err) {
   return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument");
     if (e->frozen) {
       e->download(e->min_micro, out, e->C);
     } else {
@@ -645,16 +659,20 @@ int wn_engine_get_min_micro(wn_engine* e, int32_t* out, WalnutpyError** err) {
   });
 }
 int wn_engine_get_depths(wn_engine* e, int32_t* out, WalnutpyError** err) {
-  return guarded(err, [&] { e->download(e->depth, out, e->C); });
+  return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download(e->depth, out, e->C); });
 }
 int wn_engine_get_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err) {
-  return guarded(err, [&] { e->download(e->grad_evals, out, e->C); });
+  return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download(e->grad_evals, out, e->C); });
 }
 int wn_engine_get_rng_draws(wn_engine* e, int32_t* out, WalnutpyError** err) {
-  return guarded(err, [&] { e->download(e->rng_draws, out, e->C); });
+  return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download(e->rng_draws, out, e->C); });
 }
 int wn_engine_get_adam(wn_engine* e, double* out, WalnutpyError** err) {
-  return guarded(err, [&] { e->download(e->adam, out, 6 * e->C); });
+  return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download(e->adam, out, 6 * e->C); });
 }
 int wn_engine_get_estimator(wn_engine* e, double* dm, double* ds, double* sm, double* ss, double* w,
                             WalnutpyError** err) {
@@ -801,11 +819,14 @@ int wn_engine_timing_reset(wn_engine* e, WalnutpyError** err) {
 int wn_engine_kernel_times(wn_engine* e, float* ms_out, int max_launches, int* num_launches, WalnutpyError** err) {
   return guarded(err, [&] {
     e->use_device();
-    const int n = static_cast<int>(e->events_used);
+    // the last min(launches, ring) launches since the reset, oldest first
+    const size_t have = std::min(e->events_used, wn_engine::kEventRing);
+    const int n = static_cast<int>(have);
     if (num_launches) *num_launches = n;
     for (int i = 0; i < n && i < max_launches; ++i) {
-      HIP_OK(hipEventSynchronize(e->events[i].second));
-      HIP_OK(hipEventElapsedTime(&ms_out[i], e->events[i].first, e->events[i].second));
+      const size_t slot = (e->events_used - have + static_cast<size_t>(i)) % wn_engine::kEventRing;
+      HIP_OK(hipEventSynchronize(e->events[slot].second));
+      HIP_OK(hipEventElapsedTime(&ms_out[i], e->events[slot].first, e->events[slot].second));
     }
   });
 }

@@ -75,6 +75,12 @@ struct Params {
   int32_t pool_lds;      // vector buffers living in LDS
   int32_t pool_total;    // LDS + register + arena buffers
   uint32_t* work_counter;
+  uint32_t* error_flags;  // sticky: OR of kErr* bits of every chain and transition since the engine was created
+};
+
+enum : uint32_t {
+  kErrPoolExhausted = 1u,    // a chain needed more span-pool vectors than the engine holds
+  kErrVariatesExhausted = 2u // host-fed uniforms (wn_engine_set_variates) ran out inside a transition
 };
 
 }  // namespace wn

@@ -177,6 +177,14 @@ struct Printer {  // python/src/walnutpie/handlers.hpp:17-59
   void progress(size_t num_chains) {
     ++iter;
     if (refresh == 0 || print == nullptr || iter % refresh != 0) return;
+    if (num_chains > 16) {  // lock-step chains: one line for all of them instead of 65 536 callbacks per refresh
+      std::stringstream ss;
+      ss << "Chains [1-" << num_chains << "]: Iteration " << iter << "\t" << (in_warmup ? "(Warmup)" : "(Sampling)")
+         << std::endl;
+      const std::string s = ss.str();
+      print(s.c_str(), s.length(), false);
+      return;
+    }
     for (size_t c = 0; c < num_chains; ++c) {
       std::stringstream ss;
       ss << "Chain [" << (c + 1) << "]: Iteration " << iter << "\t" << (in_warmup ? "(Warmup)" : "(Sampling)")

@@ -652,6 +652,10 @@ struct TrajBase {
         w[1] = mean;
         w[2] += delta * (lpsel - mean);
       }
+      // host-fed uniforms: a transition that consumed more than were supplied used the filler value
+      if (Q.rng_mode == kRngBuffer && n_draw > Q.u_stride) err |= static_cast<int>(kErrVariatesExhausted);
+      // the per-transition report (depth -1) is overwritten by the next transition; the engine-wide word is not
+      if (err) atomicOr(Q.error_flags, static_cast<uint32_t>(err));
       Q.logp_out[chain] = lpsel;
       Q.depth_out[chain] = err ? -1 : depth;
       Q.grad_evals[chain] += n_grad;

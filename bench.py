@@ -60,7 +60,7 @@ def parse():
                     help="strong: --chains is the job's total, sharded over the GPUs (north star); weak: per GPU")
     ap.add_argument("--config", type=int, default=0, help="5 = BASELINE config #5 (262 144 chains, sharded)")
     ap.add_argument("--dim", type=int, default=1024)
-    ap.add_argument("--model", default="std_normal", choices=["std_normal", "diag_normal", "ill_normal", "funnel"],
+    ap.add_argument("--model", default="std_normal", choices=["std_normal", "diag_normal", "ill_normal", "funnel", "rw1"],
                     help="diag_normal: sigma_d = 1 + (d mod 16) (config #4); ill_normal: sigma_d = d + 1 (config #2, "
                          "examples/examples.cpp:20-31)")
     ap.add_argument("--adapt-iters", type=int, default=100, help="untimed adaptive warmup transitions")
@@ -93,6 +93,8 @@ def model_setup(name, D):
         return wa.MODEL_STD_NORMAL, None
     if name == "funnel":
         return wa.MODEL_FUNNEL, None
+    if name == "rw1":
+        return wa.MODEL_RW1, None   # examples/examples.cpp:34-49 through the public model interface
     if name == "ill_normal":
         return wa.MODEL_DIAG_NORMAL, np.array([(d + 1.0) ** 2 for d in range(D)])
     return wa.MODEL_DIAG_NORMAL, np.array([(1.0 + (d % 16)) ** 2 for d in range(D)])
@@ -102,7 +104,7 @@ def oracle_model(name):
     import wno
 
     return {"std_normal": wno.MODEL_STD_NORMAL, "diag_normal": wno.MODEL_DIAG_NORMAL,
-            "ill_normal": wno.MODEL_DIAG_NORMAL, "funnel": wno.MODEL_FUNNEL}[name]
+            "ill_normal": wno.MODEL_DIAG_NORMAL, "funnel": wno.MODEL_FUNNEL, "rw1": wno.MODEL_RW1}[name]
 
 
 def csrc_sha():

@@ -52,7 +52,9 @@ typedef void (*PRINT_CALLBACK)(const char* msg, size_t len, bool bad);
 typedef enum {
   WN_MODEL_STD_NORMAL = 0,  /* examples/walnutpie_api.cpp:37-41; no parameters            */
   WN_MODEL_DIAG_NORMAL = 1, /* examples/examples.cpp:20-31; params = sigma_sq[num_params]  */
-  WN_MODEL_FUNNEL = 2       /* Neal's funnel, x0 ~ N(0,9), x_i ~ N(0,e^x0); no parameters  */
+  WN_MODEL_FUNNEL = 2,      /* Neal's funnel, x0 ~ N(0,9), x_i ~ N(0,e^x0); no parameters  */
+  WN_MODEL_RW1 = 3          /* examples/examples.cpp:34-49, AR(1) covariance rho^|i-j|, rho = 0.99; added through the
+                               public model interface (csrc/models/rw1.h); further models: wn_model_id()        */
 } wn_model;
 
 /* ---- replaces walnutpie_sample_cfunc (walnutpy.cpp:134-149) ------------------- */
@@ -114,6 +116,10 @@ typedef struct wn_config {
 } wn_config;
 
 WALNUTS_HIP_EXPORT void wn_default_config(wn_config* cfg);
+/* Device models are compiled into the library and entered into a registry by their translation units
+ * (walnuts_amd/csrc/wn_model_api.h; INTEGRATION.md "Adding a device model").  -> the id registered under `name`
+ * ("std_normal" 0, "diag_normal" 1, "funnel" 2, "rw1" 3, ...), or -1. */
+WALNUTS_HIP_EXPORT int wn_model_id(const char* name);
 
 /* model_params: host pointer (copied). */
 WALNUTS_HIP_EXPORT int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params,

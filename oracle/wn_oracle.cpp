@@ -144,6 +144,34 @@ struct Model {
         for (size_t i = 1; i < D; ++i) g[i] = -(x[i] * ev);
         break;
       }
+      case WNO_MODEL_RW1: {
+        // examples/examples.cpp:34-49: normal(0, Sigma), Sigma[i,j] = rho^|i-j|, rho = 0.99
+        const double rho = 0.99;
+        const double sigma_sq = 1.0 - rho * rho;
+        const double inv_sigma_sq = 1.0 / sigma_sq;
+        if (m.mode == WNO_MATH_PORTABLE) {
+          // device arithmetic: the log density is -0.5 * (sum of the per-coordinate terms, device summation order)
+          logp = -0.5 * r.sum(D, [&](size_t n) {
+            if (n == 0) return x[0] * x[0];
+            const double rr = x[n] - rho * x[n - 1];
+            return rr * (rr * inv_sigma_sq);
+          });
+        } else {
+          logp = -0.5 * x[0] * x[0];
+          for (size_t n = 1; n < D; ++n) {
+            const double rr = x[n] - rho * x[n - 1];
+            const double w = rr * inv_sigma_sq;
+            logp -= 0.5 * rr * w;
+          }
+        }
+        // grad[n] = (0 - w[n]) + rho * w[n + 1] in both modes (element-wise: no summation order involved)
+        for (size_t n = 0; n < D; ++n) {
+          double gn = n == 0 ? -x[0] : -((x[n] - rho * x[n - 1]) * inv_sigma_sq);
+          if (n + 1 < D) gn = gn + rho * ((x[n + 1] - rho * x[n]) * inv_sigma_sq);
+          g[n] = gn;
+        }
+        break;
+      }
       default:
         logp = -kInf;
         for (size_t i = 0; i < D; ++i) g[i] = 0.0;

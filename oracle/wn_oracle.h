@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-enum { WNO_MODEL_STD_NORMAL = 0, WNO_MODEL_DIAG_NORMAL = 1, WNO_MODEL_FUNNEL = 2 };
+enum { WNO_MODEL_STD_NORMAL = 0, WNO_MODEL_DIAG_NORMAL = 1, WNO_MODEL_FUNNEL = 2, WNO_MODEL_RW1 = 3 };
 enum { WNO_MATH_LIBM = 0, WNO_MATH_PORTABLE = 1 };
 enum { WNO_RNG_STD_MT64 = 0, WNO_RNG_STD_MT32 = 1, WNO_RNG_PHILOX = 2 };
 

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libwn_oracle.so")
 
-MODEL_STD_NORMAL, MODEL_DIAG_NORMAL, MODEL_FUNNEL = 0, 1, 2
+MODEL_STD_NORMAL, MODEL_DIAG_NORMAL, MODEL_FUNNEL, MODEL_RW1 = 0, 1, 2, 3
 MATH_LIBM, MATH_PORTABLE = 0, 1
 RNG_STD_MT64, RNG_STD_MT32, RNG_PHILOX = 0, 1, 2
 STREAM_MOMENTUM, STREAM_TREE, STREAM_INIT_POS, STREAM_INIT_STEP = 0, 1, 2, 3

@@ -7,13 +7,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "walnuts_amd", "csrc")
 OUT = os.path.join(HERE, "libwalnuts_sim.so")
-SOURCES = ["wn_engine.hip", "wn_sample.hip", "wn_summary.hip", "wn_kernels_std_normal.hip", "wn_kernels_diag_normal.hip",
-           "wn_kernels_funnel.hip"]
+SOURCES = ["wn_engine.hip", "wn_sample.hip", "wn_summary.hip"] + sorted(
+    f for f in os.listdir(CSRC) if f.startswith("wn_kernels_") and f.endswith(".hip"))  # one per device model
 
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [
+        os.path.join(CSRC, "models", f) for f in os.listdir(os.path.join(CSRC, "models"))] + [
         os.path.join(HERE, "wn_cpusim.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT

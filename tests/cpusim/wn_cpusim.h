@@ -116,6 +116,16 @@ template <class T>
 inline T __shfl(T v, int src, int = 64) {
   return wnsim::exchange(v, (wnsim::tidx.x & ~63u) + static_cast<unsigned>(src));
 }
+template <class T>
+inline T __shfl_up(T v, unsigned delta, int = 64) {  // lanes below `delta` keep their own value, as on the device
+  const unsigned l = wnsim::tidx.x & 63u;
+  return wnsim::exchange(v, (wnsim::tidx.x & ~63u) + (l >= delta ? l - delta : l));
+}
+template <class T>
+inline T __shfl_down(T v, unsigned delta, int = 64) {
+  const unsigned l = wnsim::tidx.x & 63u, top = std::min(63u, wnsim::bdim.x - 1 - (wnsim::tidx.x & ~63u));
+  return wnsim::exchange(v, (wnsim::tidx.x & ~63u) + (l + delta <= top ? l + delta : l));
+}
 inline void __syncthreads() { wnsim::sync(); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }

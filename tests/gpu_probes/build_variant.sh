@@ -3,8 +3,8 @@
 # usage: build_variant.sh <name> "<flags>"
 set -e
 HERE=$(cd $(dirname $0) && pwd); CS=$HERE/../../walnuts_amd/csrc; D=/tmp/wn_variant_$1; mkdir -p $D
-for f in wn_engine wn_sample wn_summary wn_kernels_std_normal wn_kernels_diag_normal wn_kernels_funnel; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -DWN_FAST_BUILD $2 -c $CS/$f.hip -o $D/$f.o &
+for f in wn_engine wn_sample wn_summary $(cd $CS && ls wn_kernels_*.hip | sed s/.hip//); do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -I$CS -DWN_FAST_BUILD $2 -c $CS/$f.hip -o $D/$f.o &
 done; wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o $HERE/libwalnuts_$1.so $D/*.o
 echo built $HERE/libwalnuts_$1.so

@@ -14,7 +14,8 @@ import wno
 
 MODELS = {"std_normal": (wa.MODEL_STD_NORMAL, wno.MODEL_STD_NORMAL),
           "diag_normal": (wa.MODEL_DIAG_NORMAL, wno.MODEL_DIAG_NORMAL),
-          "funnel": (wa.MODEL_FUNNEL, wno.MODEL_FUNNEL)}
+          "funnel": (wa.MODEL_FUNNEL, wno.MODEL_FUNNEL),
+          "rw1": (wa.MODEL_RW1, wno.MODEL_RW1)}
 
 CFG_FIELDS = ("max_trajectory_doublings", "max_step_halvings", "min_micro_steps", "max_hamiltonian_error",
               "mass_init_count", "max_macro_steps_target", "step_accept_rate_target", "step_learning_rate",

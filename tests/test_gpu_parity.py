@@ -57,6 +57,10 @@ def _need_gpu(gpu):
     ("diag_normal", 130, 64, (1, 4)),
     ("funnel", 128, 128, None),             # config #3
     ("funnel", 1000, 32, (4, 4)),           # cross-wavefront reductions inside the model
+    ("funnel", 1024, 48, None),             # general-gradient path at the headline dimension: (1,16)
+    ("rw1", 1024, 48, None),                # 4th model, added through csrc/models/rw1.h: neighbour-coupled gradient
+    ("rw1", 200, 64, (2, 2)),               # ... wavefront edges through LDS
+    ("rw1", 2000, 16, (4, 8)),               # ... pair-row wrap-around across four wavefronts
     ("diag_normal", 16384, 12, None),       # config #4 dimension: streaming backend (vectors in HBM)
     ("std_normal", 20000, 8, (8, -1)),      # streaming, 8 wavefronts per chain, ragged last tile
     ("std_normal", 1000, 24, (2, -1)),      # streaming forced at a small dimension

@@ -203,3 +203,15 @@ def test_emulated_device_errors_are_sticky(sim, oracle):
     assert np.all(dev.depths() >= 1)
     with pytest.raises(RuntimeError, match="host-fed uniforms"):
         dev.check()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("D,geometry", [(9, None), (131, (1, 4)), (150, (2, 2))])
+def test_emulated_fourth_model_added_through_the_model_interface(sim, oracle, D, geometry):
+    """rw1 (the reference's examples/examples.cpp:34-49) lives in csrc/models/rw1.h + a five-line .hip file: no edit
+    of the kernels.  Its gradient couples neighbouring coordinates (cx.shift: lane shuffles, wavefront edges through
+    LDS, pair-row wrap-around) and is kept as a vector -- the general path of the register kernels."""
+    assert wa.model_id("rw1", lib_path=sim) == wa.MODEL_RW1 and wa.model_id("std_normal", lib_path=sim) == 0
+    with pytest.raises(ValueError):
+        wa.model_id("no_such_model", lib_path=sim)
+    parity.run_case("rw1", D, 2, warmup=3, sampling=3, lib_path=sim, geometry=geometry)

@@ -7,7 +7,7 @@ Everything runs through ``walnuts_amd/lib/libwalnuts_hip.so`` (hand-written HIP 
 CPU fallback: importing the binding without the built library raises.
 """
 from ._ffi import WalnutsHipError, load_library  # noqa: F401
-from .engine import (MODEL_DIAG_NORMAL, MODEL_FUNNEL, MODEL_STD_NORMAL, DeviceEngine,  # noqa: F401
+from .engine import (MODEL_DIAG_NORMAL, MODEL_FUNNEL, MODEL_RW1, MODEL_STD_NORMAL, DeviceEngine, model_id,  # noqa: F401
                      default_config)
 from .device import WalnutsOutputArray, WarmupInfo, walnuts_device  # noqa: F401
 from . import summary  # noqa: F401,E402

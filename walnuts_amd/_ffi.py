@@ -61,6 +61,7 @@ SYMBOLS = [
     ("walnutpie_r_hat", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("walnutpie_mcse", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("wn_default_config", None, [C.POINTER(Config)]),
+    ("wn_model_id", _i32, [C.c_char_p]),
     ("wn_engine_create", _i32, [C.POINTER(_vp), _i32, _i32, _dp, _sz, C.POINTER(Config), _errpp]),
     ("wn_engine_destroy", None, [_vp]),
     ("wn_engine_set_positions", _i32, [_vp, _dp, _errpp]),

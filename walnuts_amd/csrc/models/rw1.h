@@ -1,0 +1,55 @@
+// models/rw1.h -- a device model added through the public model interface (wn_model_api.h), as a user would:
+// the reference's AR(1) "random walk" example density, examples/examples.cpp:34-49,
+//     p(y) = normal(y | 0, Sigma),  Sigma[i, j] = rho^|i - j|,  rho = 0.99,
+// whose gradient couples NEIGHBOURING coordinates: grad[n] = -w[n] + rho * w[n + 1], w[n] = (y[n] - rho * y[n - 1]) / (1 - rho^2).
+// Nothing about it is element-wise or cheap, so it exercises the general path of the kernels: the gradient vector is
+// kept (two more register vectors per trajectory-end set), parked and reloaded with the span ends, and every
+// evaluation needs a cross-lane exchange (cx.shift).
+#pragma once
+
+#include "../wn_model_api.h"
+
+namespace wn {
+
+struct Rw1Model {
+  static constexpr bool kUsesParams = false;
+  static constexpr bool kElementwise = false;
+  static constexpr bool kGradIsNegTheta = false;
+  static constexpr bool kCheapGrad = false;
+  __device__ __forceinline__ static double grad_elem(double, double) { return 0.0; }
+  struct Aux {};
+
+  template <int EPL, class Cx>
+  __device__ __forceinline__ static void eval(Cx& cx, const double (&y)[EPL], double (&g)[EPL], const double (&)[EPL],
+                                              Aux&, double& acc) {
+    constexpr double rho = 0.99;
+    const double sigma_sq = 1.0 - rho * rho;       // examples.cpp:37-38
+    const double inv_sigma_sq = 1.0 / sigma_sq;
+    double prev[EPL], next[EPL];
+    cx.shift(y, prev, next);                        // y[n - 1] and y[n + 1] of every coordinate this lane owns
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      const int n = cx.index(j);
+      double term, gj;
+      if (n == 0) {
+        term = y[j] * y[j];                         // logp = -0.5 * y[0] * y[0]; grad[0] -= y[0]
+        gj = -y[j];
+      } else {
+        const double r = y[j] - rho * prev[j];      // examples.cpp:43-46
+        const double w = r * inv_sigma_sq;
+        term = r * w;
+        gj = -w;
+      }
+      if (n + 1 < cx.dim()) {                       // grad[n] += rho * w[n + 1] (examples.cpp:47)
+        const double r1 = next[j] - rho * y[j];
+        gj = gj + rho * (r1 * inv_sigma_sq);
+      }
+      const bool in = cx.valid(j);
+      g[j] = in ? gj : 0.0;
+      acc += in ? term : 0.0;
+    }
+  }
+  __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return -0.5 * sum; }
+};
+
+}  // namespace wn

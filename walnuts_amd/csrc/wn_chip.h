@@ -51,7 +51,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
   using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::wave;
   using Base::chain; using Base::aux; using Base::n_grad; using Base::n_draw; using Base::draw_base; using Base::err;
   using Base::max_error; using Base::min_micro; using Base::step; using Base::free_mask; using Base::onchip_mask;
-  using Base::w_draw0; using Base::w_score0; using Base::meta; using Base::carry;
+  using Base::w_draw0; using Base::w_score0; using Base::meta; using Base::carry; using Base::bcast;
   static constexpr int L = Base::L;
   static constexpr int NP = EPL / 2;
   static constexpr int kDp = L * EPL;  // padded dimension: a compile-time constant of the geometry
@@ -92,6 +92,45 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
   template <int S>
   __device__ __forceinline__ double G(int j) const {
     return kNoGrad ? Model::grad_elem(th[S][j], mp[j]) : g[S][j];
+  }
+
+  // Neighbours in coordinate order, for models whose gradient couples adjacent coordinates (wn_model_api.h):
+  // prev[j] = v at coordinate index(j) - 1, next[j] = v at index(j) + 1, 0.0 beyond either end of the padded vector.
+  // Slot pairs are consecutive coordinates, so half of the neighbours are the lane's own; the others are the
+  // adjacent lane's (a lane shuffle), the adjacent wavefront's edge lane (through LDS) or the adjacent pair row's.
+  __device__ __forceinline__ void shift(const double (&v)[EPL], double (&prev)[EPL], double (&next)[EPL]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      prev[2 * k + 1] = v[2 * k];
+      next[2 * k] = v[2 * k + 1];
+    }
+    WN_LDS double* sh = this->bcast + 2;  // [pair slot][wavefront][first lane's even | last lane's odd]
+    if (NW > 1) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (lane == 0) sh[(k * NW + wave) * 2] = v[2 * k];
+        if (lane == 63) sh[(k * NW + wave) * 2 + 1] = v[2 * k + 1];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      // pair m - 1's odd element / pair m + 1's even element, m = k * L + tid
+      const double up = __shfl_up(v[2 * k + 1], 1, 64);
+      const double dn = __shfl_down(v[2 * k], 1, 64);
+      double left_edge, right_edge;  // what lane 0 / lane 63 of this wavefront take instead
+      if (NW == 1) {
+        left_edge = k > 0 ? __shfl(v[2 * (k > 0 ? k - 1 : 0) + 1], 63, 64) : 0.0;
+        right_edge = k + 1 < NP ? __shfl(v[2 * (k + 1 < NP ? k + 1 : k)], 0, 64) : 0.0;
+      } else {
+        const bool first = wave == 0, last = wave == NW - 1;
+        left_edge = !first ? sh[(k * NW + wave - 1) * 2 + 1] : (k > 0 ? sh[((k - 1) * NW + NW - 1) * 2 + 1] : 0.0);
+        right_edge = !last ? sh[(k * NW + wave + 1) * 2] : (k + 1 < NP ? sh[((k + 1) * NW) * 2] : 0.0);
+      }
+      prev[2 * k] = lane == 0 ? left_edge : up;
+      next[2 * k + 1] = lane == 63 ? right_edge : dn;
+    }
+    if (NW > 1) __syncthreads();  // the scratch is free again
   }
 
   // ---- vector buffers -----------------------------------------------------------------------------

@@ -271,7 +271,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
                   const wn_config& cfg) {
   if (num_params < 1) throw std::invalid_argument("num_params must be positive");
   if (num_chains < 1) throw std::invalid_argument("num_chains must be positive");
-  if (model < 0 || model > 2) throw std::invalid_argument("unknown device model id");
+  const wn::ModelOps& ops = wn::model_ops(model);  // throws for an id no model registered
   if (cfg.max_trajectory_doublings < 1) throw std::invalid_argument("max_nuts_depth must be positive");
   if (cfg.max_trajectory_doublings > wn::kMaxLevels + 1)
     throw std::invalid_argument("max_trajectory_doublings exceeds the device span stack");
@@ -279,16 +279,16 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   if (cfg.min_micro_steps < 1) throw std::invalid_argument("min_micro_steps must be positive");
   if (!(cfg.max_hamiltonian_error > 0) || !std::isfinite(cfg.max_hamiltonian_error))
     throw std::invalid_argument("max_hamiltonian_error must be positive and finite");
-  if (model == WN_MODEL_DIAG_NORMAL && model_params == nullptr)
-    throw std::invalid_argument("diag-normal model needs sigma_sq[num_params]");
-  if (model == WN_MODEL_FUNNEL && num_params < 2) throw std::invalid_argument("funnel needs num_params >= 2");
+  if (ops.uses_params && model_params == nullptr)
+    throw std::invalid_argument(std::string(ops.name) + " model needs a parameter vector of num_params doubles");
+  ops.validate(num_params);
 
   e.model = model;
   e.D = num_params;
   e.C = num_chains;
   e.cfg = cfg;
   e.device = cfg.device;
-  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, model != WN_MODEL_FUNNEL);
+  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane);
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
@@ -362,14 +362,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   {
     std::vector<double> mp(e.Dp, 1.0);
     if (model_params) std::copy(model_params, model_params + num_params, mp.begin());
-    if (model == WN_MODEL_DIAG_NORMAL) {
-      // the kernels multiply by 1/sigma_sq, rounded once here, instead of dividing by sigma_sq at every gradient
-      // evaluation (an fp64 division costs about ten multiply-adds on the device; DESIGN.md "differs on purpose")
-      for (int i = 0; i < num_params; ++i) {
-        if (!(mp[i] > 0) || !std::isfinite(mp[i])) throw std::invalid_argument("sigma_sq must be positive and finite");
-        mp[i] = 1.0 / mp[i];
-      }
-    }
+    ops.host_params(mp.data(), num_params);  // the model's own validation / transformation (wn_models.h)
     HIP_OK(hipMemcpyAsync(e.model_params.p, mp.data(), mp.size() * sizeof(double), hipMemcpyHostToDevice, e.stream));
     HIP_OK(hipStreamSynchronize(e.stream));
   }
@@ -416,6 +409,15 @@ const char* walnutpie_get_error_message(const WalnutpyError* err) {
 }
 WalnutpyErrorType walnutpie_get_error_type(const WalnutpyError* err) { return err == nullptr ? generic : err->type; }
 void walnutpie_destroy_error(WalnutpyError* err) { delete err; }
+
+int wn_model_id(const char* name) {
+  if (name == nullptr) return -1;
+  for (int i = 0; i < wn::kMaxModels; ++i) {
+    const wn::ModelOps* ops = wn::model_table()[i];
+    if (ops != nullptr && std::strcmp(ops->name, name) == 0) return i;
+  }
+  return -1;
+}
 
 void wn_default_config(wn_config* c) {
   c->max_trajectory_doublings = 5;
@@ -841,7 +843,8 @@ int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {
 }
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {
   try {
-    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, model != WN_MODEL_FUNNEL).nw;
+    (void)model;
+    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane).nw;
   } catch (...) {
     return -1;
   }

@@ -64,7 +64,7 @@ inline bool geometry_exists(int nw, int epl) {
 }
 
 // elems_per_lane == -1 requests the streaming backend explicitly (it is the default above kMaxRegisterDim)
-inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_model = true) {
+inline Geometry choose_geometry(int dim, int nw_req, int epl_req) {
   Geometry g{0, 0, false};
   if (epl_req < 0 || (dim > kMaxRegisterDim && epl_req == 0)) {
     g.mem = true;
@@ -83,7 +83,6 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool light_mod
   // every reduction of a multi-wavefront chain is an LDS exchange behind a barrier, so ONE wavefront per chain wins
   // as long as the vectors fit its registers (16 elements per lane = 1024 dimensions: 2.43 ms against 2.57 ms for
   // two wavefronts on the headline workload); beyond that, as few wavefronts as possible
-  (void)light_model;
   static const int pref_all[][2] = {{1, 2}, {1, 4}, {1, 8}, {1, 16}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
   const int(*pref)[2] = pref_all;
   const int npref = 8;
@@ -118,59 +117,49 @@ inline int padded_dim(const Geometry& g, int dim) {
   return ((dim + 2 * lanes - 1) / (2 * lanes)) * 2 * lanes;
 }
 
-// defined once per model in wn_kernels_<model>.hip
-#define WN_DECLARE_MODEL(tag)                                                                              \
-  void launch_transition_##tag(const Geometry&, int grid, size_t smem, hipStream_t, const Params&);        \
-  void launch_init_##tag(const Geometry&, int grid, size_t smem, hipStream_t, const InitParams&);          \
-  void prepare_##tag(const Geometry&, size_t smem);                                                        \
-  int register_pool_##tag(const Geometry&);                                                                \
-  int waves_per_simd_##tag(const Geometry&);
-WN_DECLARE_MODEL(std_normal)
-WN_DECLARE_MODEL(diag_normal)
-WN_DECLARE_MODEL(funnel)
-#undef WN_DECLARE_MODEL
-
+// ---- model registry -----------------------------------------------------------------------------------
+// One entry per device model, filled in by the model's own translation unit (WN_REGISTER_MODEL in
+// wn_model_api.h) when the library is loaded.  Nothing else in the host code names a model: adding one is
+// writing its header and a three-line .hip file ("Adding a device model").
+struct ModelOps {
+  int id;
+  const char* name;
+  bool uses_params;   // needs a parameter vector of num_params doubles
+  bool elementwise;   // has streaming (num_params > 8192) kernels
+  void (*launch_transition)(const Geometry&, int grid, size_t smem, hipStream_t, const Params&);
+  void (*launch_init)(const Geometry&, int grid, size_t smem, hipStream_t, const InitParams&);
+  void (*prepare)(const Geometry&, size_t smem);
+  int (*register_pool)(const Geometry&);
+  int (*waves_per_simd)(const Geometry&);
+  void (*host_params)(double* params, int num_params);  // validate / transform the parameter vector before upload
+  void (*validate)(int num_params);
+};
+constexpr int kMaxModels = 64;
+inline const ModelOps** model_table() {
+  static const ModelOps* table[kMaxModels] = {};
+  return table;
+}
+inline bool register_model(const ModelOps* ops) {
+  if (ops->id < 0 || ops->id >= kMaxModels) throw std::invalid_argument("device model id out of range");
+  if (model_table()[ops->id] != nullptr) throw std::invalid_argument("device model id registered twice");
+  model_table()[ops->id] = ops;
+  return true;
+}
+inline const ModelOps& model_ops(int model) {
+  if (model < 0 || model >= kMaxModels || model_table()[model] == nullptr)
+    throw std::invalid_argument("unknown device model id");
+  return *model_table()[model];
+}
 inline void launch_transition(int model, const Geometry& g, int grid, size_t smem, hipStream_t s, const Params& p) {
-  switch (model) {
-    case kStdNormal: launch_transition_std_normal(g, grid, smem, s, p); break;
-    case kDiagNormal: launch_transition_diag_normal(g, grid, smem, s, p); break;
-    case kFunnel: launch_transition_funnel(g, grid, smem, s, p); break;
-    default: throw std::invalid_argument("unknown device model id");
-  }
+  model_ops(model).launch_transition(g, grid, smem, s, p);
 }
 inline void launch_init(int model, const Geometry& g, int grid, size_t smem, hipStream_t s, const InitParams& q) {
-  switch (model) {
-    case kStdNormal: launch_init_std_normal(g, grid, smem, s, q); break;
-    case kDiagNormal: launch_init_diag_normal(g, grid, smem, s, q); break;
-    case kFunnel: launch_init_funnel(g, grid, smem, s, q); break;
-    default: throw std::invalid_argument("unknown device model id");
-  }
+  model_ops(model).launch_init(g, grid, smem, s, q);
 }
 // pool vectors the register kernel of this model / geometry keeps in VGPRs (0 for the streaming kernels)
-inline int register_pool(int model, const Geometry& g) {
-  switch (model) {
-    case kStdNormal: return register_pool_std_normal(g);
-    case kDiagNormal: return register_pool_diag_normal(g);
-    case kFunnel: return register_pool_funnel(g);
-    default: throw std::invalid_argument("unknown device model id");
-  }
-}
+inline int register_pool(int model, const Geometry& g) { return model_ops(model).register_pool(g); }
 // wavefronts per SIMD the register kernel of this model / geometry is compiled for (its VGPR budget)
-inline int waves_per_simd(int model, const Geometry& g) {
-  switch (model) {
-    case kStdNormal: return waves_per_simd_std_normal(g);
-    case kDiagNormal: return waves_per_simd_diag_normal(g);
-    case kFunnel: return waves_per_simd_funnel(g);
-    default: throw std::invalid_argument("unknown device model id");
-  }
-}
-inline void prepare_kernels(int model, const Geometry& g, size_t smem) {
-  switch (model) {
-    case kStdNormal: prepare_std_normal(g, smem); break;
-    case kDiagNormal: prepare_diag_normal(g, smem); break;
-    case kFunnel: prepare_funnel(g, smem); break;
-    default: throw std::invalid_argument("unknown device model id");
-  }
-}
+inline int waves_per_simd(int model, const Geometry& g) { return model_ops(model).waves_per_simd(g); }
+inline void prepare_kernels(int model, const Geometry& g, size_t smem) { model_ops(model).prepare(g, smem); }
 
 }  // namespace wn

@@ -1,0 +1,128 @@
+// wn_models.h -- the built-in device models: what a target density looks like to the kernels.
+//
+// A device model is the LogpGrad contract of the reference (concepts.hpp:258-262, C form LOGP_CFUNC
+// walnutpy.cpp:131-132: f(theta) -> (logp, grad)) as a struct of static device functions that the transition
+// kernels are instantiated with, so that the gradient is compiled INTO the trajectory loop.  The contract is spelled
+// out in wn_model_api.h; models of your own go into their own header next to a five-line .hip file
+// ("Adding a device model") -- nothing in this file or in the kernels has to change.
+#pragma once
+
+#include <cmath>
+#include <stdexcept>
+
+#include "wn_devmath.h"
+#include "wn_hip.h"
+#include "wn_params.h"
+
+namespace wn {
+
+// ---- target densities (device form of the LogpGrad contract, concepts.hpp:258-262) ----
+// eval():   writes grad for the lane's elements and ADDS the lane's log-density terms, in index order,
+//           to `acc` (the running per-lane partial); may reduce internally through cx.
+// finish(): turns the reduced sum into logp.
+struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
+  static constexpr int kKind = kStdNormal;
+  static constexpr bool kUsesParams = false;
+  static constexpr bool kElementwise = true;
+  // grad = -theta: the register kernels carry no gradient vector at all (a sign modifier on theta at every use)
+  static constexpr bool kGradIsNegTheta = true;
+  static constexpr bool kCheapGrad = true;
+  __device__ __forceinline__ static double grad_elem(double th, double) { return -th; }
+  struct Aux {};
+  template <int EPL, class Cx>
+  __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
+                                              const double (&)[EPL], Aux&, double& acc) {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      g[j] = -th[j];
+      acc += th[j] * th[j];
+    }
+  }
+  // element-wise models: the gradient alone, the same expression eval() uses (so the same bits)
+  template <int EPL, class Cx>
+  __device__ __forceinline__ static void grad(Cx&, const double (&th)[EPL], double (&g)[EPL], const double (&)[EPL],
+                                              Aux&) {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) g[j] = -th[j];
+  }
+  __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return -0.5 * sum; }
+};
+
+// The device receives 1/sigma_sq (rounded once on the host, wn_engine_create) and multiplies where the reference's
+// example divides: (-0.5 x x) * (1/s2) and -x * (1/s2) -- within an ulp of the quotients, a third of the instructions.
+struct DiagNormalModel {  // examples/examples.cpp:20-31, params = 1 / sigma_sq
+  static constexpr int kKind = kDiagNormal;
+  static constexpr bool kUsesParams = true;
+  static constexpr bool kElementwise = true;
+  static constexpr bool kGradIsNegTheta = false;
+  // one multiply per element: cheaper to recompute at each use than to keep, park and reload a gradient vector
+  static constexpr bool kCheapGrad = true;
+  __device__ __forceinline__ static double grad_elem(double th, double rs2) { return -th * rs2; }
+  struct Aux {};
+  template <int EPL, class Cx>
+  __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
+                                              const double (&rs2)[EPL], Aux&, double& acc) {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      g[j] = -th[j] * rs2[j];
+      acc += -0.5 * th[j] * th[j] * rs2[j];
+    }
+  }
+  template <int EPL, class Cx>
+  __device__ __forceinline__ static void grad(Cx&, const double (&th)[EPL], double (&g)[EPL],
+                                              const double (&rs2)[EPL], Aux&) {
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) g[j] = -th[j] * rs2[j];
+  }
+  __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return sum; }
+  // host side, before the parameter vector is uploaded: sigma_sq -> 1 / sigma_sq, rounded once (an fp64 division costs
+  // about ten multiply-adds on the device; DESIGN.md "differs on purpose")
+  static void host_params(double* sigma_sq, int num_params) {
+    for (int i = 0; i < num_params; ++i) {
+      if (!(sigma_sq[i] > 0) || !std::isfinite(sigma_sq[i])) throw std::invalid_argument("sigma_sq must be positive and finite");
+      sigma_sq[i] = 1.0 / sigma_sq[i];
+    }
+  }
+};
+
+struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the reference)
+  static constexpr int kKind = kFunnel;
+  static constexpr bool kUsesParams = false;
+  static constexpr bool kElementwise = false;  // the gradient needs sum(x^2): register backend only
+  static constexpr bool kGradIsNegTheta = false;
+  static constexpr bool kCheapGrad = false;
+  __device__ __forceinline__ static double grad_elem(double, double) { return 0.0; }
+  struct Aux {
+    double v, S, hev;
+  };
+  template <int EPL, class Cx>
+  __device__ __forceinline__ static void eval(Cx& cx, const double (&th)[EPL], double (&g)[EPL],
+                                              const double (&)[EPL], Aux& aux, double&) {
+    const double v = cx.element0(th[0]);
+    double sp = 0.0;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) sp += (cx.index(j) == 0) ? 0.0 : th[j] * th[j];
+    const double S = cx.sum1(sp);
+    const double ev = wnd::dexp(-v, cx.uniform_tab());
+    const double hd = 0.5 * static_cast<double>(cx.dim() - 1);
+    const double hev = 0.5 * ev;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      double gj = -(th[j] * ev);
+      if (cx.index(j) == 0) gj = ((-v / 9.0) + hev * S) - hd;
+      g[j] = cx.valid(j) ? gj : 0.0;
+    }
+    aux.v = v;
+    aux.S = S;
+    aux.hev = hev;
+  }
+  __device__ __forceinline__ static double finish(double, const Aux& a, int D) {
+    const double hd = 0.5 * static_cast<double>(D - 1);
+    return ((-(a.v * a.v) / 18.0) - a.hev * a.S) - hd * a.v;
+  }
+  static void validate(int num_params) {
+    if (num_params < 2) throw std::invalid_argument("funnel needs num_params >= 2");
+  }
+};
+
+}  // namespace wn

@@ -38,6 +38,7 @@
 #include "wn_hip.h"
 
 #include "wn_devmath.h"
+#include "wn_models.h"
 #include "wn_params.h"
 
 namespace wn {
@@ -149,104 +150,6 @@ __device__ __forceinline__ double log_sum_exp(double x1, double x2, const Tab& t
   const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
   return m + wnd::dlog(1.0 + wnd::dexp(d, tab), tab);
 }
-
-// ---- target densities (device form of the LogpGrad contract, concepts.hpp:258-262) ----
-// eval():   writes grad for the lane's elements and ADDS the lane's log-density terms, in index order,
-//           to `acc` (the running per-lane partial); may reduce internally through cx.
-// finish(): turns the reduced sum into logp.
-struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
-  static constexpr int kKind = kStdNormal;
-  static constexpr bool kUsesParams = false;
-  static constexpr bool kElementwise = true;
-  // grad = -theta: the register kernels carry no gradient vector at all (a sign modifier on theta at every use)
-  static constexpr bool kGradIsNegTheta = true;
-  static constexpr bool kCheapGrad = true;
-  __device__ __forceinline__ static double grad_elem(double th, double) { return -th; }
-  struct Aux {};
-  template <int EPL, class Cx>
-  __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
-                                              const double (&)[EPL], Aux&, double& acc) {
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      g[j] = -th[j];
-      acc += th[j] * th[j];
-    }
-  }
-  // element-wise models: the gradient alone, the same expression eval() uses (so the same bits)
-  template <int EPL, class Cx>
-  __device__ __forceinline__ static void grad(Cx&, const double (&th)[EPL], double (&g)[EPL], const double (&)[EPL],
-                                              Aux&) {
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) g[j] = -th[j];
-  }
-  __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return -0.5 * sum; }
-};
-
-// The device receives 1/sigma_sq (rounded once on the host, wn_engine_create) and multiplies where the reference's
-// example divides: (-0.5 x x) * (1/s2) and -x * (1/s2) -- within an ulp of the quotients, a third of the instructions.
-struct DiagNormalModel {  // examples/examples.cpp:20-31, params = 1 / sigma_sq
-  static constexpr int kKind = kDiagNormal;
-  static constexpr bool kUsesParams = true;
-  static constexpr bool kElementwise = true;
-  static constexpr bool kGradIsNegTheta = false;
-  // one multiply per element: cheaper to recompute at each use than to keep, park and reload a gradient vector
-  static constexpr bool kCheapGrad = true;
-  __device__ __forceinline__ static double grad_elem(double th, double rs2) { return -th * rs2; }
-  struct Aux {};
-  template <int EPL, class Cx>
-  __device__ __forceinline__ static void eval(Cx&, const double (&th)[EPL], double (&g)[EPL],
-                                              const double (&rs2)[EPL], Aux&, double& acc) {
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      g[j] = -th[j] * rs2[j];
-      acc += -0.5 * th[j] * th[j] * rs2[j];
-    }
-  }
-  template <int EPL, class Cx>
-  __device__ __forceinline__ static void grad(Cx&, const double (&th)[EPL], double (&g)[EPL],
-                                              const double (&rs2)[EPL], Aux&) {
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) g[j] = -th[j] * rs2[j];
-  }
-  __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return sum; }
-};
-
-struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the reference)
-  static constexpr int kKind = kFunnel;
-  static constexpr bool kUsesParams = false;
-  static constexpr bool kElementwise = false;  // the gradient needs sum(x^2): register backend only
-  static constexpr bool kGradIsNegTheta = false;
-  static constexpr bool kCheapGrad = false;
-  __device__ __forceinline__ static double grad_elem(double, double) { return 0.0; }
-  struct Aux {
-    double v, S, hev;
-  };
-  template <int EPL, class Cx>
-  __device__ __forceinline__ static void eval(Cx& cx, const double (&th)[EPL], double (&g)[EPL],
-                                              const double (&)[EPL], Aux& aux, double&) {
-    const double v = cx.element0(th[0]);
-    double sp = 0.0;
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) sp += (cx.index(j) == 0) ? 0.0 : th[j] * th[j];
-    const double S = cx.sum1(sp);
-    const double ev = wnd::dexp(-v, cx.uniform_tab());
-    const double hd = 0.5 * static_cast<double>(cx.dim() - 1);
-    const double hev = 0.5 * ev;
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      double gj = -(th[j] * ev);
-      if (cx.index(j) == 0) gj = ((-v / 9.0) + hev * S) - hd;
-      g[j] = cx.valid(j) ? gj : 0.0;
-    }
-    aux.v = v;
-    aux.S = S;
-    aux.hev = hev;
-  }
-  __device__ __forceinline__ static double finish(double, const Aux& a, int D) {
-    const double hd = 0.5 * static_cast<double>(D - 1);
-    return ((-(a.v * a.v) / 18.0) - a.hev * a.S) - hd * a.v;
-  }
-};
 
 // ---- optional phase profiler (tests/gpu_probes only; compiled out of the product build) -------------
 #if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
@@ -1236,7 +1139,7 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(tail + (threadIdx.x >> 6) * kMetaDoubles);
   WN_LDS double* red = tail + NW * kMetaDoubles;
   WN_LDS double* bcast = red + kRedDoubles(NW);
-  WN_LDS int* next_chain = (WN_LDS int*)(bcast + 1);
+  WN_LDS int* next_chain = (WN_LDS int*)(bcast + 1);  // (the shift scratch of TrajChip follows at bcast + 2)
   double* arena = P.arena + static_cast<long long>(blockIdx.x) * P.arena_stride;
 
   T t(P, pool, meta, red, bcast, arena);
@@ -1271,8 +1174,11 @@ __global__ __launch_bounds__(64 * NW) void transition_kernel_mem(const Params P)
   persistent_loop<TrajMem<Model, NW>, NW>(P);
 }
 
+// cx.shift() scratch: the edge lanes of every wavefront publish one value per pair slot (at most 8 pairs per lane)
+constexpr int kShiftDoubles(int nw) { return 2 * 8 * nw; }
 inline size_t transition_smem_bytes(int nw, int lds_vectors, int dim_padded) {
-  return (static_cast<size_t>(lds_vectors) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + kRedDoubles(nw) + 2) *
+  return (static_cast<size_t>(lds_vectors) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + kRedDoubles(nw) + 2 +
+          kShiftDoubles(nw)) *
          sizeof(double);
 }
 

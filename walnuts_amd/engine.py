@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _ffi
 
-MODEL_STD_NORMAL, MODEL_DIAG_NORMAL, MODEL_FUNNEL = 0, 1, 2
+MODEL_STD_NORMAL, MODEL_DIAG_NORMAL, MODEL_FUNNEL, MODEL_RW1 = 0, 1, 2, 3
 _dp = _ffi._dp
 
 
@@ -26,6 +26,14 @@ def default_config(lib_path: Optional[str] = None, **overrides) -> _ffi.Config:
             raise AttributeError(k)
         setattr(cfg, k, v)
     return cfg
+
+
+def model_id(name: str, lib_path: Optional[str] = None) -> int:
+    """Id of the device model registered under `name` (see walnuts_amd/csrc/wn_model_api.h); ValueError if none."""
+    i = _ffi.load_library(lib_path).wn_model_id(name.encode())
+    if i < 0:
+        raise ValueError(f"no device model named {name!r} in this build of the library")
+    return i
 
 
 def _f64(a) -> np.ndarray:

@@ -288,7 +288,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.C = num_chains;
   e.cfg = cfg;
   e.device = cfg.device;
-  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane);
+  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params);
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
@@ -843,8 +843,7 @@ int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {
 }
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {
   try {
-    (void)model;
-    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane).nw;
+    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, wn::model_ops(model).uses_params).nw;
   } catch (...) {
     return -1;
   }

@@ -31,6 +31,7 @@
 #define __shared__ static
 #define WN_LDS
 typedef double v2f64 __attribute__((vector_size(16)));
+#define WN_VEC_OF(N) __attribute__((vector_size(8 * (N))))
 
 struct dim3 {
   unsigned x, y, z;
@@ -134,6 +135,33 @@ inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v)
 }
 using std::fabs;
 using std::fmax;
+
+// ---- the platform layer's names (walnuts_amd/csrc/wn_gfx950.h) over the emulation --------------
+namespace wn {
+// the emulation pays one OS thread per lane: keep its launches small
+constexpr int kMonitorBlocks = 2;
+constexpr int kSummaryBlock = 64;
+constexpr int kSummaryLagSlabChains = 256;
+constexpr int kSummaryCandidateCap = 8;
+inline int uni(int v) { return wnsim::readfirstlane(v); }
+inline double uni(double v) { return wnsim::readfirstlane(v); }
+inline double lane_value(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+inline double wave_sum(double v) {  // xor butterfly, offsets 32,1,2,4,8,16: the device's association order
+  v = v + __shfl_xor(v, 32, 64);
+  for (int off = 1; off < 32; off <<= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+inline double wave_sum_packed(double a, double b) {  // a's total in lanes 0-31, b's in lanes 32-63
+  const double sa = wave_sum(a), sb = wave_sum(b);
+  return (wnsim::tidx.x & 63u) < 32u ? sa : sb;
+}
+inline int opaque_thread_id() { return static_cast<int>(wnsim::tidx.x); }
+template <class T>
+inline const T& kernel_argument(const T& by_value) { return by_value; }
+inline v2f64 stream_load(const v2f64* p) { return *p; }
+inline void stream_store(v2f64 v, v2f64* p) { *p = v; }
+inline void stream_store(double v, double* p) { *p = v; }
+}  // namespace wn
 
 // ---- the sliver of the HIP runtime the host code uses ------------------------------------------
 typedef int hipError_t;

@@ -137,7 +137,7 @@ def test_engine_argument_and_state_errors(sim):
         mk(wa.MODEL_STD_NORMAL, 3, 0, wa.default_config(sim))
     with pytest.raises(ValueError, match="model"):
         mk(17, 3, 2, wa.default_config(sim))
-    with pytest.raises(ValueError, match="sigma_sq"):
+    with pytest.raises(ValueError, match="diag_normal model needs a parameter vector"):
         mk(wa.MODEL_DIAG_NORMAL, 3, 2, wa.default_config(sim))
     with pytest.raises(ValueError, match="funnel"):
         mk(wa.MODEL_FUNNEL, 1, 2, wa.default_config(sim))

@@ -28,11 +28,6 @@ namespace wn {
 // N doubles per lane addressed by a wave-uniform index: one column of a register bank.  The index reaches the
 // hardware as VGPR-relative addressing (s_set_gpr_idx_on + v_mov), so a pool vector moves in and out of the bank
 // with two VALU moves per element and no code per slot.
-#if defined(WN_CPU_SIM)
-#define WN_VEC_OF(N) __attribute__((vector_size(8 * (N))))
-#else
-#define WN_VEC_OF(N) __attribute__((ext_vector_type(N)))
-#endif
 template <int N>
 struct RegColumn {
   typedef double type WN_VEC_OF(N);
@@ -154,29 +149,21 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
   // the chain's own planes are read once and written once per transition: streamed past the L2 (nt) so that they
   // do not evict the arena vectors a deep tree spills there
   __device__ __forceinline__ void vload_stream(const double* base, double (&v)[EPL]) const {
-#if defined(WN_CPU_SIM)
-    vload(base, v);
-#else
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const v2f64 t = __builtin_nontemporal_load(reinterpret_cast<const v2f64*>(base + (k * L + tid) * 2));
+      const v2f64 t = stream_load(reinterpret_cast<const v2f64*>(base + (k * L + tid) * 2));
       v[2 * k] = t[0];
       v[2 * k + 1] = t[1];
     }
-#endif
   }
   __device__ __forceinline__ void vstore_stream(double* base, const double (&v)[EPL]) const {
-#if defined(WN_CPU_SIM)
-    vstore(base, v);
-#else
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       v2f64 t;
       t[0] = v[2 * k];
       t[1] = v[2 * k + 1];
-      __builtin_nontemporal_store(t, reinterpret_cast<v2f64*>(base + (k * L + tid) * 2));
+      stream_store(t, reinterpret_cast<v2f64*>(base + (k * L + tid) * 2));
     }
-#endif
   }
   __device__ __forceinline__ void lds_load(const WN_LDS double* base, double (&v)[EPL]) const {
 #pragma unroll
@@ -708,11 +695,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       double* out = draws + static_cast<long long>(chain) * Q.draws_stride;
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
-#if defined(WN_CPU_SIM)
-        if (valid(j)) out[index(j)] = th[0][j];
-#else
-        if (valid(j)) __builtin_nontemporal_store(th[0][j], &out[index(j)]);
-#endif
+        if (valid(j)) stream_store(th[0][j], &out[index(j)]);
       }
     }
     if (warm) {

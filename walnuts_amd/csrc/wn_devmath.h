@@ -17,7 +17,7 @@
 
 #include "wn_math_tables.h"
 
-#if defined(__HIPCC__) && !defined(WN_CPU_SIM)
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define WND_HD __host__ __device__ __forceinline__
 #else

@@ -71,11 +71,7 @@ static __global__ void inv_mass_estimate_kernel(int C, int Dp, const double* dra
 // ---- cross-chain monitors (the reference's controller loops) --------------------------------------
 // Deterministic two-stage sums: stage 1 gives every block a contiguous slice and a fixed tree inside the
 // block, stage 2 (one block) adds the block partials left to right.
-#ifdef WN_CPU_SIM
-constexpr int kMonitorBlocks = 2;  // the emulation pays one OS thread per lane: keep its launches small
-#else
-constexpr int kMonitorBlocks = 256;
-#endif
+// (kMonitorBlocks, the number of stage-1 blocks, is a constant of the platform layer: wn_hip.h)
 
 template <int K, class F>
 static __device__ void block_partial_sums(int n, F f, double* partial /*[gridDim][K]*/) {

@@ -1,0 +1,116 @@
+// wn_gfx950.h -- the gfx950 (MI355X, CDNA4) platform layer of the kernels: the HIP runtime, LDS address-space
+// pointers, and the wavefront primitives everything else is written on -- wave-uniform broadcast, the packed
+// two-sum butterfly (DPP / v_permlane*_swap), lane reads, laundered kernel arguments, streaming loads and stores.
+// wn_hip.h includes this file for the product build; the CPU test tier substitutes tests/cpusim/wn_cpusim.h, which
+// provides the same names over a lock-step host emulation.  No other source file of walnuts_amd/csrc knows which.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) double name[]
+// LDS is addressed through address-space-3 pointers only, so every pool / scratch access is a
+// ds_* instruction (no flat aperture tests)
+#define WN_LDS __attribute__((address_space(3)))
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+// N doubles per lane addressed by a wave-uniform run-time index (VGPR-relative addressing)
+#define WN_VEC_OF(N) __attribute__((ext_vector_type(N)))
+
+namespace wn {
+
+// launch sizes of the element-wise / summary kernels
+constexpr int kMonitorBlocks = 256;
+constexpr int kSummaryBlock = 256;
+constexpr int kSummaryLagSlabChains = 8192;
+constexpr int kSummaryCandidateCap = 2048;
+
+__device__ __forceinline__ uint64_t bits_of(double d) { return static_cast<uint64_t>(__double_as_longlong(d)); }
+__device__ __forceinline__ double double_of(uint64_t u) { return __longlong_as_double(static_cast<long long>(u)); }
+
+// ---- wave-uniform helpers ----------------------------------------------------
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+  const uint64_t u = bits_of(v);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u >> 32));
+  return double_of((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// xor-butterfly sum over the 64 lanes, offsets 32,1,2,4,8,16: every lane ends with the same bits
+// (a+b == b+a), and the CPU oracle replays exactly this association order.
+// gfx950: offsets 1,2 are quad permutes, 4 and 8 are row_half_mirror / row_mirror (the groups are already
+// uniform there, so the mirrored lane holds the xor partner's value), 16 and 32 are v_permlane{16,32}_swap.
+// All VALU: no LDS crossbar traffic (ds_bpermute) on the reduction path.
+template <int CTRL>
+__device__ __forceinline__ double dpp_partner(double v) {
+  const uint64_t u = bits_of(v);
+  const int lo = static_cast<int>(u), hi = static_cast<int>(u >> 32);
+  // mov_dpp (no tied `old` operand): one v_mov_b32_dpp per dword, no preparatory copies; every lane has a
+  // valid source in these patterns
+  const int plo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  const int phi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return double_of((static_cast<uint64_t>(static_cast<uint32_t>(phi)) << 32) | static_cast<uint32_t>(plo));
+}
+// Two sums at once.  Offset 32 goes first and packs the pair: after one v_permlane32_swap per dword, lanes 0-31
+// hold a[l] + a[l+32] and lanes 32-63 hold b[l-32] + b[l]; offsets 1..16 never leave a 32-lane half, so ONE
+// butterfly finishes both (18 VALU instead of 36).  Returns the packed register: a's sum in lanes 0-31, b's in
+// lanes 32-63.
+__device__ __forceinline__ double wave_sum_packed(double a, double b) {
+  double v;
+  {
+    const uint64_t ua = bits_of(a), ub = bits_of(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(ua), static_cast<uint32_t>(ub), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(ua >> 32), static_cast<uint32_t>(ub >> 32),
+                                                     false, false);
+    v = double_of((static_cast<uint64_t>(hi[0]) << 32) | lo[0]) + double_of((static_cast<uint64_t>(hi[1]) << 32) | lo[1]);
+  }
+  v = v + dpp_partner<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+  v = v + dpp_partner<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+  v = v + dpp_partner<0x141>(v);  // row_half_mirror      : partner quad  (lane ^ 4)
+  v = v + dpp_partner<0x140>(v);  // row_mirror           : partner octet (lane ^ 8)
+  {
+    const uint64_t u = bits_of(v);
+    const uint32_t lo = static_cast<uint32_t>(u), hi = static_cast<uint32_t>(u >> 32);
+    const auto p = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto q = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = double_of((static_cast<uint64_t>(q[0]) << 32) | p[0]) + double_of((static_cast<uint64_t>(q[1]) << 32) | p[1]);
+  }
+  return v;
+}
+// value held by lane `src_lane` (wave-uniform index) as a scalar
+__device__ __forceinline__ double lane_value(double v, int src_lane) {
+  const uint64_t u = bits_of(v);
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(u), src_lane);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(u >> 32), src_lane);
+  return double_of((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// The lane identity behind an optimisation barrier: whatever is computed from it is rebuilt where it is used
+// instead of being hoisted to the kernel entry and held for the whole kernel.
+__device__ __forceinline__ int opaque_thread_id() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
+// The kernel's single by-value argument struct, read back from the kernel-argument segment behind an optimisation
+// barrier: fields used once or twice per transition are then fetched where they are used (s_load) instead of being
+// loaded at the kernel entry and held -- or spilled to VGPR lanes -- for the whole kernel.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T& kernel_argument(const T&) {
+  typedef const __attribute__((address_space(4))) T CT;
+  CT* p = (CT*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *p;
+}
+
+// read-once / write-once traffic streamed past the L2 (nt)
+__device__ __forceinline__ v2f64 stream_load(const v2f64* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stream_store(v2f64 v, v2f64* p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void stream_store(double v, double* p) { __builtin_nontemporal_store(v, p); }
+
+#if defined(WN_PHASE_PROFILE)
+__device__ __forceinline__ unsigned long long shader_clock() { return __builtin_amdgcn_s_memtime(); }
+#endif
+
+}  // namespace wn

@@ -1,16 +1,11 @@
-// wn_hip.h -- the one place the HIP runtime is pulled in.  Under WN_CPU_SIM (tests/cpusim, test
-// infrastructure only -- never part of libwalnuts_hip.so) the same sources are compiled by g++ against
-// a lock-step host emulation of a workgroup so that the host logic and the kernels' control flow can be
-// exercised without a GPU.
+// wn_hip.h -- the one place that decides what the kernels are compiled against: the gfx950 platform layer
+// (wn_gfx950.h: HIP runtime + wavefront primitives) or, under WN_CPU_SIM, the lock-step host emulation of a
+// workgroup that the CPU test tier uses to drive the real host code and the kernels' control flow without a GPU
+// (tests/cpusim/wn_cpusim.h -- test infrastructure, never part of libwalnuts_hip.so).
 #pragma once
 
 #if defined(WN_CPU_SIM)
 #include "wn_cpusim.h"
 #else
-#include <hip/hip_runtime.h>
-#define WN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) double name[]
-// LDS is addressed through address-space-3 pointers only, so every pool / scratch access is a
-// ds_* instruction (no flat aperture tests)
-#define WN_LDS __attribute__((address_space(3)))
-typedef double v2f64 __attribute__((ext_vector_type(2)));
+#include "wn_gfx950.h"
 #endif

@@ -24,30 +24,18 @@
 
 namespace wns {
 
-#if defined(WN_CPU_SIM)
-constexpr int kBlock = 64;  // the emulation pays one OS thread per lane
-#else
-constexpr int kBlock = 256;
-#endif
+constexpr int kBlock = wn::kSummaryBlock;  // (launch sizes are constants of the platform layer: wn_hip.h)
 constexpr int kWaves = kBlock / 64;
 constexpr int kLagBlock = 16;     // lags per pass of the autocovariance kernel (accumulators + ring in VGPRs)
 constexpr int kChainBlock = 256;  // chains per run of the two-stage sums over chains
 // the ESS computes its lag table for this many chains at a time (a multiple of kChainBlock): the [chains][16][D]
 // workspace stays at 1 GB for 1 024 dimensions however many chains there are
-#if defined(WN_CPU_SIM)
-constexpr int kLagSlabChains = 256;
-#else
-constexpr int kLagSlabChains = 8192;
-#endif
+constexpr int kLagSlabChains = wn::kSummaryLagSlabChains;
 constexpr int kRows = 8;          // draws a lane loads ahead in the radix-select pass
 constexpr int kMaxTargets = 16;
 // radix select: draws left per (target, dimension) at which the rest is finished in a gathered list instead of more
 // passes over all draws
-#if defined(WN_CPU_SIM)
-constexpr int kCandidateCap = 8;
-#else
-constexpr int kCandidateCap = 2048;
-#endif   // order statistics per radix-select sweep (16 * 4 KB of LDS histograms)
+constexpr int kCandidateCap = wn::kSummaryCandidateCap;
 
 struct View {
   const double* x;        // draws

@@ -47,76 +47,6 @@ namespace wn {
 constexpr int kRedStride(int nw) { return 4 * nw + 1; }
 constexpr int kRedDoubles(int nw) { return 2 * kRedStride(nw); }
 
-// ---- wave-uniform helpers ----------------------------------------------------
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ double uni(double v) {
-#if defined(WN_CPU_SIM)
-  return wnsim::readfirstlane(v);
-#endif
-  const uint64_t u = wnd::as_u64(v);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u));
-  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u >> 32));
-  return wnd::as_f64((static_cast<uint64_t>(hi) << 32) | lo);
-}
-
-// xor-butterfly sum over the 64 lanes, offsets 32,1,2,4,8,16: every lane ends with the same bits
-// (a+b == b+a), and the CPU oracle replays exactly this association order.
-#if defined(WN_CPU_SIM)
-__device__ __forceinline__ double wave_sum(double v) {
-  v = v + __shfl_xor(v, 32, 64);
-  for (int off = 1; off < 32; off <<= 1) v = v + __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ double lane_value(double v, int src_lane) { return __shfl(v, src_lane, 64); }
-#else
-// gfx950: offsets 1,2 are quad permutes, 4 and 8 are row_half_mirror / row_mirror (the groups are already
-// uniform there, so the mirrored lane holds the xor partner's value), 16 and 32 are v_permlane{16,32}_swap.
-// All VALU: no LDS crossbar traffic (ds_bpermute) on the reduction path.
-template <int CTRL>
-__device__ __forceinline__ double dpp_partner(double v) {
-  const uint64_t u = wnd::as_u64(v);
-  const int lo = static_cast<int>(u), hi = static_cast<int>(u >> 32);
-  // mov_dpp (no tied `old` operand): one v_mov_b32_dpp per dword, no preparatory copies; every lane has a
-  // valid source in these patterns
-  const int plo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-  const int phi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-  return wnd::as_f64((static_cast<uint64_t>(static_cast<uint32_t>(phi)) << 32) | static_cast<uint32_t>(plo));
-}
-// Two sums at once.  Offset 32 goes first and packs the pair: after one v_permlane32_swap per dword, lanes 0-31
-// hold a[l] + a[l+32] and lanes 32-63 hold b[l-32] + b[l]; offsets 1..16 never leave a 32-lane half, so ONE
-// butterfly finishes both (18 VALU instead of 36).  Returns the packed register: a's sum in lanes 0-31, b's in
-// lanes 32-63.
-__device__ __forceinline__ double wave_sum_pair(double a, double b) {
-  double v;
-  {
-    const uint64_t ua = wnd::as_u64(a), ub = wnd::as_u64(b);
-    const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(ua), static_cast<uint32_t>(ub), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(ua >> 32), static_cast<uint32_t>(ub >> 32),
-                                                     false, false);
-    v = wnd::as_f64((static_cast<uint64_t>(hi[0]) << 32) | lo[0]) + wnd::as_f64((static_cast<uint64_t>(hi[1]) << 32) | lo[1]);
-  }
-  v = v + dpp_partner<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
-  v = v + dpp_partner<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
-  v = v + dpp_partner<0x141>(v);  // row_half_mirror      : partner quad  (lane ^ 4)
-  v = v + dpp_partner<0x140>(v);  // row_mirror           : partner octet (lane ^ 8)
-  {
-    const uint64_t u = wnd::as_u64(v);
-    const uint32_t lo = static_cast<uint32_t>(u), hi = static_cast<uint32_t>(u >> 32);
-    const auto p = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto q = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    v = wnd::as_f64((static_cast<uint64_t>(q[0]) << 32) | p[0]) + wnd::as_f64((static_cast<uint64_t>(q[1]) << 32) | p[1]);
-  }
-  return v;
-}
-// value held by lane `src_lane` (wave-uniform index) as a scalar
-__device__ __forceinline__ double lane_value(double v, int src_lane) {
-  const uint64_t u = wnd::as_u64(v);
-  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(u), src_lane);
-  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(u >> 32), src_lane);
-  return wnd::as_f64((static_cast<uint64_t>(hi) << 32) | lo);
-}
-#endif
-
 // The exp / log tables (wn_devmath.h) as one entry per lane of three VGPR pairs.  A wave-uniform argument looks its
 // entries up with v_readlane (a few cycles, no memory), per-lane arguments with a lane gather.
 struct LaneTables {
@@ -152,7 +82,7 @@ __device__ __forceinline__ double log_sum_exp(double x1, double x2, const Tab& t
 }
 
 // ---- optional phase profiler (tests/gpu_probes only; compiled out of the product build) -------------
-#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+#if defined(WN_PHASE_PROFILE)
 enum { kPhIdle = 0, kPhPrologue, kPhLeapfrog, kPhEnergy, kPhRestart, kPhReversible, kPhUturn, kPhCombine, kPhPush,
        kPhTopMerge, kPhDoublingStart, kPhEpilogue, kPhCount };
 __device__ unsigned long long wn_phase_cycles[kPhCount];
@@ -193,7 +123,7 @@ struct TrajBase {
     int sel[kMaxLevels];
     double u[kDrawCache];   // tree draws draw_base .. draw_base+kDrawCache-1 of this transition
     double lu[kDrawCache];  // their logarithms
-#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+#if defined(WN_PHASE_PROFILE)
     unsigned long long prof[16];
     unsigned long long prof_last;
     int prof_cur;
@@ -235,16 +165,7 @@ struct TrajBase {
   // them to VGPR lanes (185-236 spilled SGPRs, 13 % of the VALU stream, before this).  The empty asm hides the
   // pointer's origin at every use so that the loads cannot be hoisted or merged across calls.  Only the
   // transition kernels, whose single kernel argument IS the Params struct, may call this.
-#if defined(WN_CPU_SIM)
-  __device__ __forceinline__ const Params& cold() const { return P; }
-#else
-  typedef const __attribute__((address_space(4))) Params ColdParams;
-  __device__ __forceinline__ ColdParams& cold() const {
-    ColdParams* p = (ColdParams*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return *p;
-  }
-#endif
+  __device__ __forceinline__ auto& cold() const { return kernel_argument(P); }
 
   __device__ __forceinline__ TrajBase(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
                                       WN_LDS double* bc, double* ar)
@@ -260,9 +181,9 @@ struct TrajBase {
     tabs.load(lane);
   }
 
-#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+#if defined(WN_PHASE_PROFILE)
   __device__ __forceinline__ void phase_mark(int k) {
-    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned long long t = shader_clock();
     if (lane == 0) {
       meta->prof[meta->prof_cur] += t - meta->prof_last;
       meta->prof_last = t;
@@ -272,7 +193,7 @@ struct TrajBase {
   __device__ __forceinline__ void phase_begin() {
     if (lane == 0) {
       for (int i = 0; i < 16; ++i) meta->prof[i] = 0;
-      meta->prof_last = __builtin_amdgcn_s_memtime();
+      meta->prof_last = shader_clock();
       meta->prof_cur = kPhIdle;
     }
   }
@@ -307,30 +228,21 @@ struct TrajBase {
   // masks, the counter words of the random stream) is then rebuilt where it is used instead of being hoisted out
   // of the persistent chain loop to the kernel entry and held -- or spilled -- for the whole kernel.
   __device__ __forceinline__ void refresh_ids() {
-#if !defined(WN_CPU_SIM)
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
+    const int t = opaque_thread_id();
     tid = t;
     lane = t & 63;
     wave = uni(t >> 6);
-#endif
   }
 
   // ---- reductions -----------------------------------------------------------------
   __device__ __forceinline__ void sum2(double& a, double& b) {
-#if defined(WN_CPU_SIM)
-    a = wave_sum(a);
-    b = wave_sum(b);
-    const double packed = lane < 32 ? a : b;
-#else
-    const double packed = wave_sum_pair(a, b);  // a's sum in lanes 0-31, b's in lanes 32-63
+    const double packed = wave_sum_packed(a, b);  // a's sum in lanes 0-31, b's in lanes 32-63
     if (NW == 1) {
       a = uni(packed);
       b = lane_value(packed, 32);
       carry_armed = false;
       return;
     }
-#endif
     if (NW > 1) {
       WN_LDS double* r = red + red_parity * kRedStride(NW);
       if (lane == 0) r[wave * 2] = packed;
@@ -355,14 +267,7 @@ struct TrajBase {
   // four sums behind one exchange (a leaf's two energies and the two level-0 U-turn products): two packed
   // butterflies interleave, one barrier
   __device__ __forceinline__ void sum4(double& a, double& b, double& c, double& d) {
-#if defined(WN_CPU_SIM)
-    a = wave_sum(a);
-    b = wave_sum(b);
-    c = wave_sum(c);
-    d = wave_sum(d);
-    const double p1 = lane < 32 ? a : b, p2 = lane < 32 ? c : d;
-#else
-    const double p1 = wave_sum_pair(a, b), p2 = wave_sum_pair(c, d);
+    const double p1 = wave_sum_packed(a, b), p2 = wave_sum_packed(c, d);
     if (NW == 1) {
       a = uni(p1);
       b = lane_value(p1, 32);
@@ -371,7 +276,6 @@ struct TrajBase {
       carry_armed = false;
       return;
     }
-#endif
     if (NW > 1) {
       WN_LDS double* r = red + red_parity * kRedStride(NW);
       if (lane == 0) {
@@ -1143,7 +1047,7 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   double* arena = P.arena + static_cast<long long>(blockIdx.x) * P.arena_stride;
 
   T t(P, pool, meta, red, bcast, arena);
-#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+#if defined(WN_PHASE_PROFILE)
   t.phase_begin();
 #endif
   // The workgroup's first chain is its own index; the following ones come from the shared counter, and the fetch
@@ -1164,7 +1068,7 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
       slot ^= 1;
     }
   }
-#if defined(WN_PHASE_PROFILE) && !defined(WN_CPU_SIM)
+#if defined(WN_PHASE_PROFILE)
   t.phase_end();
 #endif
 }

@@ -38,9 +38,12 @@ struct RegColumn<0> {
 };
 
 // RA + RB = pool vectors kept in registers, as two banks whose sizes are vector widths (2, 4, 8, 16) or 0
-template <class Model, int NW, int EPL, int RA, int RB>
-struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
-  using Base = TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW>;
+// WARM: the kernel of the adaptive warmup transitions (Adam, mass estimator) or of the frozen sampler's -- two
+// instantiations, because the sampler's, freed of the adaptation code, needs fewer registers (measured: +3 % on the
+// one-wavefront headline kernel, +8 % on the two-wavefront one)
+template <class Model, int NW, int EPL, int RA, int RB, bool WARM = false>
+struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
+  using Base = TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW>;
   static constexpr int RP = RA + RB;
   using typename Base::Meta;
   using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::wave;
@@ -80,6 +83,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
     const int on = n_lds + n_reg;
     onchip_mask = on >= 64 ? ~0ull : ((1ull << on) - 1ull);
   }
+
+  __device__ __forceinline__ static constexpr bool is_warmup() { return WARM; }
 
   // ---- model context (what Model::eval sees) ------------------------------------------------------
   __device__ __forceinline__ int index(int j) const { return ((j >> 1) * L + tid) * 2 + (j & 1); }
@@ -336,13 +341,67 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       p_far += b[j] * sd;
     }
   }
-  // the moving end (always set 0 when a pool-resident span is merged) against a span end kept in the pool
+  // CH consecutive slots (a whole number of pairs) of a pool vector, starting at slot j0
+  template <int CH>
+  __device__ __forceinline__ void pool_load_slots(int b, int j0, double (&v)[CH]) {
+    const int k0 = j0 / 2;
+    if (b < n_lds) {
+      const WN_LDS double* base = lds_pool + b * kDp;
+#pragma unroll
+      for (int k = 0; k < CH / 2; ++k) {
+        const v2f64 t = *reinterpret_cast<const WN_LDS v2f64*>(base + ((k0 + k) * L + tid) * 2);
+        v[2 * k] = t[0];
+        v[2 * k + 1] = t[1];
+      }
+      return;
+    }
+    const int kk = b - n_lds;
+    if (RP > 0 && kk < n_reg) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+#pragma unroll
+        for (int jj = 0; jj < EPL; ++jj) {
+          if (jj == j0 + j) v[j] = (RB == 0 || kk < RA) ? bank_a[jj][kk] : bank_b[jj][kk - RA];
+        }
+      }
+      return;
+    }
+    const double* base = arena + static_cast<long long>(kk - n_reg) * kDp;
+#pragma unroll
+    for (int k = 0; k < CH / 2; ++k) {
+      const v2f64 t = *reinterpret_cast<const v2f64*>(base + ((k0 + k) * L + tid) * 2);
+      v[2 * k] = t[0];
+      v[2 * k + 1] = t[1];
+    }
+  }
+  // the moving end (always set 0 when a pool-resident span is merged) against a span end kept in the pool.  With 16
+  // elements per lane the two operands are taken half a vector at a time: the kernel is at its register limit there,
+  // and 64 more live registers mean as many moves to and from the accumulator file.
   __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
-    double a[EPL], b[EPL];
-    pool_load(bth, a);
-    pool_load(brh, b);
-    double p_hot, p_far;
-    uturn_partials<0>(a, b, fwd, p_hot, p_far);
+    double p_hot = 0.0, p_far = 0.0;
+    if (EPL >= 16) {
+      constexpr int CH = EPL >= 16 ? EPL / 2 : EPL;
+      const uint64_t flip = fwd ? 0ull : 0x8000000000000000ull;
+#pragma unroll
+      for (int h = 0; h < EPL / CH; ++h) {
+        double a[CH], b[CH];
+        pool_load_slots<CH>(bth, h * CH, a);
+        pool_load_slots<CH>(brh, h * CH, b);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const int jj = h * CH + j;
+          const double diff = wnd::as_f64(wnd::as_u64(th[0][jj] - a[j]) ^ flip);
+          const double sd = im[jj] * diff;
+          p_hot += rh[0][jj] * sd;
+          p_far += b[j] * sd;
+        }
+      }
+    } else {
+      double a[EPL], b[EPL];
+      pool_load(bth, a);
+      pool_load(brh, b);
+      uturn_partials<0>(a, b, fwd, p_hot, p_far);
+    }
     this->sum2(p_hot, p_far);
     return p_hot < 0 || p_far < 0;
   }
@@ -371,7 +430,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
       finish_energy(part, ke, logp_pos, logp_joint);
       if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
         // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
-        if (P.warmup && wave == 0) this->adam_observe(wnd::dexp(-fabs(logp_start - logp_joint), this->uniform_tab()));
+        if (is_warmup() && wave == 0) this->adam_observe(wnd::dexp(-fabs(logp_start - logp_joint), this->uniform_tab()));
       }
       WN_PHASE(kPhRestart);
       if (fabs(logp_start - logp_joint) <= max_error) {
@@ -411,7 +470,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB>, Model, NW> {
     max_error = P.max_error;
     free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
     const long long row = static_cast<long long>(chain) * kDp;
-    const bool warm = P.warmup != 0;
+    const bool warm = is_warmup();
     this->load_tuning(warm);
 
     // momentum refresh + initial point (walnuts.hpp:528-535), into set 0
@@ -764,9 +823,9 @@ constexpr int chip_reg_pool() {
   return chip_bank_a<Model, EPL>() + chip_bank_b<Model, EPL>();
 }
 
-template <class Model, int NW, int EPL>
+template <class Model, int NW, int EPL, bool WARM>
 __global__ __launch_bounds__(64 * NW, (chip_waves_per_simd<Model, EPL>())) void transition_kernel_chip(const Params P) {
-  persistent_loop<TrajChip<Model, NW, EPL, chip_bank_a<Model, EPL>(), chip_bank_b<Model, EPL>()>, NW>(P);
+  persistent_loop<TrajChip<Model, NW, EPL, chip_bank_a<Model, EPL>(), chip_bank_b<Model, EPL>(), WARM>, NW>(P);
 }
 
 }  // namespace wn

@@ -16,6 +16,8 @@ $B --no-cpu-baseline --config 5 --steps 10 --warmup 3 > $OUT/bench_cfg5_one_gpu.
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_funnel_1024.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model rw1 --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_rw1_1024.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --steps 10 --warmup 3 > /dev/null 2>&1
+python3 $ROOT/profiles/summarize.py r02 $(find $OUT/headline_trace -name "*results.db" | head -1) > $OUT/kernel_trace_headline.txt 2>&1
+rm -rf $OUT/headline_trace
 for f in $OUT/bench_*.json; do python3 -c "
 import json,sys
 d=json.load(open('$f')); r=d['roofline']

@@ -54,3 +54,4 @@ if "SQ_WAVE_CYCLES" in vals:
         if n in vals: print(f"{n}/SQ_WAVE_CYCLES = {vals[n][0]/wc:.3f}")
 PY
 cat $OUT/summary.txt
+rm -rf $OUT/p[0-9] $OUT/p[0-9].log   # the rocpd databases stay on the box: summary.txt + traffic.json are what is filed

@@ -471,7 +471,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
     const long long row = static_cast<long long>(chain) * kDp;
     const bool warm = is_warmup();
-    this->load_tuning(warm);
 
     // momentum refresh + initial point (walnuts.hpp:528-535), into set 0
     double lp_pos, lj;
@@ -698,44 +697,49 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   // load the chain, refresh the momentum (walnuts.hpp:528-529), evaluate the initial point (:532)
   __device__ __forceinline__ double begin_transition(long long row, bool warm) {
     const auto& Q = this->cold();
+    // Order matters: the chain's scalars and planes are REQUESTED first, then the momentum's standard normals are
+    // generated (pure arithmetic: Philox + Box-Muller, ~2 000 VALU instructions per wavefront at 16 elements per
+    // lane), and only then is anything loaded looked at -- the round trips to HBM hide behind the generator.
+    this->request_tuning(warm);
     vload_stream(Q.theta + row, th[0]);
     if (Model::kUsesParams) vload(Q.model_params, mp);
-    double chol[EPL];
+    double ds[EPL], ss[EPL];  // warmup: the estimator's two sums of squared deviations
     if (warm) {
-      // adaptive_walnuts.hpp:235-236 with MassEstimator::inv_mass_estimate :89-94
-      const double wd = w_draw0, ws = w_score0;
-      double ds[EPL], ss[EPL];
       vload_stream(Q.est_draw_ssd + row, ds);
       vload_stream(Q.est_score_ssd + row, ss);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        im[j] = __builtin_sqrt((ds[j] / wd) / (ss[j] / ws));
-        chol[j] = __builtin_sqrt(1.0 / im[j]);
-      }
     } else {
       vload_stream(Q.inv_mass + row, im);
-      // 1/sqrt(inv_mass), walnuts.hpp:647: the expression freeze_kernel stores in the chol_mass plane, re-evaluated
-      // here (one division and one square root per element and transition) instead of streaming a third plane:
-      // 8 KB of the 40 KB a 1024-dimensional chain moves per transition
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) chol[j] = 1.0 / __builtin_sqrt(im[j]);
     }
-    if (Q.rng_mode == kRngBuffer) {
-      double z[EPL];
-      vload_stream(Q.z_buf + row, z);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) rh[0][j] = chol[j] * z[j];
+    const bool fed = Q.rng_mode == kRngBuffer;
+    if (fed) {
+      vload_stream(Q.z_buf + row, rh[0]);
     } else {
       const uint64_t seed = Q.seed;
       const uint32_t key_chain = Q.chain_offset + chain, key_tr = Q.transition;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        double z0, z1;
         const uint32_t pair = static_cast<uint32_t>(k * L + tid);
-        wnd::stream_normal_pair(seed, key_chain, key_tr, wnd::kStreamMomentum, pair, z0, z1, this->gather_tab());
-        rh[0][2 * k] = valid(2 * k) ? chol[2 * k] * z0 : 0.0;
-        rh[0][2 * k + 1] = valid(2 * k + 1) ? chol[2 * k + 1] * z1 : 0.0;
+        wnd::stream_normal_pair(seed, key_chain, key_tr, wnd::kStreamMomentum, pair, rh[0][2 * k], rh[0][2 * k + 1],
+                                this->gather_tab());
       }
+    }
+    this->finish_tuning(warm);
+    // rho = cholesky_mass * z (walnuts.hpp:528-529), padding slots zero
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      double chol;
+      if (warm) {
+        // adaptive_walnuts.hpp:235-236 with MassEstimator::inv_mass_estimate :89-94
+        im[j] = __builtin_sqrt((ds[j] / w_draw0) / (ss[j] / w_score0));
+        chol = __builtin_sqrt(1.0 / im[j]);
+      } else {
+        // 1/sqrt(inv_mass), walnuts.hpp:647: the expression freeze_kernel stores in the chol_mass plane, re-evaluated
+        // here (one division and one square root per element and transition) instead of streaming a third plane:
+        // 8 KB of the 40 KB a 1024-dimensional chain moves per transition
+        chol = 1.0 / __builtin_sqrt(im[j]);
+      }
+      const double r = chol * rh[0][j];
+      rh[0][j] = (fed || valid(j)) ? r : 0.0;
     }
     return model_eval<0>();
   }

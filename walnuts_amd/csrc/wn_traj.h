@@ -417,25 +417,46 @@ struct TrajBase {
     }
   }
 
-  // per-chain tuning parameters of this transition (adaptive_walnuts.hpp:235-245 / walnuts.hpp:686-689)
-  __device__ __forceinline__ void load_tuning(bool warm) {
+  // per-chain tuning parameters of this transition (adaptive_walnuts.hpp:235-245 / walnuts.hpp:686-689), in two
+  // halves: request_tuning() only ISSUES the loads of the chain's scalars (they sit behind the kernel-argument fetch
+  // of their array pointers: two dependent round trips), finish_tuning() turns them into wave-uniform values.  The
+  // register backend requests them before the chain's planes and finishes after the momentum has been generated.
+  double t_a, t_b, t_c, t_d;  // in flight between the two halves
+  int t_i;
+  __device__ __forceinline__ void request_tuning(bool warm) {
     const auto& Q = cold();
     if (warm) {
-      w_draw0 = uni(Q.est_weight[2 * chain]);
-      w_score0 = uni(Q.est_weight[2 * chain + 1]);
+      t_a = Q.est_weight[2 * chain];
+      t_b = Q.est_weight[2 * chain + 1];
+      t_c = Q.mm_state[2 * chain];
+      t_d = Q.mm_state[2 * chain + 1];
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) meta->adam[i] = Q.adam[6 * chain + i];
       }
-      step = uni(wnd::dexp(Q.adam[6 * chain], uniform_tab()));  // adam.hpp:93
+    } else {
+      t_a = Q.step_size[chain];
+      t_i = Q.min_micro[chain];
+    }
+  }
+  __device__ __forceinline__ void finish_tuning(bool warm) {
+    if (warm) {
+      const auto& Q = cold();
+      w_draw0 = uni(t_a);
+      w_score0 = uni(t_b);
+      step = uni(wnd::dexp(meta->adam[0], uniform_tab()));  // adam.hpp:93 (written by this wavefront's lane 0 above)
       // adaptive_walnuts.hpp:152-157
-      const double mean_micro = Q.mm_state[2 * chain] / Q.mm_state[2 * chain + 1];
+      const double mean_micro = t_c / t_d;
       const long long est = static_cast<long long>(__builtin_round(mean_micro / Q.macro_target));
       min_micro = uni(static_cast<int>(est > Q.cfg_min_micro ? est : Q.cfg_min_micro));
     } else {
-      step = uni(Q.step_size[chain]);
-      min_micro = uni(Q.min_micro[chain]);
+      step = uni(t_a);
+      min_micro = uni(t_i);
     }
+  }
+  __device__ __forceinline__ void load_tuning(bool warm) {
+    request_tuning(warm);
+    finish_tuning(warm);
   }
   // per-chain scalar results of this transition
   __device__ __forceinline__ void store_scalars(bool warm, int depth, double lpsel) {

@@ -703,12 +703,15 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     this->request_tuning(warm);
     vload_stream(Q.theta + row, th[0]);
     if (Model::kUsesParams) vload(Q.model_params, mp);
-    double ds[EPL], ss[EPL];  // warmup: the estimator's two sums of squared deviations
+    double ds[EPL], ss[EPL];  // warmup: the estimator's two sums of squared deviations; sampling: ds = cholesky_mass
     if (warm) {
       vload_stream(Q.est_draw_ssd + row, ds);
       vload_stream(Q.est_score_ssd + row, ss);
     } else {
       vload_stream(Q.inv_mass + row, im);
+#if !defined(WN_RECOMPUTE_CHOL)
+      vload_stream(Q.chol_mass + row, ds);  // 1/sqrt(inv_mass), walnuts.hpp:647, stored once by freeze_kernel
+#endif
     }
     const bool fed = Q.rng_mode == kRngBuffer;
     if (fed) {
@@ -733,10 +736,14 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
         im[j] = __builtin_sqrt((ds[j] / w_draw0) / (ss[j] / w_score0));
         chol = __builtin_sqrt(1.0 / im[j]);
       } else {
-        // 1/sqrt(inv_mass), walnuts.hpp:647: the expression freeze_kernel stores in the chol_mass plane, re-evaluated
-        // here (one division and one square root per element and transition) instead of streaming a third plane:
-        // 8 KB of the 40 KB a 1024-dimensional chain moves per transition
+        // Streaming the plane costs 8 KB of the 48 KB a 1024-dimensional chain moves per transition; re-evaluating
+        // the expression (a division and a square root per element) costs ~2 000 cycles of the ~85 000 a transition
+        // takes -- measured: 2.22 ms / 3.7 GB streamed against 2.27 ms / 3.15 GB recomputed (-DWN_RECOMPUTE_CHOL).
+#if defined(WN_RECOMPUTE_CHOL)
         chol = 1.0 / __builtin_sqrt(im[j]);
+#else
+        chol = ds[j];
+#endif
       }
       const double r = chol * rh[0][j];
       rh[0][j] = (fed || valid(j)) ? r : 0.0;
@@ -756,9 +763,14 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     double* draws = Q.draws_out;
     if (draws != nullptr) {
       double* out = draws + static_cast<long long>(chain) * Q.draws_stride;
+      // an unpadded row on a 16-byte boundary takes the pair stores; anything else goes element by element
+      if (P.dim == kDp && ((reinterpret_cast<unsigned long long>(out) & 15ull) == 0ull)) {
+        vstore_stream(out, th[0]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        if (valid(j)) stream_store(th[0][j], &out[index(j)]);
+        for (int j = 0; j < EPL; ++j) {
+          if (valid(j)) stream_store(th[0][j], &out[index(j)]);
+        }
       }
     }
     if (warm) {

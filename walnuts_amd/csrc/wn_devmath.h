@@ -129,6 +129,33 @@ WND_HD double dlog(double x, const Tab& tab) {
   return y;
 }
 
+// dlog() for an argument known to be a positive NORMAL number (the generator's open-interval uniforms): the same main
+// path, hence the same bits, without the special-value patches and the subnormal rescaling.
+template <class Tab>
+WND_HD double dlog_normal(double x, const Tab& tab) {
+  constexpr double kLn2Hi = 6.93147180369123816490e-01;
+  constexpr double kLn2Lo = 1.90821492927058770002e-10;
+  const uint64_t bits = as_u64(x);
+  int k = static_cast<int>(bits >> 52) - 1023;
+  const uint64_t frac = bits & 0x000fffffffffffffULL;
+  const bool upper = frac >= 0x0008000000000000ULL;
+  k += upper ? 1 : 0;
+  const double s = as_f64(frac | (static_cast<uint64_t>(upper ? 1022 : 1023) << 52));
+  const int i = static_cast<int>(s * 64.0 + 0.5);
+  const double c = static_cast<double>(i) * 0.015625;
+  const double u = (s - c) * tab.rcp(i - 48);
+  const double lc = tab.logc(i - 48);
+  const double q = u * u;
+  const double a0 = 0.5 - u * 3.33333333333333315e-01;
+  const double a1 = 0.25 - u * 2.00000000000000011e-01;
+  const double a2 = 1.66666666666666657e-01 - u * 1.42857142857142849e-01;
+  const double q2 = q * q;
+  const double pl = (a0 + q * a1) + q2 * (a2 + q * 0.125);
+  const double l1 = u - q * pl;
+  const double dk = static_cast<double>(k);
+  return (dk * kLn2Hi + lc) + (l1 + dk * kLn2Lo);
+}
+
 // the tables as plain arrays (host: tests, engine set-up; device: constant memory for the rarely used call sites)
 struct ArrayTables {
   const unsigned long long* e2;
@@ -175,9 +202,12 @@ WND_HD void dsincospi(double a, double& sn, double& cs) {
   pc = -1.38888888888741095749e-03 + z * pc;
   pc = 4.16666666666666019037e-02 + z * pc;
   const double c = (1.0 - 0.5 * z) + (z * z) * pc;
-  const int m = q & 3;
-  sn = (m == 0) ? s : (m == 1) ? c : (m == 2) ? -s : -c;
-  cs = (m == 0) ? c : (m == 1) ? -s : (m == 2) ? -c : s;
+  // quadrant m = q mod 4: (sin, cos) = (s, c), (c, -s), (-s, -c), (-c, s): one swap, then sign flips on the high words
+  const uint64_t m = static_cast<uint64_t>(q & 3);
+  const bool swap = (m & 1) != 0;
+  const double a0 = swap ? c : s, b0 = swap ? s : c;
+  sn = as_f64(as_u64(a0) ^ ((m >> 1) << 63));
+  cs = as_f64(as_u64(b0) ^ (((m ^ (m >> 1)) & 1) << 63));
 }
 
 // ---------------------------------------------------------------------------
@@ -209,9 +239,13 @@ enum : uint32_t { kStreamMomentum = 0, kStreamTree = 1, kStreamInitPos = 2, kStr
 WND_HD double dpow_pos(double x, double y) { return dpow_pos(x, y, array_tables()); }
 
 // 64 bits -> open-interval uniform, exact in binary64
+// (k + 0.5) * 2^-52 for the top 52 bits k, built in the mantissa: 1 + k 2^-52 is exact, so are the subtraction and the
+// addition of 2^-53 (the result (2k + 1) 2^-53 is representable) -- the same value as converting k to double, without
+// the 64-bit integer conversion.
 WND_HD double open01(uint32_t lo, uint32_t hi) {
   const uint64_t v = (static_cast<uint64_t>(hi) << 32) | lo;
-  return (static_cast<double>(v >> 12) + 0.5) * 2.220446049250313080847e-16;
+  const double one_plus = as_f64(0x3ff0000000000000ULL | (v >> 12));
+  return (one_plus - 1.0) + 1.1102230246251565404e-16;
 }
 
 // counter = (index, transition, chain, stream); key = seed
@@ -232,7 +266,7 @@ WND_HD void stream_normal_pair(uint64_t seed, uint32_t chain, uint32_t transitio
   z1 = (u2 - 0.5) * 3.4641016151377544;
   return;
 #endif
-  const double rad = __builtin_sqrt(-2.0 * dlog(u1, tab));
+  const double rad = __builtin_sqrt(-2.0 * dlog_normal(u1, tab));
   double sn, cs;
   dsincospi(2.0 * u2, sn, cs);
   z0 = rad * cs;

@@ -381,7 +381,8 @@ struct TrajBase {
       u = wnd::stream_uniform(Q.seed, Q.chain_offset + chain, Q.transition, wnd::kStreamTree,
                               static_cast<uint32_t>(j));
     }
-    const double lu = wnd::dlog(u, gather_tab());  // every lane takes part in the table gather
+    // every lane takes part in the table gather; a host-fed uniform may be anything, the generator's is a normal number
+    const double lu = Q.rng_mode == kRngBuffer ? wnd::dlog(u, gather_tab()) : wnd::dlog_normal(u, gather_tab());
     if (lane < kDrawCache) {
       meta->u[lane] = u;
       meta->lu[lane] = lu;

@@ -121,8 +121,6 @@ struct TrajBase {
     int in_th[kMaxLevels];
     int in_rh[kMaxLevels];
     int sel[kMaxLevels];
-    double u[kDrawCache];   // tree draws draw_base .. draw_base+kDrawCache-1 of this transition
-    double lu[kDrawCache];  // their logarithms
 #if defined(WN_PHASE_PROFILE)
     unsigned long long prof[16];
     unsigned long long prof_last;
@@ -147,7 +145,8 @@ struct TrajBase {
   bool carry_armed;
   long long n_grad;
   int n_draw;
-  int draw_base;  // first tree-draw index held in meta->u / meta->lu (-1: none)
+  int draw_base;  // first tree-draw index held in draw_u / draw_lu (-1: none)
+  double draw_u, draw_lu;
   int err;
   double step, max_error;
   double w_draw0, w_score0;  // estimator weights at entry (read once: another wave's lane 0 rewrites them at exit)
@@ -366,10 +365,8 @@ struct TrajBase {
   }
 
   // ---- randomness (util.hpp:102,112 order; counter-based stream or host-fed variates) ----
-  // The tree consumes wave-uniform scalars one at a time.  They are produced kDrawCache at a time, lane j
-  // computing draw number draw_base + j and its logarithm into the wave's LDS scratch, and handed out with
-  // a broadcast LDS read.  (A v_readlane hand-out from registers was miscompiled by ROCm 7.2's backend:
-  // after a refill the read used the stale register pair; caught by the bit-exact parity tests.)
+  // The tree consumes wave-uniform scalars one at a time.  They are produced 64 at a time, lane j computing draw number
+  // draw_base + j and its logarithm, kept in two VGPR pairs and handed out with v_readlane.
   __device__ __forceinline__ void refill_draws(int base) {
     draw_base = base;
     const int j = base + lane;
@@ -383,10 +380,8 @@ struct TrajBase {
     }
     // every lane takes part in the table gather; a host-fed uniform may be anything, the generator's is a normal number
     const double lu = Q.rng_mode == kRngBuffer ? wnd::dlog(u, gather_tab()) : wnd::dlog_normal(u, gather_tab());
-    if (lane < kDrawCache) {
-      meta->u[lane] = u;
-      meta->lu[lane] = lu;
-    }
+    draw_u = u;   // lane j holds draw number draw_base + j and its logarithm: handed out with v_readlane
+    draw_lu = lu;
   }
   __device__ __forceinline__ int next_draw_slot() {
     const int j = uni(n_draw);
@@ -394,8 +389,16 @@ struct TrajBase {
     if (draw_base < 0 || j - draw_base >= kDrawCache) refill_draws(j & ~(kDrawCache - 1));
     return j - draw_base;
   }
-  __device__ __forceinline__ double uniform01() { return uni(meta->u[next_draw_slot()]); }
-  __device__ __forceinline__ double log_uniform01() { return uni(meta->lu[next_draw_slot()]); }
+  // (the slot first, in a statement of its own: next_draw_slot() may refill the registers the read then uses, and the
+  // order in which a call's arguments are evaluated is unspecified -- clang and g++ differ)
+  __device__ __forceinline__ double uniform01() {
+    const int slot = next_draw_slot();
+    return lane_value(draw_u, slot);
+  }
+  __device__ __forceinline__ double log_uniform01() {
+    const int slot = next_draw_slot();
+    return lane_value(draw_lu, slot);
+  }
 
   // adam.hpp:70-86
   __device__ __forceinline__ void adam_observe(double alpha) {

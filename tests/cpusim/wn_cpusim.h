@@ -145,6 +145,11 @@ constexpr int kSummaryLagSlabChains = 256;
 constexpr int kSummaryCandidateCap = 8;
 inline int uni(int v) { return wnsim::readfirstlane(v); }
 inline double uni(double v) { return wnsim::readfirstlane(v); }
+struct ParkedDouble {
+  double v;
+};
+inline void park(ParkedDouble& a, double v) { a.v = v; }
+inline double fetch(const ParkedDouble& a) { return a.v; }
 inline double lane_value(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 inline double wave_sum(double v) {  // xor butterfly, offsets 32,1,2,4,8,16: the device's association order
   v = v + __shfl_xor(v, 32, 64);

@@ -21,6 +21,8 @@
 //    end when the walk turns around; nothing is written while the walk keeps its direction.
 #pragma once
 
+#include <type_traits>
+
 #include "wn_traj.h"
 
 namespace wn {
@@ -70,7 +72,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   static constexpr bool kOtherRegs = kNoGrad;
 #endif
   static constexpr int kOther = -4;           // "this vector is the other end's theta" (kOtherRegs)
-  double oth[EPL], orh[EPL];
+  ParkedDouble oth[EPL], orh[EPL];
   typename RegColumn<RA>::type bank_a[EPL];   // register tier of the span pool: element j of slot k is bank_a[j][k]
   typename RegColumn<RB>::type bank_b[EPL];
   int n_lds, n_reg;                           // pool buffers [0, n_lds) live in LDS, [n_lds, n_lds + n_reg) in the banks
@@ -489,8 +491,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     if (kOtherRegs) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
-        oth[j] = th[0][j];
-        orh[j] = rh[0][j];
+        park(oth[j], th[0][j]);
+        park(orh[j], rh[0][j]);
       }
       a_sel = kOther;
     } else {
@@ -503,29 +505,35 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       a_sel = o_th;
     }
     double lj_hot = lj, lj_other = lj, a_logsum = lj, a_lpsel = lp_pos;
-    bool both = true, hot_fw = true;
+    bool hot_fw = true;
 
+    // One doubling (walnuts.hpp:541-558); returns whether the tree keeps growing.  The first doubling is a single
+    // leaf, every later one a loop over leaf pairs: two instantiations, so that neither carries the other's
+    // register shuffles.
     int depth = 1;
-    for (; depth <= P.max_depth; ++depth) {
+    auto doubling = [&](auto first_tag) -> bool {
+      constexpr bool kFirst = decltype(first_tag)::value;
       WN_PHASE(kPhDoublingStart);
       const bool fwd = this->uniform01() < 0.5;  // bernoulli(0.5), walnuts.hpp:552
-      if (both) {
+      if (kFirst) {
         hot_fw = fwd;
-        both = false;
       } else if (fwd != hot_fw) {
         // the walk turns around: the moving end and the parked end change places
         if (kOtherRegs) {
           if (a_sel == kOther) {  // the selected position was the other end's: it gets a buffer of its own
             a_sel = this->alloc_cold();
-            pool_store(a_sel, oth);
+            double t[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) t[j] = fetch(oth[j]);
+            pool_store(a_sel, t);
           }
 #pragma unroll
           for (int j = 0; j < EPL; ++j) {
             const double t0 = th[0][j], t1 = rh[0][j];
-            th[0][j] = oth[j];
-            rh[0][j] = orh[j];
-            oth[j] = t0;
-            orh[j] = t1;
+            th[0][j] = fetch(oth[j]);
+            rh[0][j] = fetch(orh[j]);
+            park(oth[j], t0);
+            park(orh[j], t1);
           }
         } else {
           double a[EPL], b[EPL];
@@ -555,13 +563,13 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       double h_cur = lj_hot;
 
       // ---- build_span(depth-1) (walnuts.hpp:464-495) as a post-order walk over 2^(depth-1) leaves, two at a time ----
-      const int nleaf = 1 << (depth - 1);
+      const int nleaf = kFirst ? 1 : 1 << (depth - 1);
       int sp = 0;
       bool ok = true;
       bool top_turned = false;
       int c_in_th = kHot, c_in_rh = kHot, c_sel = kHot;
       double c_logsum = 0.0, c_lpsel = 0.0;
-      if (nleaf == 1) {
+      if (kFirst) {
         // a single leaf: its U-turn test against the span's other end (= the initial point, still in set 0 when
         // the leaf is done) rides in the leaf's reduction
         double leaf_lp, leaf_lj;
@@ -649,20 +657,26 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
           }
         }
       }
-      if (!ok) break;  // walnuts.hpp:543-545
+      if (!ok) return false;  // walnuts.hpp:543-545
 
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
       WN_PHASE(kPhTopMerge);
       bool turned;
       double total;
-      if (nleaf == 1) {
+      if (kFirst) {
         turned = top_turned;
         total = uni(log_sum_exp(a_logsum, c_logsum, this->uniform_tab()));
       } else {
         this->lse_on_leader(a_logsum, c_logsum);
         if (kOtherRegs) {
           double p_hot, p_far;
-          uturn_partials<0>(oth, orh, fwd, p_hot, p_far);
+          double a[EPL], b[EPL];
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) {
+            a[j] = fetch(oth[j]);
+            b[j] = fetch(orh[j]);
+          }
+          uturn_partials<0>(a, b, fwd, p_hot, p_far);
           this->sum2(p_hot, p_far);
           turned = p_hot < 0 || p_far < 0;
         } else {
@@ -684,7 +698,12 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       }
       lj_hot = h_cur;
       a_logsum = total;
-      if (turned) break;  // walnuts.hpp:549,556-558
+      return !turned;  // walnuts.hpp:549,556-558
+    };
+    if (depth <= P.max_depth && doubling(std::true_type{})) {
+      for (depth = 2; depth <= P.max_depth; ++depth) {
+        if (!doubling(std::false_type{})) break;
+      }
     }
 
     // ---- selected state out (walnuts.hpp:560-562), estimator update (adaptive_walnuts.hpp:247-248) ----
@@ -755,7 +774,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     const auto& Q = this->cold();
     if (kOtherRegs && a_sel == kOther) {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) th[0][j] = oth[j];
+      for (int j = 0; j < EPL; ++j) th[0][j] = fetch(oth[j]);
     } else {
       pool_load(a_sel, th[0]);
     }

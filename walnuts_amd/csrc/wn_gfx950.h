@@ -85,6 +85,25 @@ __device__ __forceinline__ double lane_value(double v, int src_lane) {
   return double_of((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
+// A double parked in the accumulator half of the register file (AGPRs).  Vector arithmetic cannot read AGPRs, so the
+// compiler uses them only as spill space and shuffles whole vectors in and out at region boundaries as it sees
+// fit; a value parked explicitly stays put, and a vector that is read once per doubling costs exactly one
+// v_accvgpr_read per register per doubling.
+struct ParkedDouble {
+  uint32_t lo, hi;
+};
+__device__ __forceinline__ void park(ParkedDouble& a, double v) {
+  const uint64_t u = bits_of(v);
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.lo) : "v"(static_cast<uint32_t>(u)));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.hi) : "v"(static_cast<uint32_t>(u >> 32)));
+}
+__device__ __forceinline__ double fetch(const ParkedDouble& a) {
+  uint32_t lo, hi;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(a.lo));
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(a.hi));
+  return double_of((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
 // The lane identity behind an optimisation barrier: whatever is computed from it is rebuilt where it is used
 // instead of being hoisted to the kernel entry and held for the whole kernel.
 __device__ __forceinline__ int opaque_thread_id() {

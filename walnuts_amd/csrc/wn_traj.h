@@ -74,11 +74,15 @@ struct GatherTab {  // every lane has its own argument
 // evaluated; the sum is commutative, hence the same bits as the two-exp form.
 template <class Tab>
 __device__ __forceinline__ double log_sum_exp(double x1, double x2, const Tab& tab) {
+  // Branch-free: the special cases are patched in at the end, so the ~100 dependent instructions of the exp / log pair
+  // sit in ONE basic block with whatever vector work surrounds the call and the scheduler can interleave the two.
   const double m = fmax(x1, x2);
-  if (x1 != x1 || x2 != x2) return __builtin_nan("");
-  if (__builtin_isinf(m) || (x1 + x2) != (x1 + x2)) return fmax(x1, x2);
   const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
-  return m + wnd::dlog(1.0 + wnd::dexp(d, tab), tab);
+  // 1 + exp(d) is in [1, 2] (or NaN, patched below): a positive normal number, the short form of log applies
+  double r = m + wnd::dlog_normal(1.0 + wnd::dexp(d, tab), tab);
+  r = (__builtin_isinf(m) || (x1 + x2) != (x1 + x2)) ? m : r;
+  r = (x1 != x1 || x2 != x2) ? __builtin_nan("") : r;
+  return r;
 }
 
 // ---- optional phase profiler (tests/gpu_probes only; compiled out of the product build) -------------

@@ -59,6 +59,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   static constexpr bool kNoGrad = Model::kCheapGrad;  // the gradient is recomputed from theta at each use
   static constexpr bool kHasStartState = true;
   static constexpr bool kZeroCopy = false;
+  static constexpr bool kParkScalars = true;
   static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   double th[2][EPL], rh[2][EPL], g[2][EPL];  // the two sets of the moving end (g is dead when kNoGrad)
@@ -482,6 +483,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       this->sum2(part, ke);
       finish_energy(part, ke, lp_pos, lj);
     }
+    WN_MARK(kPhEvaluated);
     this->prefetch_next_chain();
     kill_register_pool();
     // The accumulated span (walnuts.hpp:34-131) is: the moving end (set 0), the other end parked in the pool,
@@ -710,7 +712,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     WN_PHASE(kPhEpilogue);
     this->refresh_ids();
     finish_transition(a_sel, row, warm);
+    WN_MARK(kPhStored);
     this->store_scalars(warm, depth, a_lpsel);
+    WN_MARK(kPhScalars);
   }
 
   // load the chain, refresh the momentum (walnuts.hpp:528-529), evaluate the initial point (:532)
@@ -732,6 +736,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       vload_stream(Q.chol_mass + row, ds);  // 1/sqrt(inv_mass), walnuts.hpp:647, stored once by freeze_kernel
 #endif
     }
+    WN_MARK(kPhLoadsIssued);
     const bool fed = Q.rng_mode == kRngBuffer;
     if (fed) {
       vload_stream(Q.z_buf + row, rh[0]);
@@ -745,7 +750,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
                                 this->gather_tab());
       }
     }
+    WN_MARK(kPhMomentum);
     this->finish_tuning(warm);
+    WN_MARK(kPhTuned);
     // rho = cholesky_mass * z (walnuts.hpp:528-529), padding slots zero
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
@@ -778,6 +785,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     } else {
       pool_load(a_sel, th[0]);
     }
+    WN_MARK(kPhSelLoaded);
     vstore_stream(Q.theta + row, th[0]);
     double* draws = Q.draws_out;
     if (draws != nullptr) {

@@ -10,6 +10,9 @@ constexpr int kMaxPool = 64;     // vector buffers per resident chain (free mask
 constexpr int kDrawCache = 64;    // tree draws (and their logs) produced per refill, one per lane
 #if defined(WN_PHASE_PROFILE)
 constexpr int kMetaDoubles = 152; // per-wave scalar scratch kept in LDS (see TrajBase::Meta)
+#elif defined(WN_TIMELINE)
+constexpr int kTimelineMarks = 1536;
+constexpr int kMetaDoubles = 128 + kTimelineMarks + 8;
 #else
 constexpr int kMetaDoubles = 128;
 #endif

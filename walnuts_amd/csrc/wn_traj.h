@@ -92,9 +92,22 @@ enum { kPhIdle = 0, kPhPrologue, kPhLeapfrog, kPhEnergy, kPhRestart, kPhReversib
 __device__ unsigned long long wn_phase_cycles[kPhCount];
 #define WN_PHASE(k) this->phase_mark(k)
 #define WN_PHASE_OUTER(k) t.phase_mark(k)
+#elif defined(WN_TIMELINE)
+// tests/gpu_probes only: (shader clock, mark id) pairs of workgroup 0's transitions, kept in LDS and copied out when
+// the workgroup retires.  One s_memtime and one LDS store per mark.
+enum { kPhIdle = 0, kPhPrologue, kPhLeapfrog, kPhEnergy, kPhRestart, kPhReversible, kPhUturn, kPhCombine, kPhPush,
+       kPhTopMerge, kPhDoublingStart, kPhEpilogue, kPhLoadsIssued, kPhMomentum, kPhTuned, kPhEvaluated, kPhSelLoaded,
+       kPhStored, kPhScalars, kPhCount };
+__device__ unsigned long long wn_timeline[kTimelineMarks];
+#define WN_PHASE(k) this->timeline_mark(k)
+#define WN_PHASE_OUTER(k) t.timeline_mark(k)
+#define WN_MARK(k) this->timeline_mark(k)
 #else
 #define WN_PHASE(k) ((void)0)
 #define WN_PHASE_OUTER(k) ((void)0)
+#endif
+#if !defined(WN_MARK)
+#define WN_MARK(k) ((void)0)  // marks only the timeline probe records
 #endif
 
 constexpr int kHot = -1;    // "this vector is the moving trajectory end"
@@ -129,6 +142,9 @@ struct TrajBase {
     unsigned long long prof[16];
     unsigned long long prof_last;
     int prof_cur;
+#endif
+#if defined(WN_TIMELINE)
+    unsigned long long tl[kTimelineMarks];
 #endif
   };
   static_assert(sizeof(Meta) <= kMetaDoubles * sizeof(double), "meta scratch too small");
@@ -204,6 +220,22 @@ struct TrajBase {
     phase_mark(kPhIdle);
     if (lane == 0)
       for (int i = 0; i < kPhCount; ++i) atomicAdd(&wn_phase_cycles[i], meta->prof[i]);
+  }
+#endif
+
+#if defined(WN_TIMELINE)
+  int tl_n = 0, tl_skip = 0;
+  __device__ __forceinline__ void timeline_mark(int k) {
+    if (blockIdx.x != 0 || k == kPhRestart || k == kPhReversible) return;
+    if (k == kPhIdle) ++tl_skip;
+    if (tl_skip <= 3) return;  // the workgroup's first chains run while the caches are cold
+    const unsigned long long t = shader_clock();
+    if (lane == 0 && wave == 0 && tl_n < kTimelineMarks) meta->tl[tl_n] = (t << 6) | static_cast<unsigned>(k);
+    ++tl_n;
+  }
+  __device__ __forceinline__ void timeline_end() {
+    if (blockIdx.x != 0 || wave != 0) return;
+    for (int i = lane; i < kTimelineMarks; i += 64) wn_timeline[i] = i < tl_n ? meta->tl[i] : 0ull;
   }
 #endif
 
@@ -431,6 +463,12 @@ struct TrajBase {
   // register backend requests them before the chain's planes and finishes after the momentum has been generated.
   double t_a, t_b, t_c, t_d;  // in flight between the two halves
   int t_i;
+  // The running per-chain statistics a transition updates at its end (sampling: the lp_stats row and the
+  // gradient-evaluation total; warmup: the min-micro handler's two sums).  A backend with kParkScalars requests them
+  // with the tuning scalars and parks them in accumulator registers: read-modify-write at the end of the transition
+  // otherwise stands behind an HBM round trip (~1 800 cycles of a ~73 000-cycle transition, tests/gpu_probes/timeline.py).
+  long long t_g;
+  ParkedDouble k_s0, k_s1, k_s2, k_ge;
   __device__ __forceinline__ void request_tuning(bool warm) {
     const auto& Q = cold();
     if (warm) {
@@ -445,7 +483,14 @@ struct TrajBase {
     } else {
       t_a = Q.step_size[chain];
       t_i = Q.min_micro[chain];
+      if constexpr (Self::kParkScalars) {
+        const double* w = Q.lp_stats + 3ll * chain;
+        t_b = w[0];
+        t_c = w[1];
+        t_d = w[2];
+      }
     }
+    if constexpr (Self::kParkScalars) t_g = Q.grad_evals[chain];
   }
   __device__ __forceinline__ void finish_tuning(bool warm) {
     if (warm) {
@@ -457,10 +502,20 @@ struct TrajBase {
       const double mean_micro = t_c / t_d;
       const long long est = static_cast<long long>(__builtin_round(mean_micro / Q.macro_target));
       min_micro = uni(static_cast<int>(est > Q.cfg_min_micro ? est : Q.cfg_min_micro));
+      if constexpr (Self::kParkScalars) {
+        park(k_s0, t_c);
+        park(k_s1, t_d);
+      }
     } else {
       step = uni(t_a);
       min_micro = uni(t_i);
+      if constexpr (Self::kParkScalars) {
+        park(k_s0, t_b);
+        park(k_s1, t_c);
+        park(k_s2, t_d);
+      }
     }
+    if constexpr (Self::kParkScalars) park(k_ge, wnd::as_f64(static_cast<uint64_t>(t_g)));
   }
   __device__ __forceinline__ void load_tuning(bool warm) {
     request_tuning(warm);
@@ -474,19 +529,34 @@ struct TrajBase {
         const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(Q.warmup_iter));
         Q.est_weight[2 * chain] = discount * w_draw0 + 1;
         Q.est_weight[2 * chain + 1] = discount * w_score0 + 1;
-        Q.mm_state[2 * chain] += static_cast<double>(1ll << depth);  // observe(1 << depth)
-        Q.mm_state[2 * chain + 1] += 1.0;
+        if constexpr (Self::kParkScalars) {
+          Q.mm_state[2 * chain] = fetch(k_s0) + static_cast<double>(1ll << depth);  // observe(1 << depth)
+          Q.mm_state[2 * chain + 1] = fetch(k_s1) + 1.0;
+        } else {
+          Q.mm_state[2 * chain] += static_cast<double>(1ll << depth);
+          Q.mm_state[2 * chain + 1] += 1.0;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) Q.adam[6 * chain + i] = meta->adam[i];
       }
       if (!warm) {  // ChainWorker: logp_stats_.observe(lp), sampler.hpp:87-88 / online_moments.hpp:34-40
         double* w = Q.lp_stats + 3ll * chain;
-        const double n = w[0] + 1;
-        const double delta = lpsel - w[1];
-        const double mean = w[1] + delta / n;
+        double w0, w1, w2;
+        if constexpr (Self::kParkScalars) {
+          w0 = fetch(k_s0);
+          w1 = fetch(k_s1);
+          w2 = fetch(k_s2);
+        } else {
+          w0 = w[0];
+          w1 = w[1];
+          w2 = w[2];
+        }
+        const double n = w0 + 1;
+        const double delta = lpsel - w1;
+        const double mean = w1 + delta / n;
         w[0] = n;
         w[1] = mean;
-        w[2] += delta * (lpsel - mean);
+        w[2] = w2 + delta * (lpsel - mean);
       }
       // host-fed uniforms: a transition that consumed more than were supplied used the filler value
       if (Q.rng_mode == kRngBuffer && n_draw > Q.u_stride) err |= static_cast<int>(kErrVariatesExhausted);
@@ -494,7 +564,11 @@ struct TrajBase {
       if (err) atomicOr(Q.error_flags, static_cast<uint32_t>(err));
       Q.logp_out[chain] = lpsel;
       Q.depth_out[chain] = err ? -1 : depth;
-      Q.grad_evals[chain] += n_grad;
+      if constexpr (Self::kParkScalars) {
+        Q.grad_evals[chain] = static_cast<long long>(wnd::as_u64(fetch(k_ge))) + n_grad;
+      } else {
+        Q.grad_evals[chain] += n_grad;
+      }
       Q.rng_draws[chain] = n_draw;
     }
   }
@@ -738,6 +812,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
   static constexpr int L = Base::L;
   static constexpr bool kHasStartState = true;
   static constexpr bool kZeroCopy = true;
+  static constexpr bool kParkScalars = false;
   static_assert(Model::kElementwise, "the streaming backend needs an element-wise gradient");
 
   // The three vector sets are pool buffers themselves (role slot r: 0-2 cur, 3-5 alt, 6-8 work).  Handing a
@@ -1099,6 +1174,9 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   }
 #if defined(WN_PHASE_PROFILE)
   t.phase_end();
+#endif
+#if defined(WN_TIMELINE)
+  t.timeline_end();
 #endif
 }
 

@@ -145,6 +145,7 @@ constexpr int kSummaryLagSlabChains = 256;
 constexpr int kSummaryCandidateCap = 8;
 inline int uni(int v) { return wnsim::readfirstlane(v); }
 inline double uni(double v) { return wnsim::readfirstlane(v); }
+inline void drain_loads() {}
 struct ParkedDouble {
   double v;
 };

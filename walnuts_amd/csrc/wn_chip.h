@@ -322,6 +322,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     pool_load(k0, th[S]);
     pool_load(k1, rh[S]);
     if (!kNoGrad) pool_load(k2, g[S]);
+    drain_loads();  // (rare path; nothing stays in flight into the set's registers, see wn_gfx950.h)
     this->release(k0);
     this->release(k1);
     this->release(k2);

@@ -123,6 +123,12 @@ __device__ __forceinline__ const __attribute__((address_space(4))) T& kernel_arg
   return *p;
 }
 
+// Wait here for every load this wavefront has in flight (s_waitcnt vmcnt(0) lgkmcnt(0)).  The compiler places its
+// waits where a loaded register is first read and merges "may be in flight" over all control-flow paths: a load
+// into long-lived state registers at the end of a RARE path makes it guard every later use of those registers on
+// the COMMON paths with counted waits -- which also wait for stores (one counter for both on this hardware).
+__device__ __forceinline__ void drain_loads() { __builtin_amdgcn_s_waitcnt(0x0070); }
+
 // read-once / write-once traffic streamed past the L2 (nt)
 __device__ __forceinline__ v2f64 stream_load(const v2f64* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void stream_store(v2f64 v, v2f64* p) { __builtin_nontemporal_store(v, p); }

@@ -189,7 +189,9 @@ double log_sum_exp(const MathOps& m, double x1, double x2) {
   double mx = std::fmax(x1, x2);
   if (std::isnan(x1) || std::isnan(x2)) return std::numeric_limits<double>::quiet_NaN();
   if (std::isinf(mx) || std::isnan(x1 + x2)) return std::fmax(x1, x2);
-  return mx + m.log(m.exp(x1 - mx) + m.exp(x2 - mx));
+  if (m.mode == WNO_MATH_LIBM) return mx + std::log(std::exp(x1 - mx) + std::exp(x2 - mx));
+  // device arithmetic: one of the two exponentials is exp(0) = 1, the other's argument is min - max <= 0
+  return mx + wno_log1pexp(x1 < x2 ? x1 - mx : x2 - mx);
 }
 
 // ---------------------------------------------------------------------------
@@ -1307,5 +1309,6 @@ void wno_stream_normals(uint64_t seed, uint32_t chain, uint32_t transition, uint
 }
 double wno_math_exp(double x) { return wno_exp(x); }
 double wno_math_log(double x) { return wno_log(x); }
+double wno_math_log1pexp(double x) { return wno_log1pexp(x); }
 
 }  // extern "C"

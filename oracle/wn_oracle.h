@@ -161,6 +161,7 @@ void wno_stream_normals(uint64_t seed, uint32_t chain, uint32_t transition, uint
                         double* out);
 double wno_math_exp(double x);
 double wno_math_log(double x);
+double wno_math_log1pexp(double x);  /* log(1 + e^x), x <= 0: the device's log_sum_exp core */
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,8 @@ def lib():
     L.wno_math_exp.argtypes = [dbl]
     L.wno_math_log.restype = dbl
     L.wno_math_log.argtypes = [dbl]
+    L.wno_math_log1pexp.restype = dbl
+    L.wno_math_log1pexp.argtypes = [dbl]
     L.wno_set_sampler_state.argtypes = [vp, _dp, _dp, C.POINTER(C.c_int64)]
     L.wno_set_transition_index.argtypes = [vp, u32]
     L.wno_set_tie_tolerance.argtypes = [vp, dbl]

@@ -156,6 +156,50 @@ WND_HD double dlog_normal(double x, const Tab& tab) {
   return (dk * kLn2Hi + lc) + (l1 + dk * kLn2Lo);
 }
 
+// log(1 + e^d) for d <= 0: the core of log_sum_exp (util.hpp:174-183), which the tree evaluates at every merge on a
+// wave-uniform value -- one wavefront per SIMD pays ~2x for every DEPENDENT instruction, and exp followed by log is a
+// chain of ~70.  Here one table look-up replaces both range reductions:
+//     1 + e^(c + r) = (1 + e^c) (1 + s (e^r - 1)),   s = e^c / (1 + e^c)
+//     log(1 + e^d)  = F(c) + log1p(s * expm1(r)),    c = k/16 nearest d, |r| <= 1/32, |s expm1(r)| < 0.016
+// with (F, s) tabulated for c = 0, -1/16, ..., -48 and two short Taylor polynomials (truncation < 1e-17 relative):
+// ~15 dependent operations around one 16-byte look-up.  Below d = -48 (e^d < 1.5e-21) the table's last entry stands
+// in.  Within 1.5 ulp of log1p(exp(d)) (tests/test_portable_math.py).  `Uniform`: the argument is the same in every
+// lane of the wavefront, the look-up is then a scalar load.
+template <bool Uniform>
+WND_HD double dlog1pexp(double d) {
+  const double dc = (d != d) ? 0.0 : (d < -48.0 ? -48.0 : d);
+  const double kf = __builtin_floor(dc * 16.0 + 0.5);
+  int i = -static_cast<int>(kf);  // 0..768
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (Uniform) i = __builtin_amdgcn_readfirstlane(i);
+#endif
+  const double F = as_f64(wn_tab_l1pe_bits[2 * i]);
+  const double S = as_f64(wn_tab_l1pe_bits[2 * i + 1]);
+  const double r = dc - kf * 0.0625;  // exact
+  // expm1(r) = r + r^2/2 + ... + r^8/8!
+  const double r2 = r * r;
+  const double r4 = r2 * r2;
+  const double p1 = 0.5 + r * 1.66666666666666657e-01;
+  const double p2 = 4.16666666666666644e-02 + r * 8.33333333333333322e-03;
+  const double p3 = 1.38888888888888894e-03 + r * 1.98412698412698413e-04;
+  const double q = (p2 + r2 * p3) + r4 * 2.48015873015873016e-05;
+  const double e1 = r + (r2 * p1 + r4 * q);
+  const double t = S * e1;
+  // log1p(t) = t - t^2/2 + t^3/3 - ... - t^10/10
+  const double t2 = t * t;
+  const double t4 = t2 * t2;
+  const double b0 = -0.5 + t * 3.33333333333333315e-01;
+  const double b1 = -0.25 + t * 2.00000000000000011e-01;
+  const double b2 = -1.66666666666666657e-01 + t * 1.42857142857142849e-01;
+  const double b3 = -0.125 + t * 1.11111111111111105e-01;
+  const double inner = (b2 + t2 * b3) + t4 * -0.1;
+  const double outer = (b0 + t2 * b1) + t4 * inner;
+  const double l = t + t2 * outer;
+  double y = F + l;
+  if (d != d) y = d;
+  return y;
+}
+
 // the tables as plain arrays (host: tests, engine set-up; device: constant memory for the rarely used call sites)
 struct ArrayTables {
   const unsigned long long* e2;

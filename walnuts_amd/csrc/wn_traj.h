@@ -78,8 +78,8 @@ __device__ __forceinline__ double log_sum_exp(double x1, double x2, const Tab& t
   // sit in ONE basic block with whatever vector work surrounds the call and the scheduler can interleave the two.
   const double m = fmax(x1, x2);
   const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
-  // 1 + exp(d) is in [1, 2] (or NaN, patched below): a positive normal number, the short form of log applies
-  double r = m + wnd::dlog_normal(1.0 + wnd::dexp(d, tab), tab);
+  (void)tab;
+  double r = m + wnd::dlog1pexp<true>(d);
   r = (__builtin_isinf(m) || (x1 + x2) != (x1 + x2)) ? m : r;
   r = (x1 != x1 || x2 != x2) ? __builtin_nan("") : r;
   return r;

@@ -434,7 +434,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       finish_energy(part, ke, logp_pos, logp_joint);
       if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
         // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
-        if (is_warmup() && wave == 0) this->adam_observe(wnd::dexp(-fabs(logp_start - logp_joint), this->uniform_tab()));
+        if (is_warmup() && wave == 0) this->adam_record(fabs(logp_start - logp_joint));
       }
       WN_PHASE(kPhRestart);
       if (fabs(logp_start - logp_joint) <= max_error) {
@@ -714,6 +714,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     this->refresh_ids();
     finish_transition(a_sel, row, warm);
     WN_MARK(kPhStored);
+    if (warm && wave == 0) this->adam_flush();
     this->store_scalars(warm, depth, a_lpsel);
     WN_MARK(kPhScalars);
   }
@@ -780,6 +781,16 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
 
   __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
     const auto& Q = this->cold();
+    // warmup: the estimator's four planes are requested before anything else -- they come from HBM (last touched a
+    // launch ago), and requested where they are used, one pair after the other, their two round trips (~2 x 2 000
+    // cycles) stood in the open at the end of every transition
+    double mean[EPL], ssd[EPL], smean[EPL], sssd[EPL];
+    if (warm) {
+      vload_stream(Q.est_draw_mean + row, mean);
+      vload_stream(Q.est_draw_ssd + row, ssd);
+      vload_stream(Q.est_score_mean + row, smean);
+      vload_stream(Q.est_score_ssd + row, sssd);
+    }
     if (kOtherRegs && a_sel == kOther) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) th[0][j] = fetch(oth[j]);
@@ -810,9 +821,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(Q.warmup_iter));
       const double wd = discount * w_draw0 + 1;
       const double ws = discount * w_score0 + 1;
-      double mean[EPL], ssd[EPL];
-      vload_stream(Q.est_draw_mean + row, mean);
-      vload_stream(Q.est_draw_ssd + row, ssd);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {  // online_moments.hpp:184-191 (lazy delta => (y - mean_new)^2)
         mean[j] += (th[0][j] - mean[j]) / wd;
@@ -820,15 +828,13 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       }
       vstore_stream(Q.est_draw_mean + row, mean);
       vstore_stream(Q.est_draw_ssd + row, ssd);
-      vload_stream(Q.est_score_mean + row, mean);
-      vload_stream(Q.est_score_ssd + row, ssd);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
-        mean[j] += (G<0>(j) - mean[j]) / ws;
-        ssd[j] = discount * ssd[j] + (G<0>(j) - mean[j]) * (G<0>(j) - mean[j]);
+        smean[j] += (G<0>(j) - smean[j]) / ws;
+        sssd[j] = discount * sssd[j] + (G<0>(j) - smean[j]) * (G<0>(j) - smean[j]);
       }
-      vstore_stream(Q.est_score_mean + row, mean);
-      vstore_stream(Q.est_score_ssd + row, ssd);
+      vstore_stream(Q.est_score_mean + row, smean);
+      vstore_stream(Q.est_score_ssd + row, sssd);
     }
   }
 };

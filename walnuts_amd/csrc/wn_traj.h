@@ -198,6 +198,8 @@ struct TrajBase {
     carry_armed = false;
     onchip_mask = ~0ull;
     tabs.load(lane);
+    adam_err = 0.0;
+    adam_n = 0;
   }
 
 #if defined(WN_PHASE_PROFILE)
@@ -436,22 +438,49 @@ struct TrajBase {
     return lane_value(draw_lu, slot);
   }
 
-  // adam.hpp:70-86
-  __device__ __forceinline__ void adam_observe(double alpha) {
+  // adam.hpp:70-86, batched.  The reference updates Adam after every macro step (walnuts.hpp:335-338); nothing reads
+  // its state before the NEXT transition (the step size is fixed at a transition's start, adaptive_walnuts.hpp:237),
+  // and one update is ~300 instructions of wave-uniform scalar maths: exp, pow, four divisions and a square root, a
+  // quarter of a warmup leaf's time.  So a macro step only RECORDS its energy error (lane i keeps the i-th), and the
+  // flush evaluates everything that is a pure function of one observation in all lanes at once -- exp(-|error|), the
+  // bias corrections' quotients, lr / t^decay, the square root -- around two short sequential passes for the
+  // recurrences (m, v, the powers of beta; then theta), which keep the reference's order and therefore its bits.
+  double adam_err;  // lane i: |energy error| of the i-th macro step since the last flush
+  int adam_n;
+  __device__ __forceinline__ void adam_record(double abs_error) {
+    adam_err = (lane == adam_n) ? abs_error : adam_err;
+    if (++adam_n == 64) adam_flush();
+  }
+  __device__ __forceinline__ void adam_flush() {
+    const int n = adam_n;
+    adam_n = 0;
+    if (n == 0) return;
     WN_LDS double* a = meta->adam;
     const auto& Q = cold();
     double theta = a[0], m = a[1], v = a[2], t = a[3], b1p = a[4], b2p = a[5];
-    t += 1;
-    b1p *= Q.adam_b1;
-    b2p *= Q.adam_b2;
+    const double alpha = wnd::dexp(-adam_err, gather_tab());  // walnuts.hpp:336 (lanes >= n: values nobody reads)
     const double grad = Q.adam_target - alpha;
-    m = Q.adam_b1 * m + (1 - Q.adam_b1) * grad;
-    v = Q.adam_b2 * v + (1 - Q.adam_b2) * grad * grad;
-    const double m_hat = m / (1 - b1p);
-    const double v_hat = v / (1 - b2p);
-    const double lr_t = Q.adam_lr / wnd::dpow_pos(t, Q.adam_decay, uniform_tab());
+    double m_i = 0.0, v_i = 0.0, b1p_i = 0.0, b2p_i = 0.0;    // lane i: the state after observation i
+    for (int i = 0; i < n; ++i) {
+      const double g = lane_value(grad, i);
+      b1p *= Q.adam_b1;
+      b2p *= Q.adam_b2;
+      m = Q.adam_b1 * m + (1 - Q.adam_b1) * g;
+      v = Q.adam_b2 * v + (1 - Q.adam_b2) * g * g;
+      const bool mine = lane == i;
+      m_i = mine ? m : m_i;
+      v_i = mine ? v : v_i;
+      b1p_i = mine ? b1p : b1p_i;
+      b2p_i = mine ? b2p : b2p_i;
+    }
+    const double t_i = t + static_cast<double>(lane + 1);     // t += 1 per observation: small integers, exact
+    const double m_hat = m_i / (1 - b1p_i);
+    const double v_hat = v_i / (1 - b2p_i);
+    const double lr_t = Q.adam_lr / wnd::dpow_pos(t_i, Q.adam_decay, gather_tab());
     const double denom = __builtin_sqrt(v_hat) + Q.adam_eps;
-    theta -= lr_t * m_hat / denom;
+    const double delta = lr_t * m_hat / denom;
+    for (int i = 0; i < n; ++i) theta -= lane_value(delta, i);
+    t += static_cast<double>(n);
     if (lane == 0) {
       a[0] = theta; a[1] = m; a[2] = v; a[3] = t; a[4] = b1p; a[5] = b2p;
     }
@@ -588,7 +617,7 @@ struct TrajBase {
       self().energy(part, logp_pos, logp_joint);
       if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
         // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
-        if (P.warmup && wave == 0) adam_observe(wnd::dexp(-fabs(logp_start - logp_joint), uniform_tab()));
+        if (P.warmup && wave == 0) adam_record(fabs(logp_start - logp_joint));
       }
       if (fabs(logp_start - logp_joint) <= max_error) {
         WN_PHASE(kPhReversible);
@@ -791,6 +820,7 @@ struct TrajBase {
     WN_PHASE(kPhEpilogue);
     // ---- selected state out (walnuts.hpp:560-562), estimator update (adaptive_walnuts.hpp:247-248) ----
     self().finish_transition(a_sel, row, warm);
+    if (warm && wave == 0) adam_flush();
     store_scalars(warm, depth, a_lpsel);
   }
 };

@@ -97,6 +97,82 @@ static __global__ void chain_sqdev_kernel(View v, const double* mu, double* csq)
   }
   csq[static_cast<long long>(s.c) * v.D + s.d] = q;
 }
+// The same two kernels for the common shape -- few draws per chain, an even number of dimensions, 16-byte aligned
+// rows: a lane owns TWO adjacent columns (16-byte loads: a wavefront's load is 1 KB of one draw) and keeps the chain's
+// at most NMAX draws in registers.  All loads are issued before the first is used (NMAX KB in flight per wavefront),
+// and the second loop of the sample variance reads registers, not memory: ONE pass over the draws where the column
+// loops above make two.  Same operations in the same order per column, hence the same bits.
+constexpr int kRegDraws = 32;
+struct Slot2 {
+  int c, d;
+  bool ok;
+};
+static __device__ __forceinline__ Slot2 slot2_of(const View& v) {
+  const int tiles = (v.D + 127) / 128;
+  const long long wave = static_cast<long long>(blockIdx.x) * kWaves + threadIdx.x / 64;
+  Slot2 s;
+  s.c = static_cast<int>(wave / tiles);
+  s.d = static_cast<int>(wave % tiles) * 128 + 2 * static_cast<int>(threadIdx.x % 64);
+  s.ok = s.c < v.C && s.d < v.D;
+  return s;
+}
+static int slot2_blocks(int C, int D) {
+  const long long waves = static_cast<long long>(C) * ((D + 127) / 128);
+  return static_cast<int>((waves + kWaves - 1) / kWaves);
+}
+template <int NMAX>
+static __global__ __launch_bounds__(kBlock) void chain_moments_wide_kernel(View v, double* csum, double* cmean, double* cvar) {
+  const Slot2 s = slot2_of(v);
+  if (!s.ok) return;
+  const double* p = v.x + v.off[s.c] + s.d;
+  const int n = v.len[s.c];
+  v2f64 r[NMAX];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i)
+    if (i < n) r[i] = wn::stream_load(reinterpret_cast<const v2f64*>(p + static_cast<long long>(i) * v.D));
+  double sum0 = 0.0, sum1 = 0.0;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i)
+    if (i < n) {
+      sum0 += r[i][0];
+      sum1 += r[i][1];
+    }
+  const double mean0 = sum0 / static_cast<double>(n), mean1 = sum1 / static_cast<double>(n);
+  double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i)
+    if (i < n) {
+      const double a = r[i][0] - mean0, b = r[i][1] - mean1;
+      q0 += a * a;
+      q1 += b * b;
+    }
+  const long long o = static_cast<long long>(s.c) * v.D + s.d;
+  *reinterpret_cast<v2f64*>(csum + o) = v2f64{sum0, sum1};
+  *reinterpret_cast<v2f64*>(cmean + o) = v2f64{mean0, mean1};
+  *reinterpret_cast<v2f64*>(cvar + o) =
+      v2f64{q0 / static_cast<double>(n - 1), q1 / static_cast<double>(n - 1)};
+}
+template <int NMAX>
+static __global__ __launch_bounds__(kBlock) void chain_sqdev_wide_kernel(View v, const double* mu, double* csq) {
+  const Slot2 s = slot2_of(v);
+  if (!s.ok) return;
+  const double* p = v.x + v.off[s.c] + s.d;
+  const int n = v.len[s.c];
+  v2f64 r[NMAX];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i)
+    if (i < n) r[i] = wn::stream_load(reinterpret_cast<const v2f64*>(p + static_cast<long long>(i) * v.D));
+  const double m0 = mu[s.d], m1 = mu[s.d + 1];
+  double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i)
+    if (i < n) {
+      const double a = r[i][0] - m0, b = r[i][1] - m1;
+      q0 += a * a;
+      q1 += b * b;
+    }
+  *reinterpret_cast<v2f64*>(csq + static_cast<long long>(s.c) * v.D + s.d) = v2f64{q0, q1};
+}
 // Sums over chains (rows of a [C][width] matrix with row stride `ld`), in two deterministic stages: runs of
 // kChainBlock consecutive chains are summed left to right, then the run totals are summed left to right.  Up to
 // kChainBlock chains this IS the reference's left-to-right loop over chains; beyond, it keeps 65 536-chain
@@ -448,7 +524,9 @@ struct wn_chains {
     N = 0;
     max_len = 0;
     min_len = h_len.empty() ? 0 : h_len[0];
+    offsets_even = true;
     for (size_t c = 0; c < C; ++c) {
+      if (h_off[c] & 1) offsets_even = false;
       h_row0[c] = N;
       N += h_len[c];
       max_len = std::max(max_len, h_len[c]);
@@ -459,14 +537,25 @@ struct wn_chains {
     up(len, h_len);
     HIP_OK(hipStreamSynchronize(stream));
   }
+  // the register-resident two-columns-per-lane kernels apply: short chains, even D, 16-byte aligned rows
+  bool offsets_even = true;
+  bool wide_ok() const {
+    return max_len <= wns::kRegDraws && D % 2 == 0 && offsets_even && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  }
   void ensure_moments() {
     if (have_moments) return;
     use();
     csum.alloc(C * D);
     cmean.alloc(C * D);
     cvar.alloc(C * D);
-    hipLaunchKernelGGL(wns::chain_moments_kernel, dim3(wns::slot_blocks(static_cast<int>(C), static_cast<int>(D))),
-                       dim3(wns::kBlock), 0, stream, view(), csum.p, cmean.p, cvar.p);
+    if (wide_ok()) {
+      hipLaunchKernelGGL(wns::chain_moments_wide_kernel<wns::kRegDraws>,
+                         dim3(wns::slot2_blocks(static_cast<int>(C), static_cast<int>(D))), dim3(wns::kBlock), 0, stream,
+                         view(), csum.p, cmean.p, cvar.p);
+    } else {
+      hipLaunchKernelGGL(wns::chain_moments_kernel, dim3(wns::slot_blocks(static_cast<int>(C), static_cast<int>(D))),
+                         dim3(wns::kBlock), 0, stream, view(), csum.p, cmean.p, cvar.p);
+    }
     HIP_OK(hipGetLastError());
     have_moments = true;
   }
@@ -505,8 +594,14 @@ void device_sample_variance(wn_chains* ch, double* d_out /*device [D]*/) {  // :
   mu.alloc(ch->D);
   csq.alloc(ch->C * ch->D);
   device_mean(ch, mu.p);
-  hipLaunchKernelGGL(wns::chain_sqdev_kernel, dim3(wns::slot_blocks(static_cast<int>(ch->C), static_cast<int>(ch->D))),
-                     dim3(wns::kBlock), 0, ch->stream, ch->view(), mu.p, csq.p);
+  if (ch->wide_ok()) {
+    hipLaunchKernelGGL(wns::chain_sqdev_wide_kernel<wns::kRegDraws>,
+                       dim3(wns::slot2_blocks(static_cast<int>(ch->C), static_cast<int>(ch->D))), dim3(wns::kBlock), 0,
+                       ch->stream, ch->view(), mu.p, csq.p);
+  } else {
+    hipLaunchKernelGGL(wns::chain_sqdev_kernel, dim3(wns::slot_blocks(static_cast<int>(ch->C), static_cast<int>(ch->D))),
+                       dim3(wns::kBlock), 0, ch->stream, ch->view(), mu.p, csq.p);
+  }
   chain_sum(ch, csq.p, static_cast<long long>(ch->D), static_cast<int>(ch->D), nullptr, static_cast<double>(ch->N - 1),
             d_out);
   HIP_OK(hipStreamSynchronize(ch->stream));  // mu/csq are released on return

@@ -26,11 +26,14 @@ def test_reference_known_answers_on_device():
     (7, 130, [90, 64, 77, 120, 33, 101, 64]),     # ragged, three column tiles, several lag blocks
     (64, 300, None),                              # equal lengths
     (700, 66, "ragged"),                          # more chains than one run of the two-stage sums over chains
+    (300, 130, "short"),                          # <= 32 draws, even D: the one-pass two-columns-per-lane moments
 ])
 def test_summaries_match_oracle_bitwise(C, D, lens):
     rng = np.random.default_rng(C * 1000 + D)
     if lens == "ragged":
         lens = [int(n) for n in rng.integers(20, 40, size=C)]
+    if lens == "short":
+        lens = [int(n) for n in rng.integers(3, 33, size=C)]
     lens = lens or [48] * C
     phi = np.where(np.arange(D) % 4 == 0, 0.9, np.where(np.arange(D) % 4 == 1, -0.5, 0.0))
     sp.check_all(sp.ar_chains(rng, C, D, lens, phi))

@@ -604,7 +604,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
           // level-0 merge, combine<Barker> (walnuts.hpp:370-386): old = the even leaf (set 1), new = the odd leaf (set 0)
           WN_PHASE(kPhCombine);
           {
-            const double total = uni(log_sum_exp(e_lj, leaf_lj, this->uniform_tab()));
+            const double total = uni(log_sum_exp(e_lj, leaf_lj));
             if (pair_turned) {  // walnuts.hpp:490-492
               ok = false;
               break;
@@ -668,7 +668,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       double total;
       if (kFirst) {
         turned = top_turned;
-        total = uni(log_sum_exp(a_logsum, c_logsum, this->uniform_tab()));
+        total = uni(log_sum_exp(a_logsum, c_logsum));
       } else {
         this->lse_on_leader(a_logsum, c_logsum);
         if (kOtherRegs) {

@@ -70,15 +70,12 @@ struct GatherTab {  // every lane has its own argument
   __device__ __forceinline__ double logc(int i) const { return __shfl(t.lc, i, 64); }
 };
 
-// util.hpp:174-183.  One of exp(x1-m), exp(x2-m) is exp(0) == 1 exactly, so only the other one is
-// evaluated; the sum is commutative, hence the same bits as the two-exp form.
-template <class Tab>
-__device__ __forceinline__ double log_sum_exp(double x1, double x2, const Tab& tab) {
-  // Branch-free: the special cases are patched in at the end, so the ~100 dependent instructions of the exp / log pair
-  // sit in ONE basic block with whatever vector work surrounds the call and the scheduler can interleave the two.
+// util.hpp:174-183 on wave-uniform arguments.  One of exp(x1-m), exp(x2-m) is exp(0) == 1 exactly, so the sum inside
+// the logarithm is 1 + e^d with d = min - max <= 0: wnd::dlog1pexp (one table look-up, wn_devmath.h).  Branch-free:
+// the special cases are patched in at the end, so the call sits in ONE basic block with the vector work around it.
+__device__ __forceinline__ double log_sum_exp(double x1, double x2) {
   const double m = fmax(x1, x2);
   const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
-  (void)tab;
   double r = m + wnd::dlog1pexp<true>(d);
   r = (__builtin_isinf(m) || (x1 + x2) != (x1 + x2)) ? m : r;
   r = (x1 != x1 || x2 != x2) ? __builtin_nan("") : r;
@@ -348,7 +345,7 @@ struct TrajBase {
   // wavefront 0 evaluates it, BEFORE the test, and the value travels to the other wavefronts of the chain in the LDS
   // exchange the test's reduction does anyway -- their SIMDs run other chains' waves meanwhile.
   __device__ __forceinline__ void lse_on_leader(double x1, double x2) {
-    if (NW == 1 || wave == 0) carry = log_sum_exp(x1, x2, uniform_tab());
+    if (NW == 1 || wave == 0) carry = log_sum_exp(x1, x2);
     carry_armed = NW > 1;
   }
   __device__ __forceinline__ double sum1(double a) {

@@ -187,6 +187,9 @@ def test_deep_trees_and_halvings():
     parity.run_case("std_normal", 64, 64, warmup=0, sampling=6, step=2.9, max_trajectory_doublings=4,
                     check_every=3)  # huge step: halving levels + reversibility checks
     parity.run_case("funnel", 32, 64, warmup=10, sampling=10, step=1.5, max_step_halvings=8, check_every=5)
+    # adaptive warmup with a tiny first step: hundreds of macro steps per transition, so Adam's batched update
+    # (64 observations per flush) takes its mid-transition flushes as well as the one at the end
+    parity.run_case("std_normal", 64, 32, warmup=4, sampling=2, step=0.02, max_trajectory_doublings=8, check_every=1)
 
 
 @pytest.mark.parametrize("kw", [

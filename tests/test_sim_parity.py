@@ -57,6 +57,15 @@ def test_emulated_engine_halving_and_reversibility(sim, oracle):
 
 
 @pytest.mark.timeout(600)
+def test_emulated_batched_adam_flushes_mid_transition(sim, oracle):
+    # warmup from a tiny step: more than 64 macro steps in a transition, so the batched Adam update (wn_traj.h
+    # adam_record / adam_flush) flushes a full register of observations mid-transition and the rest at its end
+    dev, orc = parity.run_case("std_normal", 6, 2, warmup=3, sampling=1, lib_path=sim, step=0.01,
+                               max_trajectory_doublings=7, check_every=1)
+    assert dev.grad_evals().max() > 64
+
+
+@pytest.mark.timeout(600)
 def test_emulated_streaming_backend_halvings_and_deep_trees(sim, oracle):
     # the streaming kernels' buffer hand-over under retries, reversibility passes (multi-step leaves) and deeper trees
     parity.run_case("std_normal", 140, 2, warmup=0, sampling=3, lib_path=sim, geometry=(1, -1), step=2.9,

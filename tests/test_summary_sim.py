@@ -31,7 +31,7 @@ def test_emulated_summaries_match_oracle_bitwise(sim, oracle):
     # short chains, even D: the one-pass moments with two columns per lane (a second, nearly empty column tile)
     D = 130
     phi = np.where(np.arange(D) % 3 == 0, 0.9, -0.3)
-    sp.check_all(sp.ar_chains(rng, 4, D, [32, 3, 17, 8], phi), lib_path=sim, probs=(0.25,))
+    sp.check_all(sp.ar_chains(rng, 3, D, [32, 3, 17], phi), lib_path=sim, probs=(0.25,), full_acov=False)
     # more order statistics than one radix-select sweep holds; duplicates, negative values, zeros of both signs
     x = rng.integers(-3, 4, size=(30, 3)).astype(float)
     x[x == 0] *= np.where(rng.uniform(size=(x == 0).sum()) < 0.5, -1.0, 1.0)

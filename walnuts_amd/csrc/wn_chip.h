@@ -13,12 +13,17 @@
 //    everywhere; the one single-leaf extension of a transition (the first doubling) copies once.
 //  * Level-0 merges never touch memory: both leaves of the pair are in registers when the odd leaf is done, and the
 //    two U-turn products (walnuts.hpp:192-201) ride in the SAME reduction as the leaf's two energies (sum4).
-//  * Three-tier span pool behind the wave-uniform buffer indices: LDS vectors, then RP vectors kept in VGPRs
-//    (statically indexed, reached through a wave-uniform switch), then -- only when a deep tree needs more than
-//    the chip holds -- the HBM arena.  With 4 chains per CU at D = 1024 that is 4 + 6 vectors on chip against a
-//    worst case of 12 live pool vectors at the default five doublings.
+//  * Three-tier span pool behind the wave-uniform buffer indices: LDS vectors, then RP vectors kept in VGPR banks
+//    (indexed with s_set_gpr_idx; built and measured, but any bank makes the allocator spill at these sizes, so
+//    chip_bank_a/b() return 0: DESIGN.md section 5), then -- only when a deep tree needs more than the chip holds
+//    -- the HBM arena.  With 4 chains per CU at D = 1024 that is 4 vectors in LDS (+ the span's other end in
+//    registers) against a worst case of 12 live pool vectors at the default five doublings.
 //  * The "other" end of the accumulated span is one (theta, rho[, grad]) triple that is swapped with the moving
-//    end when the walk turns around; nothing is written while the walk keeps its direction.
+//    end when the walk turns around; nothing is written while the walk keeps its direction.  For models whose
+//    gradient is recomputed it is parked in accumulator registers (AGPRs), which vector arithmetic cannot read and
+//    the register allocator therefore leaves alone.
+//  * The first doubling (a single leaf) is peeled out of the doubling loop: the two shapes share one generic lambda
+//    but not their register assignments -- in one loop the allocator re-homed whole vectors on every doubling.
 #pragma once
 
 #include <type_traits>
@@ -65,8 +70,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   double th[2][EPL], rh[2][EPL], g[2][EPL];  // the two sets of the moving end (g is dead when kNoGrad)
   double im[EPL], mp[EPL];                    // inverse mass diagonal, model parameters
   // The accumulated span's other end.  When the gradient is recomputed from theta (kNoGrad) the pair (theta, rho)
-  // has registers of its own instead of two pool buffers: the top-level U-turn test reads it in place, turning
-  // around is a register swap, and the pool's LDS vectors all serve the span stack.
+  // has registers of its own instead of two pool buffers -- accumulator registers, parked there explicitly
+  // (ParkedDouble, wn_gfx950.h): the top-level U-turn test fetches it, turning around exchanges it with the moving
+  // end, and the pool's LDS vectors all serve the span stack.
 #if defined(WN_NO_OTHER_REGS)
   static constexpr bool kOtherRegs = false;
 #else

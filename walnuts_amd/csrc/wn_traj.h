@@ -24,7 +24,7 @@
 //   combine        walnuts.hpp:368-387      inline in Traj::run (Barker / Metropolis)
 //   logp_momentum  util.hpp:220-223         Traj::energy
 //   log_sum_exp    util.hpp:174-183         log_sum_exp
-//   Adam           adam.hpp:70-93           Traj::adam_observe
+//   Adam           adam.hpp:70-93           Traj::adam_record / adam_flush (batched per transition)
 //   MassEstimator / OnlineMoments / MinMicroStepsAdaptHandler
 //                  adaptive_walnuts.hpp:54-94,127-157,234-251; online_moments.hpp:184-191
 //

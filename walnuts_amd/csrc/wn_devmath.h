@@ -261,13 +261,23 @@ struct U4 {
   uint32_t x, y, z, w;
 };
 
+// a ^ b ^ c: one instruction on gfx950 (v_bitop3_b32 with the parity truth table), which the compiler does not form
+// from two xors when one operand is a round key in a scalar register
+WND_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 WND_HD U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int round = 0; round < 10; ++round) {
     const uint64_t pa = static_cast<uint64_t>(0xD2511F53u) * c0;
     const uint64_t pb = static_cast<uint64_t>(0xCD9E8D57u) * c2;
-    const uint32_t n0 = static_cast<uint32_t>(pb >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = static_cast<uint32_t>(pa >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = xor3(static_cast<uint32_t>(pb >> 32), c1, k0);
+    const uint32_t n2 = xor3(static_cast<uint32_t>(pa >> 32), c3, k1);
     c1 = static_cast<uint32_t>(pb);
     c3 = static_cast<uint32_t>(pa);
     c0 = n0;

@@ -22,6 +22,13 @@ __global__ void probe(double* out, unsigned long long* cyc, double seed) {
       if (OP == 5) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(*(int*)&v[c]) : "v"(threadIdx.x));
       if (OP == 6) asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %0, a0" : "+v"(*(int*)&v[c]) : : "a0");
       if (OP == 7) asm volatile("v_readlane_b32 s20, %0, 3\n v_writelane_b32 %0, s20, 5" : "+v"(*(int*)&v[c]) : : "s20");
+      // the cross-lane steps of the reductions, each as a dependent chain (result feeds the next step)
+      if (OP == 8) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(*(int*)&v[c]));
+      if (OP == 9) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(*(int*)&v[c]), "+v"(((int*)&v[c])[1]));
+      if (OP == 10) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(*(int*)&v[c]), "+v"(((int*)&v[c])[1]));
+      if (OP == 11) asm volatile("v_readfirstlane_b32 s20, %0\n v_mov_b32 %0, s20" : "+v"(*(int*)&v[c]) : : "s20");
+      if (OP == 12) asm volatile("v_readlane_b32 s20, %0, 3\n v_add_u32 %0, s20, %0" : "+v"(*(int*)&v[c]) : : "s20");
+
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -50,5 +57,10 @@ int main() {
   run<1, 5>("v_xor_b32"); run<8, 5>("v_xor_b32");
   run<1, 6>("acc wr+rd pair"); run<8, 6>("acc wr+rd pair");
   run<1, 7>("readl+writel"); run<8, 7>("readl+writel");
+  run<1, 8>("mov_dpp"); run<4, 8>("mov_dpp");
+  run<1, 9>("permlane32_swap"); run<4, 9>("permlane32_swap");
+  run<1, 10>("permlane16_swap"); run<4, 10>("permlane16_swap");
+  run<1, 11>("readfirstl+mov"); run<4, 11>("readfirstl+mov");
+  run<1, 12>("readl+add_u32(s)"); run<4, 12>("readl+add_u32(s)");
   return 0;
 }

@@ -1,6 +1,8 @@
 """GPU tier (-m gpu): the HIP path through the C ABI against the oracle, bit for bit, on seeded inputs
 sized so that the oracle finishes in seconds, plus size-independent properties at BASELINE.json's full
 sizes.  Nothing here reads /root/reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -205,6 +207,19 @@ def test_streaming_backend_edge_configurations(kw):
     cases as the register kernels, warmup included."""
     parity.run_case("diag_normal", 700, 12, warmup=4, sampling=5, geometry=(2, -1), **kw)
     parity.run_case("std_normal", 9000, 3, warmup=2, sampling=3, **kw)           # default: streaming above 8192
+
+
+def test_randomised_parity_campaign():
+    """A short fixed-seed run of the randomised campaign (tests/gpu_probes/fuzz_parity.py: random model, dimension,
+    geometry, pool tiers, step size, depth / halving / micro-step limits): every case bit-exact against the oracle.
+    The 10-minute run of the round is filed as profiles/r02/fuzz_parity.txt (45 245 cases, 0 failing)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_probes", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    done, failed, _ = fz.campaign(seed=3, seconds=15.0)
+    assert done > 100 and not failed, failed[:3]
 
 
 def test_host_supplied_variates_path():

@@ -1,0 +1,18 @@
+#!/bin/bash
+# the bench's same-run parity gate (device vs the REFERENCE-ORDER oracle: sequential sums, libm; identical trees
+# required, near-tie audit) widened: 512 chains x 24 transitions for every bench configuration
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp; export TMPDIR=/tmp
+gate() {
+  local tag=$1; shift
+  python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 --gate-chains 512 --gate-transitions 24 "$@" 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); g=d['parity_gate']
+print('$tag', 'chains', g['chains'], 'transitions', g['transitions'], 'tree_mismatches', g['tree_mismatches'], 'max_rel_diff_positions', g['max_rel_diff'], 'max_rel_diff_logp %.3e' % g['max_rel_diff_logp'], 'within_1e-10', g['within_1e-10'], 'near_ties', {k: v['near'] for k, v in g['near_ties_1e-12'].items()}, 'decisions', {k: v['decisions'] for k, v in g['near_ties_1e-12'].items()})"
+}
+gate headline
+gate cfg2 --model ill_normal --chains 4096 --dim 1024 --adapt-iters 300
+gate cfg3 --model funnel --chains 16384 --dim 128 --adapt-iters 300
+gate funnel1024 --model funnel --chains 16384 --dim 1024 --adapt-iters 150
+gate rw1 --model rw1 --chains 16384 --dim 1024 --adapt-iters 150
+gate d256 --chains 65536 --dim 256

@@ -143,40 +143,51 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   }
 
   // ---- vector buffers -----------------------------------------------------------------------------
+  // the lane's byte offset inside a pair row, rebuilt at every vector operation (behind an optimisation barrier): left
+  // alone, the compiler keeps one 64-bit per-lane offset per pair-row group alive for the whole kernel
+  __device__ __forceinline__ const char* lane_base(const double* base) const {
+    unsigned long long lo = static_cast<unsigned long long>(static_cast<uint32_t>(tid)) * 16ull;
+    asm volatile("" : "+v"(lo));
+    return reinterpret_cast<const char*>(base) + lo;
+  }
   __device__ __forceinline__ void vload(const double* base, double (&v)[EPL]) const {
+    const char* lb = lane_base(base);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const v2f64 t = *reinterpret_cast<const v2f64*>(base + (k * L + tid) * 2);
+      const v2f64 t = *reinterpret_cast<const v2f64*>(lb + k * (16 * L));
       v[2 * k] = t[0];
       v[2 * k + 1] = t[1];
     }
   }
   __device__ __forceinline__ void vstore(double* base, const double (&v)[EPL]) const {
+    const char* lb = lane_base(base);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       v2f64 t;
       t[0] = v[2 * k];
       t[1] = v[2 * k + 1];
-      *reinterpret_cast<v2f64*>(base + (k * L + tid) * 2) = t;
+      *reinterpret_cast<v2f64*>(const_cast<char*>(lb) + k * (16 * L)) = t;
     }
   }
   // the chain's own planes are read once and written once per transition: streamed past the L2 (nt) so that they
   // do not evict the arena vectors a deep tree spills there
   __device__ __forceinline__ void vload_stream(const double* base, double (&v)[EPL]) const {
+    const char* lb = lane_base(base);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const v2f64 t = stream_load(reinterpret_cast<const v2f64*>(base + (k * L + tid) * 2));
+      const v2f64 t = stream_load(reinterpret_cast<const v2f64*>(lb + k * (16 * L)));
       v[2 * k] = t[0];
       v[2 * k + 1] = t[1];
     }
   }
   __device__ __forceinline__ void vstore_stream(double* base, const double (&v)[EPL]) const {
+    const char* lb = lane_base(base);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       v2f64 t;
       t[0] = v[2 * k];
       t[1] = v[2 * k + 1];
-      stream_store(t, reinterpret_cast<v2f64*>(base + (k * L + tid) * 2));
+      stream_store(t, reinterpret_cast<v2f64*>(const_cast<char*>(lb) + k * (16 * L)));
     }
   }
   __device__ __forceinline__ void lds_load(const WN_LDS double* base, double (&v)[EPL]) const {
@@ -377,9 +388,10 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       return;
     }
     const double* base = arena + static_cast<long long>(kk - n_reg) * kDp;
+    const char* lb = lane_base(base);
 #pragma unroll
     for (int k = 0; k < CH / 2; ++k) {
-      const v2f64 t = *reinterpret_cast<const v2f64*>(base + ((k0 + k) * L + tid) * 2);
+      const v2f64 t = *reinterpret_cast<const v2f64*>(lb + (k0 + k) * (16 * L));
       v[2 * k] = t[0];
       v[2 * k + 1] = t[1];
     }

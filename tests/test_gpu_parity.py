@@ -209,6 +209,17 @@ def test_streaming_backend_edge_configurations(kw):
     parity.run_case("std_normal", 9000, 3, warmup=2, sampling=3, **kw)           # default: streaming above 8192
 
 
+def test_model_geometry_hint():
+    """A model may state the elements per lane it prefers (wn_model_api.h: kPreferredElemsPerLane; models/rw1.h asks
+    for 4): the engine takes the fewest wavefronts that hold num_params at that width, an explicit request wins."""
+    cfg = wa.default_config()
+    assert wa.DeviceEngine(wa.MODEL_RW1, 1024, 8, cfg).lanes == 256          # 4 wavefronts x 4 elements per lane
+    assert wa.DeviceEngine(wa.MODEL_RW1, 200, 8, cfg).lanes == 64            # 1 x 4
+    assert wa.DeviceEngine(wa.MODEL_STD_NORMAL, 1024, 8, cfg).lanes == 64    # default policy: 1 x 16
+    cfg = wa.default_config(waves_per_chain=1, elems_per_lane=16)
+    assert wa.DeviceEngine(wa.MODEL_RW1, 1024, 8, cfg).lanes == 64
+
+
 def test_randomised_parity_campaign():
     """A short fixed-seed run of the randomised campaign (tests/gpu_probes/fuzz_parity.py: random model, dimension,
     geometry, pool tiers, step size, depth / halving / micro-step limits): every case bit-exact against the oracle.

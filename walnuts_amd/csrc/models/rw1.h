@@ -16,6 +16,10 @@ struct Rw1Model {
   static constexpr bool kElementwise = false;
   static constexpr bool kGradIsNegTheta = false;
   static constexpr bool kCheapGrad = false;
+  // geometry hint (optional): every evaluation exchanges neighbours across lanes and keeps four vectors per set, so
+  // more, narrower wavefronts win -- measured at 1 024 dimensions: 2.70 ms with (4 waves, 4 elements per lane) against
+  // 2.89 ms with the default (1, 16)
+  static constexpr int kPreferredElemsPerLane = 4;
   __device__ __forceinline__ static double grad_elem(double, double) { return 0.0; }
   struct Aux {};
 

@@ -288,7 +288,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.C = num_chains;
   e.cfg = cfg;
   e.device = cfg.device;
-  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params);
+  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params, ops.preferred_epl);
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
@@ -843,7 +843,8 @@ int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {
 }
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {
   try {
-    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, wn::model_ops(model).uses_params).nw;
+    return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, wn::model_ops(model).uses_params,
+                                    wn::model_ops(model).preferred_epl).nw;
   } catch (...) {
     return -1;
   }

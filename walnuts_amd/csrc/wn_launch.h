@@ -64,7 +64,8 @@ inline bool geometry_exists(int nw, int epl) {
 }
 
 // elems_per_lane == -1 requests the streaming backend explicitly (it is the default above kMaxRegisterDim)
-inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool params_in_registers = false) {
+inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool params_in_registers = false,
+                                int preferred_epl = 0) {
   Geometry g{0, 0, false};
   if (epl_req < 0 || (dim > kMaxRegisterDim && epl_req == 0)) {
     g.mem = true;
@@ -78,6 +79,12 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool params_in
     g.nw = nw_req;
     g.epl = epl_req;
     return g;
+  }
+  // a model's own hint (wn_model_api.h: kPreferredElemsPerLane): the fewest wavefronts that hold the vectors at that
+  // many elements per lane
+  if (preferred_epl > 0) {
+    for (int nw = 1; nw <= 16; nw *= 2)
+      if (geometry_exists(nw, preferred_epl) && 64 * nw * preferred_epl >= dim) return Geometry{nw, preferred_epl, false};
   }
   // measured on MI355X (profiles/): the wave-uniform tree logic is replicated in every wavefront of a chain and
   // every reduction of a multi-wavefront chain is an LDS exchange behind a barrier, so ONE wavefront per chain wins
@@ -130,6 +137,7 @@ struct ModelOps {
   const char* name;
   bool uses_params;   // needs a parameter vector of num_params doubles
   bool elementwise;   // has streaming (num_params > 8192) kernels
+  int preferred_epl;  // the model's geometry hint: elements per lane (0 = the default policy)
   void (*launch_transition)(const Geometry&, int grid, size_t smem, hipStream_t, const Params&);
   void (*launch_init)(const Geometry&, int grid, size_t smem, hipStream_t, const InitParams&);
   void (*prepare)(const Geometry&, size_t smem);

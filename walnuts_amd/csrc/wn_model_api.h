@@ -30,6 +30,11 @@
 //     // check num_params.  Throw std::invalid_argument to reject (-> error type `config`).
 //     static void host_params(double* params, int num_params);
 //     static void validate(int num_params);
+//     // optional: geometry hint -- elements per lane (2, 4, 8 or 16); the engine then takes the fewest wavefronts per
+//     // chain that hold num_params at that width instead of its default policy (one wavefront up to 1 024
+//     // dimensions).  A model whose evaluation exchanges data across lanes or keeps many live vectors may prefer
+//     // more, narrower wavefronts (models/rw1.h); an explicit waves_per_chain / elems_per_lane request still wins.
+//     static constexpr int kPreferredElemsPerLane;
 //   };
 //
 // What `cx` offers (all of it collective: every lane of the chain's workgroup must make the same calls):

@@ -89,13 +89,14 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool params_in
   // measured on MI355X (profiles/): the wave-uniform tree logic is replicated in every wavefront of a chain and
   // every reduction of a multi-wavefront chain is an LDS exchange behind a barrier, so ONE wavefront per chain wins
   // as long as the vectors fit its registers (16 elements per lane = 1024 dimensions: 2.43 ms against 2.57 ms for
-  // two wavefronts on the headline workload); beyond that, as few wavefronts as possible
-  // ... except that a model with a per-coordinate parameter vector holds 32 more registers at 16 elements per lane,
-  // which the one-wavefront kernel pays for in AGPR traffic: two wavefronts are faster there (config #2,
-  // 4 096 x 1 024 ill-conditioned normal: 2.89e8 against 2.62e8 gradient evaluations per second)
-  static const int pref_all[][2] = {{1, 2}, {1, 4}, {1, 8}, {1, 16}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
-  static const int pref_par[][2] = {{1, 2}, {1, 4}, {1, 8}, {2, 8}, {4, 8}, {8, 8}, {16, 8}, {16, 8}};
-  const int(*pref)[2] = params_in_registers ? pref_par : pref_all;
+  // two wavefronts on the headline workload); beyond that, as few wavefronts as possible.
+  // (A model with a per-coordinate parameter vector holds 32 more registers at 16 elements per lane; while the
+  // compiler used the accumulator file as it saw fit that made two wavefronts faster for such models.  With the
+  // span's other end parked explicitly it no longer does -- config #2, 4 096 x 1 024 ill-conditioned normal:
+  // 3.78e8 gradient evaluations per second with (1, 16) against 3.60e8 with (2, 8) -- so `params_in_registers`
+  // does not change the choice any more.)
+  (void)params_in_registers;
+  static const int pref[][2] = {{1, 2}, {1, 4}, {1, 8}, {1, 16}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
   const int npref = 8;
   for (int i = 0; i < npref; ++i) {
     const int* p = pref[i];

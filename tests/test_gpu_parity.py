@@ -223,7 +223,7 @@ def test_model_geometry_hint():
 def test_randomised_parity_campaign():
     """A short fixed-seed run of the randomised campaign (tests/gpu_probes/fuzz_parity.py: random model, dimension,
     geometry, pool tiers, step size, depth / halving / micro-step limits): every case bit-exact against the oracle.
-    The long runs of the round are filed as profiles/r02/fuzz_parity.txt (190 504 cases, 0 failing)."""
+    The long runs of the round are filed as profiles/r02/fuzz_parity.txt (222 056 cases, 0 failing)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_probes", "fuzz_parity.py"))

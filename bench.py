@@ -7,7 +7,11 @@ SamplingConfig, parameters adapted by `--adapt-iters` on-device warmup transitio
 timed sampling transitions.  Inputs are generated on the device (counter-based stream) and are resident in HBM
 when the timed region starts.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or started
+plainly -- then this process, before it touches the GPU, starts the N ranks itself (`launch_ranks`) and forwards
+rank 0's JSON line; it fails when the node has fewer than N GPUs.
 
 Multi-GPU (`--scaling`): "strong" (default, the north star's target: the 65 536 chains are SHARDED over the N
 GPUs) or "weak" (`--chains` per GPU).  `--config 5` = BASELINE config #5: 262 144 chains sharded over the GPUs.
@@ -69,7 +73,9 @@ def parse():
     ap.add_argument("--elems-per-lane", type=int, default=0)
     ap.add_argument("--workgroups-per-cu", type=int, default=0)
     ap.add_argument("--lds-vectors", type=int, default=-1)
-    ap.add_argument("--reg-vectors", type=int, default=-1)
+    ap.add_argument("--fma", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1: fused multiply-adds in the integrator (library default), 0: every product rounded (the "
+                         "element-wise bits of the reference's x86-64 -O3 build); -1: the library default")
     ap.add_argument("--reserved-cus", type=int, default=-1,
                     help="CUs left free for the RCCL all-gather kernels (default: 0 on one GPU, 16 otherwise)")
     ap.add_argument("--gather-every", type=int, default=1,
@@ -108,13 +114,19 @@ def oracle_model(name):
 
 
 def csrc_sha():
-    """Hash of the kernel sources this library was built from (what a recorded PMC measurement is valid for)."""
+    """Hash of the kernel sources this library was built from (what a recorded PMC measurement is valid for): every
+    source file under walnuts_amd/csrc, sub-directories (models/) included, plus out-of-tree model sources named in
+    $MODELS.  profiles/pmc.sh calls this function -- one definition."""
     d = os.path.join(ROOT, "walnuts_amd", "csrc")
+    files = []
+    for base, _, names in os.walk(d):
+        files += [os.path.join(base, f) for f in names if f.endswith((".h", ".hip", ".inc")) or f == "Makefile"]
+    files = sorted(files, key=lambda p: os.path.relpath(p, d))
+    files += [p for p in os.environ.get("MODELS", "").split() if os.path.isfile(p)]
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip", ".inc")) or f == "Makefile":
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for p in files:
+        h.update(os.path.relpath(p, d).encode())
+        h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -258,8 +270,64 @@ def parity_gate(args, D, cfg_kwargs):
             "near_ties_1e-12": {k: {"near": v[0], "decisions": v[1]} for k, v in ties.items()}}
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv, script=None, device_count=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: THIS process never touches the GPU (it
+    counts devices, which does not initialise HIP on this image, and nothing else); it starts the N ranks as fresh
+    child processes through torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1), forwards rank 0's
+    JSON line to stdout (everything else the children print goes to stderr) and returns their exit code.
+    Fewer than N devices is an error -- except with `--backend gloo`, where the ranks share the devices there are
+    (rank r -> device r mod device_count): that exercises the N > 1 path on a one-GPU box, it is not a scaling run."""
+    import subprocess
+
+    if device_count is None:
+        import torch
+
+        device_count = torch.cuda.device_count()
+    if device_count < args.gpus and args.backend != "gloo":
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node shows {device_count} "
+              "(use --backend gloo to run the ranks on the devices there are)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            rec = json.loads(line)
+            if rec.get("n_gpus") != args.gpus:
+                print(f"bench.py: the ranks report n_gpus={rec.get('n_gpus')}, --gpus was {args.gpus}", file=sys.stderr)
+                proc.wait()
+                return 3
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {lines}", file=sys.stderr)
+        return 4
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     import torch
 
     import walnuts_amd as wa
@@ -268,7 +336,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
@@ -299,8 +367,9 @@ def main():
     # few CUs stay free so that RCCL's all-gather of the previous draws really runs underneath it
     reserved = args.reserved_cus if args.reserved_cus >= 0 else (16 if world > 1 else 0)
     cfg_kwargs = dict(device=local_rank, waves_per_chain=args.waves_per_chain, elems_per_lane=args.elems_per_lane,
-                      workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors,
-                      reg_vectors=args.reg_vectors)
+                      workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors)
+    if args.fma >= 0:
+        cfg_kwargs["fused_multiply_add"] = args.fma
     cfg = wa.default_config(reserved_cus=reserved, **cfg_kwargs)
     eng = wa.DeviceEngine(model_id, D, C, cfg, params=params)
     if world > 1:
@@ -394,9 +463,9 @@ def main():
                                         "note": "56*D bytes per grad-eval by the metric's definition; the trajectory "
                                                 "end lives in VGPRs and the span pool in LDS, so these bytes never "
                                                 "reach HBM and this is not a bandwidth"},
-                        "note": "useful fp64 flops = 10*D per grad-eval (no FMA contraction: element-wise results carry "
-                                "the reference's bits); the kernel is bound by dependent-latency and issue of the fp64 "
-                                "vector pipe, not by HBM"}
+                        "note": "useful fp64 flops = 10*D per grad-eval (SURVEY.md section 8d's count, whether or not a "
+                                "multiply-add is issued as one instruction); the kernel is bound by dependent latency "
+                                "and issue of the fp64 vector pipe -- one wavefront per SIMD -- not by HBM"}
             assert roofline["frac"] <= 1.0 and (roofline["traffic_frac"] or 0.0) <= 1.0
         out = {
             "metric": "leapfrog grad-evals/sec (all chains)",
@@ -422,6 +491,9 @@ def main():
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
                              "reserved_cus": reserved},
                 "grad_evals_per_transition_per_chain": grad_evals / max(args.steps, 1) / C,
+                "arithmetic": ("fused multiply-adds in the integrator (as an FMA-target build of the reference)"
+                               if cfg.fused_multiply_add else
+                               "every product rounded (the reference's x86-64 -O3 element-wise bits)"),
                 "csrc_sha": csrc_sha(),
             },
             "roofline": roofline,

@@ -111,8 +111,14 @@ typedef struct wn_config {
   int32_t lds_vectors;              /* span-pool vectors kept in LDS (-1: as many as fit) */
   int32_t reserved_cus;             /* compute units the persistent grid leaves free (e.g. for RCCL kernels that
                                        all-gather the previous iteration's draws while this one runs); 0 */
-  int32_t reg_vectors;              /* span-pool vectors kept in VGPRs (-1: as many as the kernel was built with);
-                                       what fits neither LDS nor registers overflows to an HBM arena */
+  int32_t fused_multiply_add;       /* 1 (default; WALNUTS_AMD_FMA=0 in the environment makes it 0): the multiply-adds of
+                                       the integrator (walnuts.hpp:228-231,329-332), of logp_momentum (util.hpp:222),
+                                       of the U-turn products (walnuts.hpp:196-200) and of the built-in models' log
+                                       densities are single fused operations, as in a build of the reference for an
+                                       FMA target (aarch64, x86-64 -march=haswell and later).  0: every product is
+                                       rounded before it is added -- the element-wise bits of the reference built
+                                       as its CMake files build it on x86-64 (-O3, SSE2).  Both meet the <= 1e-10
+                                       bar against the reference order; the fused kernels are ~10 % faster. */
 } wn_config;
 
 WALNUTS_HIP_EXPORT void wn_default_config(wn_config* cfg);

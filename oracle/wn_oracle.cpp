@@ -55,6 +55,29 @@ struct MathOps {
 // ---------------------------------------------------------------------------
 struct Reducer {
   int L = 0;
+  // sum of a(i) * b(i) in the same order; `fused`: every partial is fma(a, b, partial), as the kernels' mad() does
+  template <class A, class B>
+  double sum_prod(size_t n, A a, B b, bool fused) const {
+    if (!fused) return sum(n, [&](size_t i) { return a(i) * b(i); });
+    if (L <= 0) {
+      double s = 0.0;
+      for (size_t i = 0; i < n; ++i) s = std::fma(a(i), b(i), s);
+      return s;
+    }
+    const size_t lanes = static_cast<size_t>(L);
+    std::vector<double> part(lanes, 0.0);
+    const size_t slots = (n + 2 * lanes - 1) / (2 * lanes);
+    for (size_t l = 0; l < lanes; ++l) {
+      double p = 0.0;
+      for (size_t k = 0; k < slots; ++k) {
+        size_t i0 = (k * lanes + l) * 2;
+        if (i0 < n) p = std::fma(a(i0), b(i0), p);
+        if (i0 + 1 < n) p = std::fma(a(i0 + 1), b(i0 + 1), p);
+      }
+      part[l] = p;
+    }
+    return butterfly(part);
+  }
   template <class F>
   double sum(size_t n, F f) const {
     if (L <= 0) {
@@ -74,6 +97,11 @@ struct Reducer {
       }
       part[l] = p;
     }
+    return butterfly(part);
+  }
+  // lane partials -> total: xor butterfly inside each group of 64 lanes, groups added left to right
+  double butterfly(std::vector<double>& part) const {
+    const size_t lanes = part.size();
     double total = 0.0;
     bool first = true;
     std::vector<double> tmp(64);
@@ -110,11 +138,13 @@ struct Model {
   MathOps m;
   Reducer r;
 
-  void operator()(const double* x, double& logp, double* g) const {
+  // `fused`: the log-density sums accumulate with fma (the device's Cx::mad inside a transition kernel running with
+  // fused multiply-adds); gradients are element-wise and never fused
+  void operator()(const double* x, double& logp, double* g, bool fused = false) const {
     switch (kind) {
       case WNO_MODEL_STD_NORMAL: {
         // examples/walnutpie_api.cpp:37-41, tests/test_util.hpp:16-22
-        logp = -0.5 * r.sum(D, [&](size_t i) { return x[i] * x[i]; });
+        logp = -0.5 * r.sum_prod(D, [&](size_t i) { return x[i]; }, [&](size_t i) { return x[i]; }, fused);
         for (size_t i = 0; i < D; ++i) g[i] = -x[i];
         break;
       }
@@ -123,7 +153,7 @@ struct Model {
         const double* s2 = params.data();
         if (m.mode == WNO_MATH_PORTABLE) {
           // device arithmetic: the engine multiplies by 1/sigma_sq, rounded once (wn_engine_create)
-          logp = r.sum(D, [&](size_t i) { return -0.5 * x[i] * x[i] * (1.0 / s2[i]); });
+          logp = r.sum_prod(D, [&](size_t i) { return -0.5 * x[i] * x[i]; }, [&](size_t i) { return 1.0 / s2[i]; }, fused);
           for (size_t i = 0; i < D; ++i) g[i] = -x[i] * (1.0 / s2[i]);
         } else {
           logp = r.sum(D, [&](size_t i) { return -0.5 * x[i] * x[i] / s2[i]; });
@@ -135,7 +165,8 @@ struct Model {
         // Neal's funnel (not in the reference): v = x0 ~
         // N(0, 3^2), x_i | v ~ N(0, e^v), i >= 1.
         const double v = x[0];
-        const double S = r.sum(D, [&](size_t i) { return i == 0 ? 0.0 : x[i] * x[i]; });
+        auto x_or_0 = [&](size_t i) { return i == 0 ? 0.0 : x[i]; };
+        const double S = r.sum_prod(D, x_or_0, x_or_0, fused);
         const double ev = m.exp(-v);
         const double hd = 0.5 * static_cast<double>(D - 1);
         const double hev = 0.5 * ev;
@@ -151,11 +182,8 @@ struct Model {
         const double inv_sigma_sq = 1.0 / sigma_sq;
         if (m.mode == WNO_MATH_PORTABLE) {
           // device arithmetic: the log density is -0.5 * (sum of the per-coordinate terms, device summation order)
-          logp = -0.5 * r.sum(D, [&](size_t n) {
-            if (n == 0) return x[0] * x[0];
-            const double rr = x[n] - rho * x[n - 1];
-            return rr * (rr * inv_sigma_sq);
-          });
+          auto rr = [&](size_t n) { return n == 0 ? x[0] : x[n] - rho * x[n - 1]; };
+          logp = -0.5 * r.sum_prod(D, rr, [&](size_t n) { return n == 0 ? x[0] : rr(n) * inv_sigma_sq; }, fused);
         } else {
           logp = -0.5 * x[0] * x[0];
           for (size_t n = 1; n < D; ++n) {
@@ -180,8 +208,8 @@ struct Model {
 };
 
 // util.hpp:220-223
-double logp_momentum(const Reducer& r, size_t n, const double* rho, const double* im) {
-  return -0.5 * r.sum(n, [&](size_t i) { return im[i] * (rho[i] * rho[i]); });
+double logp_momentum(const Reducer& r, size_t n, const double* rho, const double* im, bool fused = false) {
+  return -0.5 * r.sum_prod(n, [&](size_t i) { return im[i]; }, [&](size_t i) { return rho[i] * rho[i]; }, fused);
 }
 
 // util.hpp:174-183
@@ -387,6 +415,7 @@ struct Ctx {
   double max_error;
   MathOps mo;
   Reducer red;
+  bool fma = false;  // the transition kernels' fused arithmetic (wno_config::fma)
   RandomSource* rng;
   Adam* adam;  // null: NoOpStepSizeAdapter (walnuts.hpp:572-587)
   int64_t grad_evals = 0;
@@ -408,6 +437,14 @@ struct Ctx {
 inline void leap(Ctx& c, double step, double half, double* th, double* rho, double* g, double& logp_pos) {
   // walnuts.hpp:228-231 / :329-332
   const size_t D = c.D;
+  if (c.fma) {  // the device's mad(): one rounding per multiply-add
+    for (size_t i = 0; i < D; ++i) rho[i] = std::fma(half, g[i], rho[i]);
+    for (size_t i = 0; i < D; ++i) th[i] = std::fma(step * c.im[i], rho[i], th[i]);
+    (*c.model)(th, logp_pos, g, true);
+    ++c.grad_evals;
+    for (size_t i = 0; i < D; ++i) rho[i] = std::fma(half, g[i], rho[i]);
+    return;
+  }
   for (size_t i = 0; i < D; ++i) rho[i] += half * g[i];
   for (size_t i = 0; i < D; ++i) th[i] += step * c.im[i] * rho[i];
   (*c.model)(th, logp_pos, g);
@@ -421,7 +458,7 @@ bool within_tolerance(Ctx& c, double step, size_t num_steps, double logp_next, d
   double half = 0.5 * step;
   double logp = logp_next;
   for (size_t n = 0; n < num_steps; ++n) leap(c, step, half, th, rho, g, logp_next);
-  logp_next += logp_momentum(c.red, c.D, rho, c.im);
+  logp_next += logp_momentum(c.red, c.D, rho, c.im, c.fma);
   c.audit(0, std::abs(logp_next - logp) - c.max_error, std::max(std::fabs(logp), std::fabs(logp_next)));
   return std::abs(logp_next - logp) <= c.max_error;
 }
@@ -453,7 +490,7 @@ bool macro_step(Ctx& c, bool forward, const Vec& th0, const Vec& rho0, const Vec
     g = g0;
     double half = 0.5 * step;
     for (size_t n = 0; n < num_steps; ++n) leap(c, step, half, th.data(), rho.data(), g.data(), logp_pos_next);
-    logp_next = logp_pos_next + logp_momentum(c.red, c.D, rho.data(), c.im);
+    logp_next = logp_pos_next + logp_momentum(c.red, c.D, rho.data(), c.im, c.fma);
     if (num_steps == c.min_micro) {
       double min_accept = c.mo.exp(-std::fabs(logp - logp_next));
       c.last_alpha = min_accept;
@@ -479,8 +516,8 @@ bool uturn(Ctx& c, bool forward, const Span& s1, const Span& s2) {
   const Span& fw = forward ? s2 : s1;
   const double* im = c.im;
   auto sd = [&](size_t i) { return im[i] * (fw.th_fw[i] - bk.th_bk[i]); };
-  double d_fw = c.red.sum(c.D, [&](size_t i) { return fw.rho_fw[i] * sd(i); });
-  double d_bk = c.red.sum(c.D, [&](size_t i) { return bk.rho_bk[i] * sd(i); });
+  double d_fw = c.red.sum_prod(c.D, [&](size_t i) { return fw.rho_fw[i]; }, sd, c.fma);
+  double d_bk = c.red.sum_prod(c.D, [&](size_t i) { return bk.rho_bk[i]; }, sd, c.fma);
   if (c.tie_tol > 0) {  // scale of each product: the sum of the magnitudes of its terms
     double a_fw = 0, a_bk = 0;
     for (size_t i = 0; i < c.D; ++i) {
@@ -562,9 +599,9 @@ void transition(Ctx& c, const double* chol, size_t max_depth, Vec& theta, size_t
   c.rng->normals(D, z.data());
   for (size_t i = 0; i < D; ++i) rho[i] = chol[i] * z[i];
   double lp_pos;
-  (*c.model)(theta.data(), lp_pos, g.data());
+  (*c.model)(theta.data(), lp_pos, g.data(), c.fma);
   ++c.grad_evals;
-  double lj = lp_pos + logp_momentum(c.red, D, rho.data(), c.im);
+  double lj = lp_pos + logp_momentum(c.red, D, rho.data(), c.im, c.fma);
   Span acc = single_state(theta, rho, g, lp_pos, lj);
   for (depth = 1; depth <= max_depth; ++depth) {
     bool forward = c.rng->bernoulli();
@@ -702,6 +739,7 @@ struct wno_engine {
     c.max_error = cfg.max_hamiltonian_error;
     c.mo = mo;
     c.red = red;
+    c.fma = cfg.fma != 0;
     c.rng = rng;
     c.adam = adam;
     c.trace = trace_on ? &ch.trace : nullptr;
@@ -865,7 +903,7 @@ void wno_default_config(wno_config* c) {
   c->math_mode = WNO_MATH_LIBM;
   c->reduce_lanes = 0;
   c->rng_mode = WNO_RNG_STD_MT64;
-  c->reserved = 0;
+  c->fma = 0;
 }
 
 wno_engine* wno_create(int model, int dim, const double* params, size_t num_chains, const wno_config* cfg) {

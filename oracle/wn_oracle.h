@@ -53,7 +53,9 @@ typedef struct wno_config {
   int32_t math_mode;    /* WNO_MATH_* */
   int32_t reduce_lanes; /* 0: left-to-right sums; L>0: the device order with L lanes */
   int32_t rng_mode;     /* WNO_RNG_* */
-  int32_t reserved;
+  int32_t fma;          /* 1: device arithmetic with fused multiply-adds (wn_config::fused_multiply_add): the
+                           transition's leapfrog updates, kinetic and U-turn sums and the models' log-density sums
+                           use std::fma exactly where the kernels do; 0: every product rounded */
 } wno_config;
 
 void wno_default_config(wno_config* cfg);

@@ -39,7 +39,7 @@ class Config(C.Structure):
         ("math_mode", C.c_int32),
         ("reduce_lanes", C.c_int32),
         ("rng_mode", C.c_int32),
-        ("reserved", C.c_int32),
+        ("fma", C.c_int32),
     ]
 
 

@@ -37,15 +37,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="std_normal"); ap.add_argument("--chains", type=int, default=65536)
 ap.add_argument("--dim", type=int, default=1024); ap.add_argument("--phase", default="sampling")
 known, _ = ap.parse_known_args("$ARGS".split())
-d = os.path.join("$ROOT", "walnuts_amd", "csrc")
-h = hashlib.sha256()
-for f in sorted(os.listdir(d)):
-    if f.endswith((".h", ".hip", ".inc")) or f == "Makefile":
-        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+import sys
+sys.path.insert(0, "$ROOT")
+import bench
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     json.dump({"model": known.model, "chains": known.chains, "dim": known.dim, "phase": known.phase,
-               "csrc_sha": h.hexdigest()[:16], "bytes_per_launch": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
-               "source": "profiles/r02/pmc_$TAG.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, last "
+               "csrc_sha": bench.csrc_sha(), "bytes_per_launch": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
+               "source": "profiles/${PROFILE_ROUND:-r03}/pmc_$TAG.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, last "
                          "(steady-state) dispatch, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 note in MI355X_MICROARCH.md"},
               open("$OUT/traffic.json", "w"))
 if "SQ_WAVE_CYCLES" in vals:

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.
 import parity
 lib = os.environ.get("WALNUTS_AMD_LIB")
 cases = [("std_normal", 1024, 64, (2, 8), {}), ("std_normal", 1000, 48, (2, 8), dict(lds_vectors=1)),
-         ("std_normal", 1024, 32, (2, 8), dict(lds_vectors=0, reg_vectors=0)),
+         ("std_normal", 1024, 32, (2, 8), dict(lds_vectors=0)),
          ("diag_normal", 1024, 48, (2, 8), {}), ("funnel", 900, 32, (2, 8), {}), ("std_normal", 100, 64, None, {}),
          ("funnel", 128, 64, None, {}), ("std_normal", 1024, 32, (4, 4), {}), ("std_normal", 1024, 32, (1, 16), {}),
          ("std_normal", 64, 9, None, dict(max_trajectory_doublings=10, step=0.01, max_hamiltonian_error=50.0)),

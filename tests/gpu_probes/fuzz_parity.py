@@ -52,6 +52,7 @@ def random_case(rng):
         kw.update(lds_vectors=int(rng.integers(0, 4)))
     if rng.uniform() < 0.2:
         kw.update(average_masses=True)
+    kw.update(fused_multiply_add=int(rng.integers(0, 2)))   # both arithmetic modes
     C = int(rng.choice([1, 2, 3, 7, 16, 33, 64]))
     return model, D, C, kw
 

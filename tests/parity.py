@@ -34,12 +34,12 @@ def make_pair(model: str, D: int, C: int, lib_path=None, geometry=None, **cfg_ov
     geo = {}
     if geometry is not None:
         geo = dict(waves_per_chain=geometry[0], elems_per_lane=geometry[1])
-    extra = {k: cfg_over.pop(k) for k in ("workgroups_per_cu", "lds_vectors", "reg_vectors") if k in cfg_over}
+    extra = {k: cfg_over.pop(k) for k in ("workgroups_per_cu", "lds_vectors", "fused_multiply_add") if k in cfg_over}
     dcfg = wa.default_config(lib_path, **cfg_over, **geo, **extra)
     params = model_params(model, D)
     dev = wa.DeviceEngine(dm, D, C, dcfg, params=params, lib_path=lib_path)
     ocfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_PORTABLE, reduce_lanes=dev.lanes,
-                              **cfg_over)
+                              fma=int(dcfg.fused_multiply_add), **cfg_over)
     orc = wno.Engine(om, D, C, ocfg, params=params)
     return dev, orc
 

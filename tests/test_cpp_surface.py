@@ -51,7 +51,9 @@ def run_and_compare(surface: str, lib_path: str, model: str, C: int, D: int, W: 
     from walnuts_amd import _ffi
     dm, _ = parity.MODELS[model]
     lanes = _ffi.load_library(lib_path).wn_lanes_for_model_dim(dm, D, 0, 0)   # reduction width of the default geometry
-    cfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_PORTABLE, reduce_lanes=lanes)
+    import walnuts_amd as wa
+    cfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_PORTABLE, reduce_lanes=lanes,
+                             fma=int(wa.default_config(lib_path).fused_multiply_add))   # the library's arithmetic mode
     o = wno.Engine(om, D, C, cfg, params=parity.model_params(model, D))
     o.init_positions(seed + 5, 0, 2.0)
     o.init_masses_from_grad(1e-5)

@@ -41,7 +41,10 @@ def _need_gpu(gpu):
     return gpu
 
 
-# ---- leapfrog + tree + adaptation, every launch geometry -----------------------------------------------
+# ---- leapfrog + tree + adaptation, every launch geometry, both arithmetic modes -------------------------
+# fma = 1: the integrator's multiply-adds fused (wn_config::fused_multiply_add, the default), the oracle replaying
+# std::fma at the same places; fma = 0: every product rounded (the reference's x86-64 element-wise bits)
+@pytest.mark.parametrize("fma", [1, 0])
 @pytest.mark.parametrize("model,D,C,geometry", [
     ("std_normal", 100, 64, None),          # BASELINE config #1 shape: (1,2)
     ("std_normal", 3, 16, None),            # odd tiny D, heavy padding
@@ -68,21 +71,20 @@ def _need_gpu(gpu):
     ("std_normal", 1000, 24, (2, -1)),      # streaming forced at a small dimension
     ("diag_normal", 5000, 12, (16, -1)),
 ])
-def test_engine_matches_oracle_bitwise(model, D, C, geometry):
-    parity.run_case(model, D, C, warmup=12, sampling=8, geometry=geometry, check_every=2)
+def test_engine_matches_oracle_bitwise(model, D, C, geometry, fma):
+    parity.run_case(model, D, C, warmup=12, sampling=8, geometry=geometry, check_every=2, fused_multiply_add=fma)
 
 
-@pytest.mark.parametrize("model,D,C,geometry,lds,reg", [
-    ("std_normal", 1024, 96, (2, 8), 2, -1),    # two LDS vectors, the rest overflows to the HBM arena
-    ("std_normal", 1024, 64, (2, 8), 0, 0),     # the whole span pool in the HBM arena
-    ("diag_normal", 1000, 64, (4, 4), 1, -1),
-    ("funnel", 300, 48, (2, 4), 0, -1),
-    ("std_normal", 100, 64, None, 3, -1),
+@pytest.mark.parametrize("model,D,C,geometry,lds", [
+    ("std_normal", 1024, 96, (2, 8), 2),    # two LDS vectors, the rest overflows to the HBM arena
+    ("std_normal", 1024, 64, (2, 8), 0),     # the whole span pool in the HBM arena
+    ("diag_normal", 1000, 64, (4, 4), 1),
+    ("funnel", 300, 48, (2, 4), 0),
+    ("std_normal", 100, 64, None, 3),
 ])
-def test_span_pool_tiers_match_oracle_bitwise(model, D, C, geometry, lds, reg):
-    """Where a span-pool vector lives (LDS, register bank, HBM arena) must not change a single bit."""
-    parity.run_case(model, D, C, warmup=10, sampling=6, geometry=geometry, lds_vectors=lds, reg_vectors=reg,
-                    check_every=2)
+def test_span_pool_tiers_match_oracle_bitwise(model, D, C, geometry, lds):
+    """Where a span-pool vector lives (LDS, HBM arena) must not change a single bit."""
+    parity.run_case(model, D, C, warmup=10, sampling=6, geometry=geometry, lds_vectors=lds, check_every=2)
 
 
 @pytest.mark.parametrize("kw", [

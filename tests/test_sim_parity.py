@@ -20,24 +20,35 @@ def sim():
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("fma", [1, 0])   # fused multiply-adds (the default) / every product rounded
 @pytest.mark.parametrize("model,D,geometry", [
     ("std_normal", 10, None),          # (1,2): D < one pair per lane, heavy padding
     ("diag_normal", 130, (1, 4)),      # (1,4): four elements per lane
     ("funnel", 9, (2, 2)),             # two wavefronts: cross-wave reductions, broadcasts, barriers
     ("diag_normal", 300, (1, -1)),     # streaming backend (vectors in HBM scratch), 3 tiles per lane
+    ("rw1", 70, (1, 2)),               # neighbour-coupled gradient through the public model interface
 ])
-def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry):
-    parity.run_case(model, D, 2, warmup=4, sampling=3, lib_path=sim, geometry=geometry, step=None)
+def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry, fma):
+    parity.run_case(model, D, 2, warmup=4, sampling=3, lib_path=sim, geometry=geometry, step=None,
+                    fused_multiply_add=fma)
+
+
+@pytest.mark.timeout(600)
+def test_emulated_engine_inline_momentum_generator(sim, oracle, monkeypatch):
+    # WALNUTS_AMD_PREGEN=0: the momentum's normals generated inside the transition kernel (the default is the
+    # generator kernel one transition ahead, wn_pregen.h) -- the same bits either way
+    monkeypatch.setenv("WALNUTS_AMD_PREGEN", "0")
+    parity.run_case("std_normal", 10, 2, warmup=3, sampling=3, lib_path=sim)
+    parity.run_case("diag_normal", 130, 2, warmup=2, sampling=2, lib_path=sim, geometry=(1, 4))
 
 
 @pytest.mark.timeout(600)
 def test_emulated_engine_lds_pool_and_arena_paths(sim, oracle):
-    # same chains with the span pool in LDS, split over LDS / registers / HBM arena, in registers + arena only, in
-    # the arena only: identical results
+    # same chains with the span pool in LDS, split over LDS / HBM arena, in the arena only: identical results
     outs = []
-    for lds, reg in ((-1, -1), (2, 3), (0, 4), (0, 0)):
+    for lds in (-1, 2, 0):
         dev, orc = parity.run_case("std_normal", 12, 2, warmup=2, sampling=2, lib_path=sim, lds_vectors=lds,
-                                   reg_vectors=reg, max_trajectory_doublings=4)
+                                   max_trajectory_doublings=4)
         outs.append(dev.positions())
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
 

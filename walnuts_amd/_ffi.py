@@ -38,7 +38,7 @@ class Config(C.Structure):
         ("workgroups_per_cu", C.c_int32),
         ("lds_vectors", C.c_int32),
         ("reserved_cus", C.c_int32),
-        ("reg_vectors", C.c_int32),
+        ("fused_multiply_add", C.c_int32),
     ]
 
 

@@ -34,14 +34,15 @@ struct Rw1Model {
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       const int n = cx.index(j);
-      double term, gj;
+      double ta, tb, gj;                            // the log-density term is ta * tb
       if (n == 0) {
-        term = y[j] * y[j];                         // logp = -0.5 * y[0] * y[0]; grad[0] -= y[0]
+        ta = tb = y[j];                             // logp = -0.5 * y[0] * y[0]; grad[0] -= y[0]
         gj = -y[j];
       } else {
         const double r = y[j] - rho * prev[j];      // examples.cpp:43-46
         const double w = r * inv_sigma_sq;
-        term = r * w;
+        ta = r;
+        tb = w;
         gj = -w;
       }
       if (n + 1 < cx.dim()) {                       // grad[n] += rho * w[n + 1] (examples.cpp:47)
@@ -50,7 +51,7 @@ struct Rw1Model {
       }
       const bool in = cx.valid(j);
       g[j] = in ? gj : 0.0;
-      acc += in ? term : 0.0;
+      acc = Cx::mad(in ? ta : 0.0, in ? tb : 0.0, acc);  // (fused when the engine runs with fused multiply-adds)
     }
   }
   __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return -0.5 * sum; }

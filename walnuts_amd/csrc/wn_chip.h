@@ -13,11 +13,11 @@
 //    everywhere; the one single-leaf extension of a transition (the first doubling) copies once.
 //  * Level-0 merges never touch memory: both leaves of the pair are in registers when the odd leaf is done, and the
 //    two U-turn products (walnuts.hpp:192-201) ride in the SAME reduction as the leaf's two energies (sum4).
-//  * Three-tier span pool behind the wave-uniform buffer indices: LDS vectors, then RP vectors kept in VGPR banks
-//    (indexed with s_set_gpr_idx; built and measured, but any bank makes the allocator spill at these sizes, so
-//    chip_bank_a/b() return 0: DESIGN.md section 5), then -- only when a deep tree needs more than the chip holds
-//    -- the HBM arena.  With 4 chains per CU at D = 1024 that is 4 vectors in LDS (+ the span's other end in
-//    registers) against a worst case of 12 live pool vectors at the default five doublings.
+//  * Two-tier span pool behind the wave-uniform buffer indices: LDS vectors, then -- only when a deep tree needs
+//    more than the chip holds -- the HBM arena.  With 4 chains per CU at D = 1024 that is 4 vectors in LDS (+ the
+//    span's other end in registers) against a worst case of 12 live pool vectors at the default five doublings.
+//    (A third tier, pool vectors in VGPR banks indexed with s_set_gpr_idx, was built and measured in round 2: any
+//    bank made the allocator spill at these sizes.  Removed; the measurements are in DESIGN.md section 5.)
 //  * The "other" end of the accumulated span is one (theta, rho[, grad]) triple that is swapped with the moving
 //    end when the walk turns around; nothing is written while the walk keeps its direction.  For models whose
 //    gradient is recomputed it is parked in accumulator registers (AGPRs), which vector arithmetic cannot read and
@@ -32,26 +32,14 @@
 
 namespace wn {
 
-// N doubles per lane addressed by a wave-uniform index: one column of a register bank.  The index reaches the
-// hardware as VGPR-relative addressing (s_set_gpr_idx_on + v_mov), so a pool vector moves in and out of the bank
-// with two VALU moves per element and no code per slot.
-template <int N>
-struct RegColumn {
-  typedef double type WN_VEC_OF(N);
-};
-template <>
-struct RegColumn<0> {
-  typedef double type WN_VEC_OF(2);  // placeholder, never touched
-};
-
-// RA + RB = pool vectors kept in registers, as two banks whose sizes are vector widths (2, 4, 8, 16) or 0
 // WARM: the kernel of the adaptive warmup transitions (Adam, mass estimator) or of the frozen sampler's -- two
 // instantiations, because the sampler's, freed of the adaptation code, needs fewer registers (measured: +3 % on the
 // one-wavefront headline kernel, +8 % on the two-wavefront one)
-template <class Model, int NW, int EPL, int RA, int RB, bool WARM = false>
-struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
-  using Base = TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW>;
-  static constexpr int RP = RA + RB;
+// FMA: the multiply-adds of the integrator are fused (one rounding), as an FMA-target build of the reference fuses
+// them; false: every product is rounded before it is added, the bits of the reference's x86-64 -O3 builds
+template <class Model, int NW, int EPL, bool WARM = false, bool FMA = false>
+struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
+  using Base = TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW>;
   using typename Base::Meta;
   using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::wave;
   using Base::chain; using Base::aux; using Base::n_grad; using Base::n_draw; using Base::draw_base; using Base::err;
@@ -60,7 +48,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   static constexpr int L = Base::L;
   static constexpr int NP = EPL / 2;
   static constexpr int kDp = L * EPL;  // padded dimension: a compile-time constant of the geometry
-  static constexpr int kRegPool = RP;
   static constexpr bool kNoGrad = Model::kCheapGrad;  // the gradient is recomputed from theta at each use
   static constexpr bool kHasStartState = true;
   static constexpr bool kZeroCopy = false;
@@ -73,27 +60,24 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   // has registers of its own instead of two pool buffers -- accumulator registers, parked there explicitly
   // (ParkedDouble, wn_gfx950.h): the top-level U-turn test fetches it, turning around exchanges it with the moving
   // end, and the pool's LDS vectors all serve the span stack.
-#if defined(WN_NO_OTHER_REGS)
-  static constexpr bool kOtherRegs = false;
-#else
   static constexpr bool kOtherRegs = kNoGrad;
-#endif
   static constexpr int kOther = -4;           // "this vector is the other end's theta" (kOtherRegs)
   ParkedDouble oth[EPL], orh[EPL];
-  typename RegColumn<RA>::type bank_a[EPL];   // register tier of the span pool: element j of slot k is bank_a[j][k]
-  typename RegColumn<RB>::type bank_b[EPL];
-  int n_lds, n_reg;                           // pool buffers [0, n_lds) live in LDS, [n_lds, n_lds + n_reg) in the banks
+  int n_lds;                                  // pool buffers [0, n_lds) live in LDS, the rest in the HBM arena
 
   __device__ __forceinline__ TrajChip(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
                                       WN_LDS double* bc, double* ar)
       : Base(p, pool, m, r, bc, ar) {
     n_lds = p.pool_lds;
-    n_reg = p.pool_reg < RP ? p.pool_reg : RP;
-    const int on = n_lds + n_reg;
-    onchip_mask = on >= 64 ? ~0ull : ((1ull << on) - 1ull);
+    onchip_mask = n_lds >= 64 ? ~0ull : ((1ull << n_lds) - 1ull);
   }
 
   __device__ __forceinline__ static constexpr bool is_warmup() { return WARM; }
+  // a * b + c, fused or not (what Model::eval sees as cx.mad)
+  __device__ __forceinline__ static double mad(double a, double b, double c) {
+    if constexpr (FMA) return __builtin_fma(a, b, c);
+    return a * b + c;
+  }
 
   // ---- model context (what Model::eval sees) ------------------------------------------------------
   __device__ __forceinline__ int index(int j) const { return ((j >> 1) * L + tid) * 2 + (j & 1); }
@@ -212,47 +196,14 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       lds_load(lds_pool + b * kDp, v);
       return;
     }
-    const int k = b - n_lds;
-    if (RP > 0 && k < n_reg) {
-      if (RB == 0 || k < RA) {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) v[j] = bank_a[j][k];
-      } else {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) v[j] = bank_b[j][k - RA];
-      }
-      return;
-    }
-    vload(arena + static_cast<long long>(k - n_reg) * kDp, v);
+    vload(arena + static_cast<long long>(b - n_lds) * kDp, v);
   }
   __device__ __forceinline__ void pool_store(int b, const double (&v)[EPL]) {
     if (b < n_lds) {
       lds_store(lds_pool + b * kDp, v);
       return;
     }
-    const int k = b - n_lds;
-    if (RP > 0 && k < n_reg) {
-      if (RB == 0 || k < RA) {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) bank_a[j][k] = v[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) bank_b[j][k - RA] = v[j];
-      }
-      return;
-    }
-    vstore(arena + static_cast<long long>(k - n_reg) * kDp, v);
-  }
-
-  // No pool buffer is live across transitions.  The register allocator cannot see that (the banks are read through
-  // run-time indices), so they are redefined here and their registers are free while the chain is loaded and its
-  // momentum drawn.
-  __device__ __forceinline__ void kill_register_pool() {
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      if (RA > 0) bank_a[j] = typename RegColumn<RA>::type{};
-      if (RB > 0) bank_b[j] = typename RegColumn<RB>::type{};
-    }
+    vstore(arena + static_cast<long long>(b - n_lds) * kDp, v);
   }
 
   // ---- Hamiltonian pieces -------------------------------------------------------------------------
@@ -268,7 +219,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   __device__ __forceinline__ double kinetic_partial() const {
     double ke = 0.0;
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) ke += im[j] * (rh[S][j] * rh[S][j]);
+    for (int j = 0; j < EPL; ++j) ke = mad(im[j], rh[S][j] * rh[S][j], ke);
     return ke;
   }
   // one leapfrog micro step (walnuts.hpp:329-332) reading set A and writing set B (A == B: in place);
@@ -276,12 +227,12 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   template <int A, int B>
   __device__ __forceinline__ double micro_step(double h, double half) {
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) rh[B][j] = rh[A][j] + half * G<A>(j);
+    for (int j = 0; j < EPL; ++j) rh[B][j] = mad(half, G<A>(j), rh[A][j]);
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) th[B][j] = th[A][j] + h * im[j] * rh[B][j];
+    for (int j = 0; j < EPL; ++j) th[B][j] = mad(h * im[j], rh[B][j], th[A][j]);
     const double part = model_eval<B>();
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) rh[B][j] += half * G<B>(j);
+    for (int j = 0; j < EPL; ++j) rh[B][j] = mad(half, G<B>(j), rh[B][j]);
     return part;
   }
   // n micro steps in place on set S (walnuts.hpp:328-333)
@@ -358,8 +309,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     for (int j = 0; j < EPL; ++j) {
       const double diff = wnd::as_f64(wnd::as_u64(th[H][j] - a[j]) ^ flip);
       const double sd = im[j] * diff;
-      p_hot += rh[H][j] * sd;
-      p_far += b[j] * sd;
+      p_hot = mad(rh[H][j], sd, p_hot);
+      p_far = mad(b[j], sd, p_far);
     }
   }
   // CH consecutive slots (a whole number of pairs) of a pool vector, starting at slot j0
@@ -376,18 +327,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
       }
       return;
     }
-    const int kk = b - n_lds;
-    if (RP > 0 && kk < n_reg) {
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-#pragma unroll
-        for (int jj = 0; jj < EPL; ++jj) {
-          if (jj == j0 + j) v[j] = (RB == 0 || kk < RA) ? bank_a[jj][kk] : bank_b[jj][kk - RA];
-        }
-      }
-      return;
-    }
-    const double* base = arena + static_cast<long long>(kk - n_reg) * kDp;
+    const double* base = arena + static_cast<long long>(b - n_lds) * kDp;
     const char* lb = lane_base(base);
 #pragma unroll
     for (int k = 0; k < CH / 2; ++k) {
@@ -414,8 +354,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
           const int jj = h * CH + j;
           const double diff = wnd::as_f64(wnd::as_u64(th[0][jj] - a[j]) ^ flip);
           const double sd = im[jj] * diff;
-          p_hot += rh[0][jj] * sd;
-          p_far += b[j] * sd;
+          p_hot = mad(rh[0][jj], sd, p_hot);
+          p_far = mad(b[j], sd, p_far);
         }
       }
     } else {
@@ -504,7 +444,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
     }
     WN_MARK(kPhEvaluated);
     this->prefetch_next_chain();
-    kill_register_pool();
     // The accumulated span (walnuts.hpp:34-131) is: the moving end (set 0), the other end parked in the pool,
     // the selected position and three scalars.  Both ends are the initial point to begin with.
     int o_th = -1, o_rh = -1, o_g = -1;
@@ -757,8 +696,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
 #endif
     }
     WN_MARK(kPhLoadsIssued);
-    const bool fed = Q.rng_mode == kRngBuffer;
-    if (fed) {
+    const int rng_mode = Q.rng_mode;
+    const bool fed = rng_mode == kRngBuffer;  // host-fed rows are zero-padded already
+    if (rng_mode != kRngPhilox) {
       vload_stream(Q.z_buf + row, rh[0]);
     } else {
       const uint64_t seed = Q.seed;
@@ -857,10 +797,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, RA, RB, WARM>, Model, NW> {
   }
 };
 
-// Geometry table of the on-chip kernels: waves per SIMD the register budget is cut for, and how many pool vectors
-// live in registers (two banks, each a vector width).  One vector costs 2*EPL VGPRs per lane; the moving end's two
-// sets, the inverse mass and the two operands of a pool-side U-turn test come first, the register pool takes what
-// the budget leaves.
+// Geometry table of the on-chip kernels: waves per SIMD the register budget is cut for.  One vector costs 2*EPL VGPRs
+// per lane; the moving end's two sets, the inverse mass and the two operands of a pool-side U-turn test must fit.
 template <class Model, int EPL>
 constexpr int chip_waves_per_simd() {
 #if defined(WN_WPE8)
@@ -870,30 +808,10 @@ constexpr int chip_waves_per_simd() {
   if (!Model::kCheapGrad) return EPL >= 8 ? 1 : EPL == 4 ? 2 : 3;
   return EPL >= 16 ? 1 : EPL == 8 ? 2 : EPL == 4 ? 3 : 4;
 }
-template <class Model, int EPL>
-constexpr int chip_bank_a() {
-#if defined(WN_RA8)
-  if (EPL == 8) return WN_RA8;
-#endif
-  if (EPL >= 16) return 0;   // 512 registers, 32 per vector
-  if (EPL == 8) return 0;    // 256 registers, 16 per vector: measured, any bank makes the allocator spill
-  return 0;
-}
-template <class Model, int EPL>
-constexpr int chip_bank_b() {
-#if defined(WN_RB8)
-  if (EPL == 8) return WN_RB8;
-#endif
-  return 0;
-}
-template <class Model, int EPL>
-constexpr int chip_reg_pool() {
-  return chip_bank_a<Model, EPL>() + chip_bank_b<Model, EPL>();
-}
 
-template <class Model, int NW, int EPL, bool WARM>
+template <class Model, int NW, int EPL, bool WARM, bool FMA>
 __global__ __launch_bounds__(64 * NW, (chip_waves_per_simd<Model, EPL>())) void transition_kernel_chip(const Params P) {
-  persistent_loop<TrajChip<Model, NW, EPL, chip_bank_a<Model, EPL>(), chip_bank_b<Model, EPL>(), WARM>, NW>(P);
+  persistent_loop<TrajChip<Model, NW, EPL, WARM, FMA>, NW>(P);
 }
 
 }  // namespace wn

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -18,6 +19,7 @@
 #include "wn_init.h"
 #include "wn_launch.h"
 #include "wn_traj.h"
+#include "wn_pregen.h"
 
 #include "wn_host.h"
 
@@ -43,7 +45,7 @@ struct wn_engine {
   int device = 0;
   int num_cus = 256;
   int grid = 0;
-  int pool_lds = 0, pool_reg = 0, pool_total = 0;
+  int pool_lds = 0, pool_total = 0;
   int64_t arena_stride = 0;  // doubles per persistent workgroup: HBM part of the span pool (+ streaming scratch)
   size_t smem = 0;
   hipStream_t stream = nullptr;
@@ -67,6 +69,20 @@ struct wn_engine {
   int u_stride = 0;
   std::unique_ptr<ReferenceStreams> ref_streams;
 
+  // The momentum's normals one transition ahead (wn_pregen.h): two [C][Dp] planes, a second stream, and per plane the
+  // key the normals in it were generated for.  `gen_done[b]` orders the transition kernel after the generator that
+  // filled plane b, `read_done[b]` orders the next generator after the transition kernel that read it.
+  struct Pregen {
+    bool enabled = false;
+    DevBuf<double> z[2];
+    hipStream_t stream = nullptr;
+    hipEvent_t gen_done[2] = {nullptr, nullptr}, read_done[2] = {nullptr, nullptr};
+    bool gen_recorded[2] = {false, false}, read_recorded[2] = {false, false};
+    bool valid[2] = {false, false};
+    uint64_t seed[2] = {0, 0};
+    uint32_t chain_offset[2] = {0, 0}, transition[2] = {0, 0};
+  } pregen;
+
   // HIP event pairs around the transition launches: a fixed ring (the last kEventRing launches since the last
   // timing reset can be read back), created once
   static constexpr size_t kEventRing = 1024;
@@ -79,7 +95,51 @@ struct wn_engine {
       (void)hipEventDestroy(ev.first);
       (void)hipEventDestroy(ev.second);
     }
+    if (pregen.stream) {
+      (void)hipStreamSynchronize(pregen.stream);
+      (void)hipStreamDestroy(pregen.stream);
+    }
+    for (int b = 0; b < 2; ++b) {
+      if (pregen.gen_done[b]) (void)hipEventDestroy(pregen.gen_done[b]);
+      if (pregen.read_done[b]) (void)hipEventDestroy(pregen.read_done[b]);
+    }
     if (stream && own_stream) (void)hipStreamDestroy(stream);
+  }
+
+  void launch_pregen(int b, uint32_t tr, hipStream_t on) {
+#if defined(WN_PROBE_STALE_PREGEN)  // tests/gpu_probes only: what the transition kernel costs with no generator beside it
+    if (pregen.valid[b]) { pregen.seed[b] = seed; pregen.chain_offset[b] = chain_offset; pregen.transition[b] = tr; return; }
+#endif
+    const long long n = static_cast<long long>(C) * (Dp / 2);
+    const int blocks = static_cast<int>(std::min<long long>((n + wn::kPregenBlock - 1) / wn::kPregenBlock, 1 << 16));
+    hipLaunchKernelGGL(wn::momentum_pregen_kernel, dim3(blocks), dim3(wn::kPregenBlock), 0, on, static_cast<int>(C), Dp,
+                       seed, chain_offset, tr, pregen.z[b].p);
+    HIP_OK(hipGetLastError());
+    pregen.valid[b] = true;
+    pregen.seed[b] = seed;
+    pregen.chain_offset[b] = chain_offset;
+    pregen.transition[b] = tr;
+  }
+  // plane holding this transition's normals, generated now (in order, on the main stream) unless the generator that
+  // ran beside the previous transition already made them
+  const double* pregen_acquire() {
+    const int b = static_cast<int>(transition & 1u);
+    if (pregen.gen_recorded[b]) HIP_OK(hipStreamWaitEvent(stream, pregen.gen_done[b], 0));
+    if (!(pregen.valid[b] && pregen.seed[b] == seed && pregen.chain_offset[b] == chain_offset &&
+          pregen.transition[b] == transition))
+      launch_pregen(b, transition, stream);
+    return pregen.z[b].p;
+  }
+  // after the transition kernel of `transition` has been enqueued: its plane may be rewritten once it is done, and the
+  // other plane -- last read by the previous transition -- gets the NEXT transition's normals on the second stream
+  void pregen_ahead() {
+    const int b = static_cast<int>(transition & 1u), nb = b ^ 1;
+    HIP_OK(hipEventRecord(pregen.read_done[b], stream));
+    pregen.read_recorded[b] = true;
+    if (pregen.read_recorded[nb]) HIP_OK(hipStreamWaitEvent(pregen.stream, pregen.read_done[nb], 0));
+    launch_pregen(nb, transition + 1u, pregen.stream);
+    HIP_OK(hipEventRecord(pregen.gen_done[nb], pregen.stream));
+    pregen.gen_recorded[nb] = true;
   }
 
   std::pair<hipEvent_t, hipEvent_t>& next_events() {
@@ -179,6 +239,7 @@ struct wn_engine {
     P.max_depth = cfg.max_trajectory_doublings;
     P.max_halvings = cfg.max_step_halvings;
     P.cfg_min_micro = cfg.min_micro_steps;
+    P.fma = cfg.fused_multiply_add ? 1 : 0;
     P.max_error = cfg.max_hamiltonian_error;
     P.mass_init_count = cfg.mass_init_count;
     P.macro_target = cfg.max_macro_steps_target;
@@ -191,14 +252,13 @@ struct wn_engine {
     P.seed = seed;
     P.chain_offset = chain_offset;
     P.transition = transition;
-    P.rng_mode = variates_pending ? wn::kRngBuffer : wn::kRngPhilox;
+    P.rng_mode = variates_pending ? wn::kRngBuffer : wn::kRngPhilox;  // (step() switches to kRngPregen)
     P.u_stride = u_stride;
     P.z_buf = z_buf.p;
     P.u_buf = u_buf.p;
     P.warmup_iter = warmup_iter;
     P.arena = arena.p;
     P.arena_stride = arena_stride;
-    P.pool_reg = pool_reg;
     P.pool_lds = pool_lds;
     P.pool_total = pool_total;
     P.work_counter = counter.p;
@@ -213,12 +273,18 @@ struct wn_engine {
     use_device();
     if (ref_streams) feed_reference_streams();
     wn::Params P = make_params(warm, draws_dev, draws_stride);
+    const bool ahead = pregen.enabled && !variates_pending;
+    if (ahead) {
+      P.rng_mode = wn::kRngPregen;
+      P.z_buf = pregen_acquire();
+    }
     HIP_OK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), stream));
     auto& ev = next_events();
     HIP_OK(hipEventRecord(ev.first, stream));
     wn::launch_transition(model, geo, grid, smem, stream, P);
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(ev.second, stream));
+    if (ahead) pregen_ahead();
     variates_pending = false;
     ++transition;
     ++iteration;
@@ -301,8 +367,6 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.pool_total = required_pool(cfg) + (e.geo.mem ? wn::kMemRoleVectors : 0);
   if (e.pool_total > wn::kMaxPool)
     throw std::invalid_argument("max_trajectory_doublings needs more span-pool vectors than the device free mask holds");
-  e.pool_reg = wn::register_pool(model, e.geo);
-  if (cfg.reg_vectors >= 0) e.pool_reg = std::min(e.pool_reg, cfg.reg_vectors);
   const int wps = wn::waves_per_simd(model, e.geo);
   int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo, wps);
   wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
@@ -342,8 +406,8 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.mon_rel_mass.alloc(num_chains);
   e.mon_rel_step.alloc(num_chains);
   e.scratch64.alloc(1);
-  // what neither LDS nor the kernels' register pool holds (deep trees only) overflows to a per-workgroup HBM arena
-  const size_t arena_vecs = static_cast<size_t>(std::max(0, e.pool_total - e.pool_lds - e.pool_reg)) +
+  // what LDS does not hold (deep trees only) overflows to a per-workgroup HBM arena
+  const size_t arena_vecs = static_cast<size_t>(std::max(0, e.pool_total - e.pool_lds)) +
                             (e.geo.mem ? wn::kMemScratchVectors : 0);
   e.arena_stride = static_cast<int64_t>(arena_vecs) * e.Dp;
   e.arena.alloc(std::max<size_t>(1, static_cast<size_t>(e.grid) * arena_vecs * e.Dp));
@@ -367,6 +431,19 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
     HIP_OK(hipStreamSynchronize(e.stream));
   }
   wn::prepare_kernels(model, e.geo, e.smem);
+
+  // momentum normals one transition ahead: the register kernels only (the streaming kernels are HBM-bound: the
+  // generator's arithmetic is free there and a plane of normals is not); WALNUTS_AMD_PREGEN=0 switches it off
+  const char* pg = std::getenv("WALNUTS_AMD_PREGEN");
+  e.pregen.enabled = !e.geo.mem && !(pg != nullptr && pg[0] == '0');
+  if (e.pregen.enabled) {
+    HIP_OK(hipStreamCreateWithFlags(&e.pregen.stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      e.pregen.z[b].alloc(plane);
+      HIP_OK(hipEventCreateWithFlags(&e.pregen.gen_done[b], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&e.pregen.read_done[b], hipEventDisableTiming));
+    }
+  }
 }
 
 void run_init(wn_engine& e, bool pos, bool masses, bool step, double scale, double smoothing, uint64_t pos_seed,
@@ -419,6 +496,13 @@ int wn_model_id(const char* name) {
   return -1;
 }
 
+// WALNUTS_AMD_FMA=0/1 overrides the library default (fused) for callers that do not build a wn_config themselves
+// (walnutpie_sample_device keeps the reference's argument list)
+static int default_fma() {
+  const char* v = std::getenv("WALNUTS_AMD_FMA");
+  return (v != nullptr && v[0] == '0') ? 0 : 1;
+}
+
 void wn_default_config(wn_config* c) {
   c->max_trajectory_doublings = 5;
   c->max_step_halvings = 5;
@@ -437,7 +521,7 @@ void wn_default_config(wn_config* c) {
   c->elems_per_lane = 0;
   c->workgroups_per_cu = 0;
   c->lds_vectors = -1;
-  c->reg_vectors = -1;
+  c->fused_multiply_add = default_fma();
   c->reserved_cus = 0;
 }
 
@@ -602,6 +686,7 @@ int wn_engine_synchronize(wn_engine* e, WalnutpyError** err) {
   return guarded(err, [&] {
     e->use_device();
     HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->pregen.stream) HIP_OK(hipStreamSynchronize(e->pregen.stream));
   });
 }
 int wn_engine_check(wn_engine* e, WalnutpyError** err) {

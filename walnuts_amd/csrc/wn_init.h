@@ -29,7 +29,7 @@ struct InitParams {
 template <class Model, int NW, int EPL>
 __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
   WN_DYN_SMEM(smem);
-  using T = TrajChip<Model, NW, EPL, 0, 0>;  // the register kernels' vector helpers; set 0 is the working state
+  using T = TrajChip<Model, NW, EPL>;  // the register kernels' vector helpers (unfused arithmetic); set 0 is the working state
   Params P{};  // only the fields the model context and reductions read
   P.num_chains = Q.num_chains;
   P.dim = Q.dim;

@@ -142,7 +142,6 @@ struct ModelOps {
   void (*launch_transition)(const Geometry&, int grid, size_t smem, hipStream_t, const Params&);
   void (*launch_init)(const Geometry&, int grid, size_t smem, hipStream_t, const InitParams&);
   void (*prepare)(const Geometry&, size_t smem);
-  int (*register_pool)(const Geometry&);
   int (*waves_per_simd)(const Geometry&);
   void (*host_params)(double* params, int num_params);  // validate / transform the parameter vector before upload
   void (*validate)(int num_params);
@@ -169,8 +168,6 @@ inline void launch_transition(int model, const Geometry& g, int grid, size_t sme
 inline void launch_init(int model, const Geometry& g, int grid, size_t smem, hipStream_t s, const InitParams& q) {
   model_ops(model).launch_init(g, grid, smem, s, q);
 }
-// pool vectors the register kernel of this model / geometry keeps in VGPRs (0 for the streaming kernels)
-inline int register_pool(int model, const Geometry& g) { return model_ops(model).register_pool(g); }
 // wavefronts per SIMD the register kernel of this model / geometry is compiled for (its VGPR budget)
 inline int waves_per_simd(int model, const Geometry& g) { return model_ops(model).waves_per_simd(g); }
 inline void prepare_kernels(int model, const Geometry& g, size_t smem) { model_ops(model).prepare(g, smem); }

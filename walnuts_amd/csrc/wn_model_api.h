@@ -44,8 +44,11 @@
 //   cx.shift(v, prev, next)                   prev[j] = v at coordinate index(j) - 1, next[j] = v at index(j) + 1
 //                                             (0.0 beyond either end of the padded vector)
 //   cx.uniform_tab()                          tables for wnd::dexp / wnd::dlog of a wave-uniform argument
-// Arithmetic: the library is compiled with -ffp-contract=off; what you write is what is evaluated, so a CPU
-// restatement of the same expressions reproduces the device bit for bit (that is how the parity tests work).
+//   Cx::mad(a, b, c)                          a * b + c: one fused multiply-add when the engine was created with
+//                                             wn_config::fused_multiply_add, a rounded product plus an add otherwise
+// Arithmetic: the library is compiled with -ffp-contract=off; what you write is what is evaluated (Cx::mad is the one
+// place where the engine's arithmetic mode shows), so a CPU restatement of the same expressions reproduces the device
+// bit for bit (that is how the parity tests work).
 //
 // Registration is a five-line translation unit, wn_kernels_<name>.hip, that the Makefile picks up by its name:
 //   #include "models/my_model.h"

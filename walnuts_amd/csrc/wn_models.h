@@ -35,7 +35,7 @@ struct StdNormalModel {  // examples/walnutpie_api.cpp:37-41
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       g[j] = -th[j];
-      acc += th[j] * th[j];
+      acc = Cx::mad(th[j], th[j], acc);
     }
   }
   // element-wise models: the gradient alone, the same expression eval() uses (so the same bits)
@@ -65,7 +65,7 @@ struct DiagNormalModel {  // examples/examples.cpp:20-31, params = 1 / sigma_sq
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       g[j] = -th[j] * rs2[j];
-      acc += -0.5 * th[j] * th[j] * rs2[j];
+      acc = Cx::mad(-0.5 * th[j] * th[j], rs2[j], acc);
     }
   }
   template <int EPL, class Cx>
@@ -101,7 +101,10 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
     const double v = cx.element0(th[0]);
     double sp = 0.0;
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) sp += (cx.index(j) == 0) ? 0.0 : th[j] * th[j];
+    for (int j = 0; j < EPL; ++j) {
+      const double x = (cx.index(j) == 0) ? 0.0 : th[j];
+      sp = Cx::mad(x, x, sp);
+    }
     const double S = cx.sum1(sp);
     const double ev = wnd::dexp(-v, cx.uniform_tab());
     const double hd = 0.5 * static_cast<double>(cx.dim() - 1);

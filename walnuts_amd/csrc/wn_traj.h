@@ -107,6 +107,9 @@ __device__ unsigned long long wn_timeline[kTimelineMarks];
 #define WN_MARK(k) ((void)0)  // marks only the timeline probe records
 #endif
 
+#if !defined(WN_MAIN_PRIO)
+#define WN_MAIN_PRIO 3
+#endif
 constexpr int kHot = -1;    // "this vector is the moving trajectory end"
 constexpr int kStart = -2;  // "this vector is the macro step's restart state (= the previous leaf)"
 
@@ -830,9 +833,9 @@ struct TrajBase {
 // one fused pass reading theta, rho, grad, inv_mass and writing theta, rho, grad -- exactly the
 // algorithmic 56*D bytes.  Only models whose gradient is element-wise are supported here.
 // ---------------------------------------------------------------------------------------------------
-template <class Model, int NW>
-struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
-  using Base = TrajBase<TrajMem<Model, NW>, Model, NW>;
+template <class Model, int NW, bool FMA = false>
+struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
+  using Base = TrajBase<TrajMem<Model, NW, FMA>, Model, NW>;
   using typename Base::Meta;
   using Base::P; using Base::arena; using Base::tid; using Base::chain; using Base::Dp; using Base::aux;
   using Base::n_grad; using Base::max_error; using Base::min_micro; using Base::w_draw0; using Base::w_score0;
@@ -872,8 +875,13 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
     tiles = p.dim_padded / (2 * L);
   }
 
+  __device__ __forceinline__ static double mad(double a, double b, double c) {  // a * b + c, fused or not
+    if constexpr (FMA) return __builtin_fma(a, b, c);
+    return a * b + c;
+  }
   struct TileCx {  // model context of one 2-element tile
     int base, D;
+    __device__ __forceinline__ static double mad(double a, double b, double c) { return TrajMem::mad(a, b, c); }
     __device__ __forceinline__ int index(int j) const { return base + j; }
     __device__ __forceinline__ bool valid(int j) const { return base + j < D; }
     __device__ __forceinline__ int dim() const { return D; }
@@ -961,21 +969,21 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
         // third vector in HBM -- 16 bytes per element and pass less than the 56 the definition charges
         Model::grad(cx, th2, g2, mp2, aux);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) rh2[j] += half * g2[j];
+        for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) th2[j] += h * m0[j] * rh2[j];
+        for (int j = 0; j < 2; ++j) th2[j] = mad(h * m0[j], rh2[j], th2[j]);
         Model::eval(cx, th2, g2, mp2, aux, part);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) rh2[j] += half * g2[j];
+        for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ke += m0[j] * (rh2[j] * rh2[j]);
+        for (int j = 0; j < 2; ++j) ke = mad(m0[j], rh2[j] * rh2[j], ke);
         if (fuse) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const double diff = fwd ? (th2[j] - t0[j]) : (t0[j] - th2[j]);
             const double sd = m0[j] * diff;
-            p_hot += rh2[j] * sd;
-            p_far += r0[j] * sd;
+            p_hot = mad(rh2[j], sd, p_hot);
+            p_far = mad(r0[j], sd, p_far);
           }
         }
         st(dst[0] + o, th2[0], th2[1]);
@@ -1040,8 +1048,8 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
       for (int j = 0; j < 2; ++j) {
         const double diff = fwd ? (t[j] - av[j]) : (av[j] - t[j]);
         const double sd = m[j] * diff;
-        p_hot += r[j] * sd;
-        p_far += bv[j] * sd;
+        p_hot = mad(r[j], sd, p_hot);
+        p_far = mad(bv[j], sd, p_far);
       }
     }
     this->sum2(p_hot, p_far);
@@ -1088,7 +1096,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
         m2[0] = m0[0]; m2[1] = m0[1];
         ch2[0] = c0[0]; ch2[1] = c0[1];
       }
-      if (P.rng_mode == kRngBuffer) {
+      if (P.rng_mode != kRngPhilox) {
         const v2f64 z0 = ld(P.z_buf + row + o);
         z2[0] = z0[0];
         z2[1] = z0[1];
@@ -1102,7 +1110,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW>, Model, NW> {
       TileCx cx{o, P.dim};
       Model::eval(cx, th2, g2, mp2, aux, part);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) ke += m2[j] * (rh2[j] * rh2[j]);
+      for (int j = 0; j < 2; ++j) ke = mad(m2[j], rh2[j] * rh2[j], ke);
       st(cur[0] + o, th2[0], th2[1]);
       st(cur[1] + o, rh2[0], rh2[1]);
     }
@@ -1177,6 +1185,11 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   WN_LDS int* next_chain = (WN_LDS int*)(bcast + 1);  // (the shift scratch of TrajChip follows at bcast + 2)
   double* arena = P.arena + static_cast<long long>(blockIdx.x) * P.arena_stride;
 
+#if !defined(WN_CPU_SIM)
+  // The chain's wavefront outranks whatever shares its SIMD: the momentum generator of the NEXT transition
+  // (wn_pregen.h) runs beside this kernel at the default priority and issues only in the slots this wavefront leaves.
+  __builtin_amdgcn_s_setprio(WN_MAIN_PRIO);
+#endif
   T t(P, pool, meta, red, bcast, arena);
 #if defined(WN_PHASE_PROFILE)
   t.phase_begin();
@@ -1207,9 +1220,9 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
 #endif
 }
 
-template <class Model, int NW>
+template <class Model, int NW, bool FMA>
 __global__ __launch_bounds__(64 * NW) void transition_kernel_mem(const Params P) {
-  persistent_loop<TrajMem<Model, NW>, NW>(P);
+  persistent_loop<TrajMem<Model, NW, FMA>, NW>(P);
 }
 
 // cx.shift() scratch: the edge lanes of every wavefront publish one value per pair slot (at most 8 pairs per lane)

@@ -57,6 +57,9 @@ typedef enum {
                                public model interface (csrc/models/rw1.h); further models: wn_model_id()        */
 } wn_model;
 
+/* device-resident chains of draws for the posterior summaries at the end of this header */
+typedef struct wn_chains wn_chains;
+
 /* ---- replaces walnutpie_sample_cfunc (walnutpy.cpp:134-149) ------------------- */
 WALNUTS_HIP_EXPORT int walnutpie_sample_device(
     int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
@@ -83,6 +86,26 @@ WALNUTS_HIP_EXPORT int walnutpie_sample_device_reference_streams(
     double step_stabilization, double step_learn_rate_decay, bool save_warmup, double* out, size_t out_size,
     int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
     WalnutpyError** err);
+
+/* walnutpie_sample_device for runs whose draws should not cross PCIe (65 536 chains x 1 024 parameters are 512 MiB per
+ * iteration: ~10 ms of PCIe against ~1.6 ms of compute).  The SAMPLING draws stay in HBM as one [C][S][D] block
+ * (S = max_sampling_iter; it has to fit) owned by *chains_out -- a wn_chains for the wn_summary_* functions below (mean,
+ * variance, quantiles, R-hat, ESS, MCSE on the device), to be released with wn_chains_destroy.  `out` receives only
+ * every `thin`-th sampling draw (iterations 1, 1 + thin, ...; thin = 0: none, `out` may then be NULL unless
+ * save_warmup), after the warmup rows if save_warmup: out[C][max_warmup_iter * save_warmup + ceil(S / thin)][D].
+ * final_lengths[C + c] is the number of sampling draws chain c holds in *chains_out (all of them), of which the rows
+ * 0, thin, 2 thin, ... are the ones in `out`.  Everything else as walnutpie_sample_device. */
+WALNUTS_HIP_EXPORT int walnutpie_sample_device_resident(
+    int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
+    unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
+    int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
+    int max_step_halvings, int min_micro_steps, double max_hamiltonian_error, double step_size_converge_tol,
+    double mass_converge_tol, double rhat_converge_tol, double mass_init_count, double mass_additive_smoothing,
+    double max_macro_steps_target, double step_size_init, double step_accept_rate_target,
+    double step_learning_rate, double step_gradient_decay, double step_sq_gradient_decay,
+    double step_stabilization, double step_learn_rate_decay, bool save_warmup, double* out, size_t out_size,
+    int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
+    int thin, wn_chains** chains_out, WalnutpyError** err);
 
 /* ---- batched engine ------------------------------------------------------------- */
 typedef struct wn_engine wn_engine;
@@ -238,6 +261,13 @@ WALNUTS_HIP_EXPORT int wn_engine_set_stream(wn_engine* e, void* stream, Walnutpy
 WALNUTS_HIP_EXPORT int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane);
 /* the default launch geometry depends on the model (heavier gradients prefer one wavefront per chain) */
 WALNUTS_HIP_EXPORT int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane);
+/* (internal, for the tests) the reference's host-side initial streams as walnutpie_sample_device produces them:
+ * count_per_chain normals x scale per chain from mt19937_64(seed_seq{seed, stream}) through libstdc++'s
+ * normal_distribution -- one distribution for all chains (initial positions, config.hpp:259-268) or a fresh one per
+ * chain (step-size search, util.hpp:288) */
+WALNUTS_HIP_EXPORT void wn_internal_reference_normals(unsigned int seed, unsigned int stream, size_t num_chains,
+                                                      size_t count_per_chain, int fresh_per_chain, double scale,
+                                                      double* out);
 /* (internal) allocates the error object handed back through WalnutpyError** */
 WALNUTS_HIP_EXPORT void* wn_internal_make_error(const char* msg, int type);
 
@@ -247,7 +277,6 @@ WALNUTS_HIP_EXPORT void* wn_internal_make_error(const char* msg, int type);
  * MarkovChainsSplit / MarkovChainsUnified (summary.hpp:119-356) describe them.  The draws stay in HBM; results
  * ([dims] or [k][dims] row-major doubles) come back to host buffers the caller owns.  Same preconditions and
  * std::invalid_argument messages as the reference (-> config errors). */
-typedef struct wn_chains wn_chains;
 
 /* Borrow draws that already live on the device: chain c's n-th draw is the `dims` doubles at
  * draws_dev + c * chain_stride + n * dims -- the layout walnutpie_sample_device fills and wn_engine_*_step writes
@@ -256,6 +285,11 @@ typedef struct wn_chains wn_chains;
 WALNUTS_HIP_EXPORT int wn_chains_view(wn_chains** out, const double* draws_dev, size_t num_chains, size_t max_len,
                                       size_t dims, int64_t chain_stride, const int64_t* lengths, int device,
                                       void* stream, WalnutpyError** err);
+/* The same view, but the handle takes OWNERSHIP of draws_dev (a hipMalloc'd block of num_chains * chain_stride
+ * doubles): wn_chains_destroy frees it.  What walnutpie_sample_device_resident hands back. */
+WALNUTS_HIP_EXPORT int wn_chains_adopt(wn_chains** out, double* draws_dev, size_t num_chains, size_t max_len,
+                                       size_t dims, int64_t chain_stride, const int64_t* lengths, int device,
+                                       WalnutpyError** err);
 /* Copy host draws in MarkovChainsUnified layout (chains stacked, [sum sizes][dims] row-major) to the device. */
 WALNUTS_HIP_EXPORT int wn_chains_upload(wn_chains** out, const double* draws_host, size_t dims, const int64_t* sizes,
                                         size_t num_chains, int device, WalnutpyError** err);

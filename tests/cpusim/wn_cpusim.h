@@ -243,6 +243,9 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
   std::memset(d, v, n);
   return hipSuccess;
 }
+constexpr unsigned hipHostRegisterDefault = 0;
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \

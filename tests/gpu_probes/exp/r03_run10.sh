@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r03
+python -m pytest tests/test_sample_gpu.py -m gpu -x -q 2>&1 | tail -4
+python tests/gpu_probes/sample_device_e2e.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03/sample_device_e2e.txt

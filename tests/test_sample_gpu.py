@@ -67,3 +67,25 @@ def test_reference_summary_symbols_on_the_device(oracle):
     assert np.array_equal(s.r_hat(), sp.wnso.r_hat(chains))
     assert np.array_equal(s.mcse(), sp.wnso.monte_carlo_standard_error(chains))
     assert np.allclose(s.mean(), np.mean(np.concatenate(chains), axis=0))
+
+
+def test_resident_draws_thinned_mode_on_the_device(oracle):
+    """walnutpie_sample_device_resident at a size where the draw block matters (4 096 chains x 256 params x 24 draws):
+    the host receives rows 0, 4, 8, ... of exactly the draws the streaming call returns, the device keeps all of them,
+    and the on-device summaries over the resident block equal the oracle's over the streamed draws."""
+    C, D, S = 4096, 256, 24
+    kw = dict(num_params=D, num_chains=C, seed=33, min_warmup_iter=6, max_warmup_iter=6, min_sampling_iter=S,
+              max_sampling_iter=S)
+    whole = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    res, chains = wa.walnuts_device(wa.MODEL_STD_NORMAL, keep_on_device=True, thin=4, **kw)
+    assert chains.num_chains() == C and chains.num_draws() == C * S
+    for c in (0, 1, 2047, C - 1):
+        assert np.array_equal(np.asarray(res[c]), np.asarray(whole[c])[::4]), c
+        assert res[c].warmup.stepsize == whole[c].warmup.stepsize
+    sub = [np.asarray(w) for w in whole]
+    assert np.array_equal(chains.mean(), sp.wnso.mean(sub))
+    assert np.array_equal(chains.r_hat(), sp.wnso.r_hat(sub))
+    chains.close()
+    res0, chains0 = wa.walnuts_device(wa.MODEL_STD_NORMAL, keep_on_device=True, thin=0, **kw)   # nothing to the host
+    assert all(np.asarray(r).shape == (0, D) for r in res0[:4]) and chains0.num_draws() == C * S
+    assert np.array_equal(chains0.mean(), sp.wnso.mean(sub))

@@ -77,3 +77,31 @@ def test_reference_summary_symbols(sim, oracle):
     assert rc == -1 and lib.walnutpie_get_error_type(err) == 1
     assert b"sum of chain_sizes" in lib.walnutpie_get_error_message(err)
     lib.walnutpie_destroy_error(err)
+
+
+@pytest.mark.timeout(600)
+def test_resident_draws_and_thinned_rows_equal_the_streamed_run(sim, oracle):
+    """walnutpie_sample_device_resident: the draws that stay on the device are the streamed run's, the host gets rows
+    0, thin, 2 thin, ..., and the summaries over the resident block equal the oracle's over the streamed draws."""
+    whole = _run(sim)
+    for thin in (3, 1, 0):
+        res, chains = _run(sim, keep_on_device=True, thin=thin)
+        assert chains.num_chains() == 3 and chains.dims() == 5 and chains.num_draws() == 3 * 7
+        for a, b in zip(whole, res):
+            want = np.asarray(a)[::thin] if thin else np.zeros((0, 5))
+            assert np.array_equal(np.asarray(b), want), thin
+            assert np.array_equal(a.warmup.warmup_draws, b.warmup.warmup_draws)   # warmup rows still come to the host
+        draws = [np.asarray(a) for a in whole]
+        assert np.array_equal(chains.mean(), sp.wnso.mean(draws))
+        assert np.array_equal(chains.r_hat(), sp.wnso.r_hat(draws))
+        chains.close()
+    with pytest.raises(ValueError, match="thin"):
+        _run(sim, keep_on_device=True, thin=-1)
+
+
+@pytest.mark.timeout(600)
+def test_resident_mode_argument_errors_come_back_as_config_errors(sim):
+    import ctypes as C
+    lib = wa.load_library(sim)
+    with pytest.raises(ValueError, match="min_iter must be"):     # the reference's own validation still runs first
+        _run(sim, keep_on_device=True, min_sampling_iter=9, max_sampling_iter=7)

@@ -57,6 +57,11 @@ SYMBOLS = [
      [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
       _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
       _dp, _dp, _i32, PRINT_CALLBACK, _errpp]),
+    ("walnutpie_sample_device_resident", _i32,
+     [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
+      _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
+      _dp, _dp, _i32, PRINT_CALLBACK, _i32, C.POINTER(_vp), _errpp]),
+    ("wn_internal_reference_normals", None, [C.c_uint, C.c_uint, _sz, _sz, _i32, _dbl, _dp]),
     ("walnutpie_ess", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("walnutpie_r_hat", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("walnutpie_mcse", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
@@ -114,6 +119,7 @@ SYMBOLS = [
     ("wn_lanes_for_model_dim", _i32, [_i32, _i32, _i32, _i32]),
     # posterior summaries (summary.hpp:370-768)
     ("wn_chains_view", _i32, [C.POINTER(_vp), _vp, _sz, _sz, _sz, C.c_int64, C.POINTER(C.c_int64), _i32, _vp, _errpp]),
+    ("wn_chains_adopt", _i32, [C.POINTER(_vp), _vp, _sz, _sz, _sz, C.c_int64, C.POINTER(C.c_int64), _i32, _errpp]),
     ("wn_chains_upload", _i32, [C.POINTER(_vp), _dp, _sz, C.POINTER(C.c_int64), _sz, _i32, _errpp]),
     ("wn_chains_destroy", None, [_vp]),
     ("wn_chains_num_chains", _sz, [_vp]),

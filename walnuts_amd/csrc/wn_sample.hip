@@ -15,18 +15,23 @@
 // (walnutpy.cpp:82) instead of mt19937_64.
 #include "wn_hip.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <csignal>
 #include <cstdlib>
 #include <cstring>
 #include <iomanip>
+#include <memory>
 #include <random>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
 #include "../../include/walnuts_hip.h"
+#include "wn_refstream.h"
 
 extern "C" int wn_engine_adapt_step_with_normals(wn_engine* e, const double* normals, WalnutpyError** err);
 extern "C" void* wn_internal_make_error(const char* msg, int type);
@@ -90,6 +95,73 @@ class InterruptGuard {
   struct sigaction before_, custom_;
 };
 
+// ---- small RAII holders: a half-built sink releases what it had (no leak when a later allocation fails) ----
+struct DevBlock {
+  double* p = nullptr;
+  DevBlock() = default;
+  DevBlock(const DevBlock&) = delete;
+  DevBlock& operator=(const DevBlock&) = delete;
+  ~DevBlock() { reset(); }
+  bool alloc(size_t doubles) {
+    reset();
+    return hipMalloc(reinterpret_cast<void**>(&p), doubles * sizeof(double)) == hipSuccess;
+  }
+  void reset() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+  double* release() {
+    double* q = p;
+    p = nullptr;
+    return q;
+  }
+};
+struct Event {
+  hipEvent_t e = nullptr;
+  Event() = default;
+  Event(const Event&) = delete;
+  Event& operator=(const Event&) = delete;
+  ~Event() {
+    if (e) (void)hipEventDestroy(e);
+  }
+  void create() {
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) throw std::runtime_error("cannot create a HIP event");
+  }
+};
+struct Stream {
+  hipStream_t s = nullptr;
+  Stream() = default;
+  Stream(const Stream&) = delete;
+  Stream& operator=(const Stream&) = delete;
+  ~Stream() {
+    if (s) (void)hipStreamDestroy(s);
+  }
+  void create() {
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) throw std::runtime_error("cannot create a HIP stream");
+  }
+};
+// The caller's output buffer, page-locked for the duration of the call (opt-in: WALNUTS_AMD_PIN_OUTPUT=1).  A
+// device-to-host copy into pageable memory goes through the runtime's bounce buffers and blocks the host thread;
+// into registered memory it is a DMA that overlaps the launches.  Measured at 65 536 x 1 024 x 32 draws = 16 GiB
+// (profiles/r03/sample_device_e2e.txt): pageable 1.10 s for the sampling phase (15.6 GB/s, the host blocked),
+// registered 0.37 s (46 GB/s, overlapped) -- after 0.72 s spent registering 16 GiB of fresh pages.  A wash for a
+// buffer used once, a 3x for a caller that reuses its buffer, hence opt-in; registration is best effort
+// (RLIMIT_MEMLOCK) and falls back to the pageable path.
+struct PinnedRange {
+  void* p = nullptr;
+  PinnedRange(void* ptr, size_t bytes) {
+    const char* env = std::getenv("WALNUTS_AMD_PIN_OUTPUT");
+    if (ptr == nullptr || bytes == 0 || env == nullptr || env[0] != '1') return;
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = ptr;
+    else (void)hipGetLastError();
+  }
+  PinnedRange(const PinnedRange&) = delete;
+  PinnedRange& operator=(const PinnedRange&) = delete;
+  ~PinnedRange() {
+    if (p) (void)hipHostUnregister(p);
+  }
+};
+
 // The draw sink (handlers.hpp:63-116 writes every draw straight into the caller's buffer, whatever its size).
 // The device writes the draws of up to `span` consecutive iterations of all chains into one of two staging blocks
 // [C][span][D]; a full block goes to the caller's out[C][rows][D] as ONE strided copy on a second stream while the
@@ -97,41 +169,39 @@ class InterruptGuard {
 // [C][T][D] may exceed HBM (65 536 chains x 1 000 draws x 1 024 = 537 GB).
 class DrawSink {
  public:
-  DrawSink(size_t chains, size_t rows, size_t dim, double* out, hipStream_t compute)
+  // `rows`: rows per chain of the caller's buffer; `capacity`: how many of them this sink will be asked to write
+  DrawSink(size_t chains, size_t rows, size_t capacity, size_t dim, double* out, hipStream_t compute)
       : C_(chains), rows_(rows), D_(dim), out_(out), compute_(compute) {
-    if (C_ * rows_ * D_ == 0) return;
+    if (C_ * capacity * D_ == 0) return;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t{1} << 30;
     size_t budget = free_b / 4;  // both blocks together: a quarter of what the engine left
     if (const char* env = std::getenv("WALNUTS_AMD_DRAW_STAGING_BYTES")) budget = std::strtoull(env, nullptr, 10);
     const size_t per_iter = C_ * D_ * sizeof(double);
-    span_ = std::max<size_t>(1, std::min(rows_, budget / 2 / per_iter));
-    for (int b = 0; b < 2; ++b) {
-      if (hipMalloc(reinterpret_cast<void**>(&block_[b]), C_ * span_ * D_ * sizeof(double)) != hipSuccess)
-        throw std::runtime_error("cannot allocate the device draw staging buffer");
-      if (hipEventCreateWithFlags(&filled_[b], hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&drained_[b], hipEventDisableTiming) != hipSuccess)
-        throw std::runtime_error("cannot create the draw-sink events");
+    span_ = std::max<size_t>(1, std::min(capacity, budget / 2 / per_iter));
+    // other processes or ranks may share the device: on failure halve the span until the two blocks fit
+    for (;;) {
+      if (block_[0].alloc(C_ * span_ * D_) && block_[1].alloc(C_ * span_ * D_)) break;
+      (void)hipGetLastError();
+      block_[0].reset();
+      block_[1].reset();
+      if (span_ == 1) throw std::runtime_error("cannot allocate the device draw staging buffer");
+      span_ = (span_ + 1) / 2;
     }
-    if (hipStreamCreateWithFlags(&copy_, hipStreamNonBlocking) != hipSuccess)
-      throw std::runtime_error("cannot create the draw-sink stream");
-  }
-  ~DrawSink() {
     for (int b = 0; b < 2; ++b) {
-      if (block_[b]) (void)hipFree(block_[b]);
-      if (filled_[b]) (void)hipEventDestroy(filled_[b]);
-      if (drained_[b]) (void)hipEventDestroy(drained_[b]);
+      filled_[b].create();
+      drained_[b].create();
     }
-    if (copy_) (void)hipStreamDestroy(copy_);
+    copy_.create();
   }
   size_t stride() const { return span_ * D_; }  // doubles between two chains' rows in a staging block
   // where the next iteration's draws go (device pointer of chain 0's row)
   double* next_row() {
     if (fill_ == 0 && busy_[cur_]) {  // the block still feeds a copy: the kernels must not overwrite it yet
-      if (hipStreamWaitEvent(compute_, drained_[cur_], 0) != hipSuccess) throw std::runtime_error("draw sink: wait failed");
+      if (hipStreamWaitEvent(compute_, drained_[cur_].e, 0) != hipSuccess) throw std::runtime_error("draw sink: wait failed");
       busy_[cur_] = false;
     }
-    return block_[cur_] + fill_ * D_;
+    return block_[cur_].p + fill_ * D_;
   }
   // the iteration launched into next_row() is queued on the compute stream
   void row_done() {
@@ -143,17 +213,17 @@ class DrawSink {
   // everything written so far is in the caller's buffer when this returns
   void finish() {
     if (fill_ > 0) flush();
-    if (copy_ && hipStreamSynchronize(copy_) != hipSuccess) throw std::runtime_error("copying draws to the host failed");
+    if (copy_.s && hipStreamSynchronize(copy_.s) != hipSuccess) throw std::runtime_error("copying draws to the host failed");
   }
 
  private:
   void flush() {
     const size_t first = written_ - fill_;
-    if (hipEventRecord(filled_[cur_], compute_) != hipSuccess ||
-        hipStreamWaitEvent(copy_, filled_[cur_], 0) != hipSuccess ||
-        hipMemcpy2DAsync(out_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_], span_ * D_ * sizeof(double),
-                         fill_ * D_ * sizeof(double), C_, hipMemcpyDeviceToHost, copy_) != hipSuccess ||
-        hipEventRecord(drained_[cur_], copy_) != hipSuccess)
+    if (hipEventRecord(filled_[cur_].e, compute_) != hipSuccess ||
+        hipStreamWaitEvent(copy_.s, filled_[cur_].e, 0) != hipSuccess ||
+        hipMemcpy2DAsync(out_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_].p, span_ * D_ * sizeof(double),
+                         fill_ * D_ * sizeof(double), C_, hipMemcpyDeviceToHost, copy_.s) != hipSuccess ||
+        hipEventRecord(drained_[cur_].e, copy_.s) != hipSuccess)
       throw std::runtime_error("copying draws to the host failed");
     busy_[cur_] = true;
     cur_ ^= 1;
@@ -161,12 +231,90 @@ class DrawSink {
   }
   size_t C_, rows_, D_;
   double* out_;
-  hipStream_t compute_, copy_ = nullptr;
-  double* block_[2] = {nullptr, nullptr};
-  hipEvent_t filled_[2] = {nullptr, nullptr}, drained_[2] = {nullptr, nullptr};
+  hipStream_t compute_;
+  Stream copy_;
+  DevBlock block_[2];
+  Event filled_[2], drained_[2];
   bool busy_[2] = {false, false};
   size_t span_ = 1, fill_ = 0, written_ = 0;
   int cur_ = 0;
+};
+
+// Resident mode (walnutpie_sample_device_resident): the sampling draws stay in one [C][S][D] block in HBM; every
+// `thin`-th of them is also copied to the caller's buffer, row by row, on a second stream.
+class ResidentDraws {
+ public:
+  ResidentDraws(size_t chains, size_t max_sampling, size_t dim, int thin, double* out, size_t out_rows,
+                size_t out_first_row, hipStream_t compute)
+      : C_(chains), S_(max_sampling), D_(dim), thin_(thin), out_(out), out_rows_(out_rows), out_first_(out_first_row),
+        compute_(compute) {
+    size_t free_b = 0, total_b = 0;
+    const size_t bytes = C_ * S_ * D_ * sizeof(double);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b - free_b / 16) {
+      std::stringstream ss;
+      ss << "the sampling draws (" << C_ << " chains x " << S_ << " draws x " << D_ << " doubles = " << (bytes >> 20)
+         << " MiB) do not fit the device's free memory (" << (free_b >> 20) << " MiB): lower max_sampling_iter or use "
+         << "walnutpie_sample_device, which streams them to the host";
+      throw std::runtime_error(ss.str());
+    }
+    if (bytes > 0 && !block_.alloc(C_ * S_ * D_)) throw std::runtime_error("cannot allocate the device-resident draw block");
+    ready_.create();
+    copy_.create();
+  }
+  int64_t stride() const { return static_cast<int64_t>(S_ * D_); }
+  double* next_row() { return block_.p + written_ * D_; }
+  void row_done() {
+    if (thin_ > 0 && written_ % static_cast<size_t>(thin_) == 0) {
+      const size_t k = written_ / static_cast<size_t>(thin_);
+      if (hipEventRecord(ready_.e, compute_) != hipSuccess || hipStreamWaitEvent(copy_.s, ready_.e, 0) != hipSuccess ||
+          hipMemcpy2DAsync(out_ + (out_first_ + k) * D_, out_rows_ * D_ * sizeof(double), block_.p + written_ * D_,
+                           S_ * D_ * sizeof(double), D_ * sizeof(double), C_, hipMemcpyDeviceToHost,
+                           copy_.s) != hipSuccess)
+        throw std::runtime_error("copying thinned draws to the host failed");
+    }
+    ++written_;
+  }
+  size_t written() const { return written_; }
+  void finish() {
+    if (hipStreamSynchronize(copy_.s) != hipSuccess) throw std::runtime_error("copying thinned draws to the host failed");
+  }
+  double* release() { return block_.release(); }
+
+ private:
+  size_t C_, S_, D_;
+  int thin_;
+  double* out_;
+  size_t out_rows_, out_first_;
+  hipStream_t compute_;
+  DevBlock block_;
+  Event ready_;
+  Stream copy_;
+  size_t written_ = 0;
+};
+
+// Bounded run-ahead of the host: the steps are asynchronous, so without this the host queues every launch of the run
+// ahead of the GPU -- a Ctrl-C would only be noticed after the whole queue has drained, and progress lines would
+// report enqueued, not completed, iterations.  One event per iteration in a small ring; before enqueuing iteration n
+// the host waits for iteration n - kDepth.
+class RunAhead {
+ public:
+  static constexpr int kDepth = 4;
+  explicit RunAhead(hipStream_t s) : stream_(s) {
+    for (auto& e : ring_) e.create();
+  }
+  void before_enqueue() {
+    if (count_ >= kDepth && hipEventSynchronize(ring_[count_ % kDepth].e) != hipSuccess)
+      throw std::runtime_error("waiting for an earlier iteration failed");
+  }
+  void after_enqueue() {
+    if (hipEventRecord(ring_[count_ % kDepth].e, stream_) != hipSuccess) throw std::runtime_error("event record failed");
+    ++count_;
+  }
+
+ private:
+  hipStream_t stream_;
+  Event ring_[kDepth];
+  size_t count_ = 0;
 };
 
 struct Printer {  // python/src/walnutpie/handlers.hpp:17-59
@@ -197,8 +345,26 @@ struct Printer {  // python/src/walnutpie/handlers.hpp:17-59
 
 }  // namespace
 
+// WALNUTS_AMD_TIMING=1: wall-clock time of the call's phases on stderr (where a drop-in call spends its time)
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  PhaseTimer() : on(std::getenv("WALNUTS_AMD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[walnuts_amd] %-34s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
+struct ResidentRequest {  // walnutpie_sample_device_resident
+  int thin;
+  wn_chains** chains_out;
+};
+
 static int sample_device_impl(
-    bool reference_streams,
+    bool reference_streams, const ResidentRequest* resident,
     int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
     unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
     int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
@@ -218,7 +384,18 @@ static int sample_device_impl(
     }
     if (num_params < 1) throw std::invalid_argument("num_params must be in {1, 2, ... }");
     if (max_sampling_iter < 0 || max_warmup_iter < 0) throw std::invalid_argument("iteration counts must be >= 0");
-    const size_t rows = static_cast<size_t>(max_sampling_iter) + (save_warmup ? static_cast<size_t>(max_warmup_iter) : 0);
+    const size_t warm_rows = save_warmup ? static_cast<size_t>(max_warmup_iter) : 0;
+    size_t samp_rows = static_cast<size_t>(max_sampling_iter);  // sampling rows per chain in the caller's buffer
+    if (resident != nullptr) {
+      if (resident->thin < 0) throw std::invalid_argument("thin must be non-negative");
+      if (resident->chains_out == nullptr) throw std::invalid_argument("chains_out must not be null");
+      if (max_sampling_iter < 1) throw std::invalid_argument("resident draws need max_sampling_iter >= 1");
+      *resident->chains_out = nullptr;
+      const size_t t = static_cast<size_t>(resident->thin);
+      samp_rows = t == 0 ? 0 : (static_cast<size_t>(max_sampling_iter) + t - 1) / t;
+    }
+    const size_t rows = samp_rows + warm_rows;
+    if (rows > 0 && out == nullptr) throw std::invalid_argument("out must not be null");
     const size_t draws_offset = static_cast<size_t>(num_params) * rows;
     if (out_size < num_chains * draws_offset) {
       std::stringstream ss;
@@ -263,11 +440,35 @@ static int sample_device_impl(
     cfg.step_stabilization = step_stabilization;
     cfg.step_learn_rate_decay = step_learn_rate_decay;
 
+    PhaseTimer timer;
     EngineGuard guard;
     WN_CALL(wn_engine_create(&guard.e, model, num_params, model_params, num_chains, &cfg, &call_err_));
     wn_engine* e = guard.e;
     const size_t D = static_cast<size_t>(num_params);
+    timer.mark("engine created");
 
+    // The reference's two host streams (wn_refstream.h): the step-size search's normals -- mt19937_64(seed_seq{seed, 2}),
+    // the engine shared by the chains in order, a fresh normal distribution per chain (walnutpy.cpp:75-80, util.hpp:288)
+    // -- are produced by a second thread while this one produces the initial positions; both hand the non-sequential
+    // half of the work to the same worker pool.
+    wnref::Workers pool(wnref::usable_threads());
+    std::vector<double> z(num_chains * D);
+    std::thread step_stream([&] {
+      std::seed_seq ss{seed, 2u};
+      std::mt19937_64 rng(ss);
+      wnref::PolarStream normals(rng, pool, 1.0);
+      for (size_t c = 0; c < num_chains; ++c) {
+        normals.reset_distribution();
+        normals.fill(&z[c * D], D);
+      }
+      normals.finish();
+    });
+    struct Joiner {
+      std::thread& t;
+      ~Joiner() {
+        if (t.joinable()) t.join();
+      }
+    } join_step_stream{step_stream};
     // initial positions (walnutpy.cpp:176-190)
     {
       std::vector<double> pos(num_chains * D);
@@ -280,14 +481,16 @@ static int sample_device_impl(
         finite_positive(init_radius, "init_scale");
         std::seed_seq ss{seed, 1u};
         std::mt19937_64 rng(ss);
-        std::normal_distribution<double> normal(0.0, 1.0);  // one detail::Random for all chains, config.hpp:261-266
-        for (size_t c = 0; c < num_chains; ++c) {
-          for (size_t i = 0; i < D; ++i) pos[c * D + i] = normal(rng);
-          for (size_t i = 0; i < D; ++i) pos[c * D + i] *= init_radius;
-        }
+        // one detail::Random -- one normal distribution -- for all chains (config.hpp:261-266); x *= init_radius
+        wnref::PolarStream normals(rng, pool, init_radius);
+        normals.fill(pos.data(), pos.size());
+        normals.finish();
+        step_stream.join();
+        pool.wait_idle();
       }
       WN_CALL(wn_engine_set_positions(e, pos.data(), &call_err_));
     }
+    timer.mark("initial positions (host stream)");
     // masses (walnutpy.cpp:64-73).  NB the reference hands init_inv_metric to the builder's
     // masses(): reproduced as is.
     if (init_inv_metric != nullptr) {
@@ -299,18 +502,14 @@ static int sample_device_impl(
       std::vector<double> steps(num_chains, step_size_init);
       WN_CALL(wn_engine_set_step_sizes(e, steps.data(), &call_err_));
     }
-    // adapt_step_build with mt19937_64(seed_seq{seed, 2}) (walnutpy.cpp:75-80): the engine is shared by
-    // the chains in order and each chain starts a fresh normal distribution (util.hpp:288)
+    timer.mark("initial masses");
+    // adapt_step_build (walnutpy.cpp:75-80) on the normals the second thread produced
     {
-      std::seed_seq ss{seed, 2u};
-      std::mt19937_64 rng(ss);
-      std::vector<double> z(num_chains * D);
-      for (size_t c = 0; c < num_chains; ++c) {
-        std::normal_distribution<double> normal(0.0, 1.0);
-        for (size_t i = 0; i < D; ++i) z[c * D + i] = normal(rng);
-      }
+      if (step_stream.joinable()) step_stream.join();
+      pool.wait_idle();
       WN_CALL(wn_engine_adapt_step_with_normals(e, z.data(), &call_err_));
     }
+    timer.mark("step-size search (host stream)");
     // walnutpy.cpp:82: walnuts<mt19937_64>(seed + id + num_chains, ...)
     if (reference_streams) {
       WN_CALL(wn_engine_seed_reference_streams(e, static_cast<uint64_t>(seed) + id + num_chains, &call_err_));
@@ -319,13 +518,23 @@ static int sample_device_impl(
     }
 
     InterruptGuard interrupt;  // walnutpy.cpp: interrupt::walnutpy_interrupt_handler on the stack of the call
-    DrawSink sink(num_chains, rows, D, out, reinterpret_cast<hipStream_t>(wn_engine_stream(e)));
+    const hipStream_t compute = reinterpret_cast<hipStream_t>(wn_engine_stream(e));
+    PinnedRange pinned(out, num_chains * draws_offset * sizeof(double));
+    DrawSink sink(num_chains, rows, resident != nullptr ? warm_rows : rows, D, out, compute);
+    std::unique_ptr<ResidentDraws> kept;
+    if (resident != nullptr)
+      kept = std::make_unique<ResidentDraws>(num_chains, static_cast<size_t>(max_sampling_iter), D, resident->thin, out,
+                                             rows, warm_rows, compute);
+    RunAhead pace(compute);
+    timer.mark("output pinned, draw sink ready");
     Printer printer{print, static_cast<size_t>(refresh)};
     for (int it = 1; it <= max_warmup_iter; ++it) {  // AdaptWorker loop, adapt.hpp:116-127
       interrupt.throw_if_interrupted();
+      pace.before_enqueue();
       double* dst = save_warmup ? sink.next_row() : nullptr;
       WN_CALL(wn_engine_warmup_step(e, dst, static_cast<int64_t>(sink.stride()), &call_err_));
       if (save_warmup) sink.row_done();
+      pace.after_enqueue();
       printer.progress(num_chains);
       // controller_loop (adapt.hpp:172-229) on the snapshots published every publish_stride = 5 iterations
       if (it >= min_warmup_iter && it < max_warmup_iter && it % 5 == 0) {
@@ -335,14 +544,25 @@ static int sample_device_impl(
       }
     }
     const size_t written_warmup = sink.written();
+    if (timer.on) WN_CALL(wn_engine_synchronize(e, &call_err_));
+    timer.mark("warmup iterations");
     WN_CALL(wn_engine_freeze(e, &call_err_));  // on_warmup_complete, handlers.hpp:91-101
     printer.in_warmup = false;
     if (stepsize_out != nullptr) WN_CALL(wn_engine_get_step_sizes(e, stepsize_out, &call_err_));
     if (inv_metric_out != nullptr) WN_CALL(wn_engine_get_inv_mass(e, inv_metric_out, &call_err_));
+    size_t sampled = 0;
     for (int it = 1; it <= max_sampling_iter; ++it) {  // ChainWorker loop, sampler.hpp:82-93
       interrupt.throw_if_interrupted();
-      WN_CALL(wn_engine_sample_step(e, sink.next_row(), static_cast<int64_t>(sink.stride()), &call_err_));
-      sink.row_done();
+      pace.before_enqueue();
+      if (kept) {
+        WN_CALL(wn_engine_sample_step(e, kept->next_row(), kept->stride(), &call_err_));
+        kept->row_done();
+      } else {
+        WN_CALL(wn_engine_sample_step(e, sink.next_row(), static_cast<int64_t>(sink.stride()), &call_err_));
+        sink.row_done();
+      }
+      ++sampled;
+      pace.after_enqueue();
       printer.progress(num_chains);
       // controller_loop (sampler.hpp:117-158): R-hat of the log density once every chain has min_iter draws.  The
       // reference's controller looks on a 1 ms timer, not after every draw: here every `rhat_stride` iterations
@@ -362,13 +582,28 @@ static int sample_device_impl(
         if (rhat <= rhat_converge_tol) break;
       }
     }
-    const size_t written = sink.written();
     WN_CALL(wn_engine_check(e, &call_err_));
+    timer.mark("sampling iterations");
     sink.finish();
+    if (kept) kept->finish();
+    timer.mark("draws in the caller's buffer");
     interrupt.throw_if_interrupted();
     for (size_t c = 0; c < num_chains; ++c) {  // walnutpy.cpp:215-218
       final_lengths[c] = static_cast<int>(written_warmup);
-      final_lengths[c + num_chains] = static_cast<int>(written - written_warmup);
+      final_lengths[c + num_chains] = static_cast<int>(sampled);
+    }
+    if (kept) {
+      // the block changes hands: a wn_chains of `sampled` draws per chain that frees it when it is destroyed
+      WN_CALL(wn_engine_synchronize(e, &call_err_));
+      std::vector<int64_t> lengths(num_chains, static_cast<int64_t>(sampled));
+      double* block = kept->release();
+      WalnutpyError* adopt_err = nullptr;
+      if (wn_chains_adopt(resident->chains_out, block, num_chains, static_cast<size_t>(max_sampling_iter), D,
+                          static_cast<int64_t>(max_sampling_iter) * static_cast<int64_t>(D), lengths.data(), cfg.device,
+                          &adopt_err) != 0) {
+        (void)hipFree(block);
+        rethrow(adopt_err);
+      }
     }
     return 0;
   } catch (const InterruptException&) {
@@ -402,9 +637,42 @@ static int sample_device_impl(
       double *out, size_t out_size, int *final_lengths, double *stepsize_out, double *inv_metric_out,            \
       int refresh, PRINT_CALLBACK print, WalnutpyError **err
 
-extern "C" int walnutpie_sample_device(WN_SAMPLE_PARAMS) { return sample_device_impl(false, WN_SAMPLE_ARGS); }
+// (internal, for the tests) the host streams above as a function: `count_per_chain` normals for each of `num_chains`
+// chains from mt19937_64(seed_seq{seed, stream}), one distribution for all chains or a fresh one per chain
+extern "C" void wn_internal_reference_normals(unsigned int seed, unsigned int stream, size_t num_chains,
+                                              size_t count_per_chain, int fresh_per_chain, double scale, double* out) {
+  wnref::Workers pool(wnref::usable_threads());
+  std::seed_seq ss{seed, stream};
+  std::mt19937_64 rng(ss);
+  wnref::PolarStream normals(rng, pool, scale);
+  for (size_t c = 0; c < num_chains; ++c) {
+    if (fresh_per_chain) normals.reset_distribution();
+    normals.fill(out + c * count_per_chain, count_per_chain);
+  }
+  normals.finish();
+  pool.wait_idle();
+}
+
+extern "C" int walnutpie_sample_device(WN_SAMPLE_PARAMS) { return sample_device_impl(false, nullptr, WN_SAMPLE_ARGS); }
 extern "C" int walnutpie_sample_device_reference_streams(WN_SAMPLE_PARAMS) {
-  return sample_device_impl(true, WN_SAMPLE_ARGS);
+  return sample_device_impl(true, nullptr, WN_SAMPLE_ARGS);
+}
+#undef WN_SAMPLE_PARAMS
+#define WN_SAMPLE_PARAMS_NOERR                                                                                    \
+  int model, const double *model_params, int num_params, const double *inits, size_t num_chains,                 \
+      unsigned int seed, unsigned int id, double init_radius, const double *init_inv_metric, int min_warmup_iter, \
+      int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,           \
+      int max_step_halvings, int min_micro_steps, double max_hamiltonian_error, double step_size_converge_tol,   \
+      double mass_converge_tol, double rhat_converge_tol, double mass_init_count,                                \
+      double mass_additive_smoothing, double max_macro_steps_target, double step_size_init,                      \
+      double step_accept_rate_target, double step_learning_rate, double step_gradient_decay,                     \
+      double step_sq_gradient_decay, double step_stabilization, double step_learn_rate_decay, bool save_warmup,  \
+      double *out, size_t out_size, int *final_lengths, double *stepsize_out, double *inv_metric_out,            \
+      int refresh, PRINT_CALLBACK print
+extern "C" int walnutpie_sample_device_resident(WN_SAMPLE_PARAMS_NOERR, int thin, wn_chains** chains_out,
+                                                WalnutpyError** err) {
+  const ResidentRequest req{thin, chains_out};
+  return sample_device_impl(false, &req, WN_SAMPLE_ARGS);
 }
 
 // ---- walnutpie_ess / walnutpie_r_hat / walnutpie_mcse (walnutpy.cpp:333-369) ----------------------------------

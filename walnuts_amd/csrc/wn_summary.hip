@@ -725,6 +725,17 @@ int wn_chains_view(wn_chains** out, const double* draws_dev, size_t num_chains, 
   });
 }
 
+int wn_chains_adopt(wn_chains** out, double* draws_dev, size_t num_chains, size_t max_len, size_t dims,
+                    int64_t chain_stride, const int64_t* lengths, int device, WalnutpyError** err) {
+  wn_chains* ch = nullptr;
+  const int rc = wn_chains_view(&ch, draws_dev, num_chains, max_len, dims, chain_stride, lengths, device, nullptr, err);
+  if (rc != 0) return rc;
+  ch->owned.p = draws_dev;  // freed with the handle
+  ch->owned.n = num_chains * static_cast<size_t>(chain_stride);
+  *out = ch;
+  return 0;
+}
+
 int wn_chains_upload(wn_chains** out, const double* draws_host, size_t dims, const int64_t* sizes, size_t num_chains,
                      int device, WalnutpyError** err) {
   return guarded(err, [&] {

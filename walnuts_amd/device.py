@@ -95,10 +95,24 @@ def walnuts_device(
     save_warmup: bool = False,
     refresh: int = 0,
     reference_streams: bool = False,
+    keep_on_device: bool = False,
+    thin: int = 0,
     lib_path: Optional[str] = None,
     print_callback=None,
-) -> list:
+):
+    """The device-model sibling of the reference's ``walnuts_pyfunc`` (pyfunc.py:45-286): same keywords, same result
+    (a list of per-chain draw arrays carrying ``.warmup``).
+
+    ``keep_on_device=True`` (walnutpie_sample_device_resident): the sampling draws stay in HBM and the call returns
+    ``(results, chains)`` -- ``chains`` a :class:`walnuts_amd.summary.MarkovChains` over ALL sampling draws (mean,
+    variance, quantiles, R-hat, ESS, MCSE computed on the device), ``results[c]`` holding only every ``thin``-th draw
+    (``thin=0``: none): 65 536 chains x 1 024 parameters are 512 MiB per iteration, six times what PCIe moves in the
+    time the GPU needs to produce them."""
     lib = _ffi.load_library(lib_path)
+    if keep_on_device and reference_streams:
+        raise ValueError("keep_on_device is not available with reference_streams")
+    if thin < 0:
+        raise ValueError("thin must be non-negative")
     if inits is not None:
         inits = np.asarray(inits, dtype=np.float64)
         if inits.ndim == 1:
@@ -119,7 +133,12 @@ def walnuts_device(
         raise ValueError("model_params must have num_params entries")
 
     out = _prepare_output_buffer(num_chains=num_chains, num_params=num_params, max_sampling_iter=max_sampling_iter,
-                                 max_warmup_iter=max_warmup_iter, save_warmup=save_warmup)
+                                 max_warmup_iter=max_warmup_iter, save_warmup=save_warmup) if not keep_on_device else None
+    if keep_on_device:   # only every thin-th sampling draw comes to the host
+        _prepare_output_buffer(num_chains=num_chains, num_params=1, max_sampling_iter=max_sampling_iter,
+                               max_warmup_iter=0, save_warmup=False)   # (the same argument checks)
+        rows_sampling = 0 if thin == 0 else -(-max_sampling_iter // thin)
+        out = np.zeros((num_chains, rows_sampling + max_warmup_iter * save_warmup, num_params), dtype=np.float64)
     inv_metric_init = _prepare_inv_metric(init_inv_metric, (num_params,), num_chains)
     final_lengths = np.zeros(2 * num_chains, dtype=np.intc)
     stepsize_out = np.zeros(num_chains, dtype=np.float64)
@@ -136,6 +155,11 @@ def walnuts_device(
     dp = _ffi._dp
     err = C.c_void_p()
     entry = lib.walnutpie_sample_device_reference_streams if reference_streams else lib.walnutpie_sample_device
+    chains_handle = C.c_void_p()
+    tail = (refresh, cb, C.byref(err))
+    if keep_on_device:
+        entry = lib.walnutpie_sample_device_resident
+        tail = (refresh, cb, thin, C.byref(chains_handle), C.byref(err))
     rc = entry(
         model, None if mp is None else mp.ctypes.data_as(dp), num_params,
         None if inits is None else inits.ctypes.data_as(dp), num_chains, seed, id, init_radius,
@@ -144,9 +168,9 @@ def walnuts_device(
         max_hamiltonian_error, step_size_converge_tol, mass_converge_tol, rhat_converge_tol, mass_init_count,
         mass_additive_smoothing, max_macro_steps_target, step_size_init, step_accept_rate_target, step_learning_rate,
         step_gradient_decay, step_sq_gradient_decay, step_stabilization, step_learn_rate_decay, save_warmup,
-        out.ctypes.data_as(dp), out.size, final_lengths.ctypes.data_as(C.POINTER(C.c_int)),
+        out.ctypes.data_as(dp) if out.size else None, out.size, final_lengths.ctypes.data_as(C.POINTER(C.c_int)),
         stepsize_out.ctypes.data_as(dp), None if inv_metric_out is None else inv_metric_out.ctypes.data_as(dp),
-        refresh, cb, C.byref(err))
+        *tail)
     _ffi.check(lib, rc, err)
 
     results = []  # python/src/walnutpie/pyfunc.py:270-286
@@ -155,5 +179,11 @@ def walnuts_device(
         warm = out[c, :n_warm] if save_warmup else None
         info = WarmupInfo(stepsize=float(stepsize_out[c]),
                           inv_metric=None if inv_metric_out is None else inv_metric_out[c], warmup_draws=warm)
+        if keep_on_device:   # rows 0, thin, 2 thin, ... of the n_samp draws the device holds
+            n_samp = 0 if thin == 0 else -(-n_samp // thin)
         results.append(WalnutsOutputArray(out[c, n_warm:n_warm + n_samp], info))
+    if keep_on_device:
+        from .summary import MarkovChains
+
+        return results, MarkovChains(chains_handle, lib)
     return results

@@ -96,6 +96,25 @@ class MarkovChains:
         _ffi.check(self.lib, rc, err)
         return out
 
+    # the free functions below as methods (what a caller holding the chains of walnuts_device(keep_on_device=True) uses)
+    def mean(self):
+        return mean(self)
+
+    def sample_variance(self):
+        return sample_variance(self)
+
+    def quantiles(self, probs):
+        return quantiles(self, probs)
+
+    def r_hat(self):
+        return r_hat(self)
+
+    def effective_sample_size(self):
+        return effective_sample_size(self)
+
+    def monte_carlo_standard_error(self):
+        return monte_carlo_standard_error(self)
+
 
 def mean(chains: MarkovChains) -> np.ndarray:
     return chains._vec(chains.lib.wn_summary_mean, (chains.dims(),))

@@ -29,9 +29,11 @@ Rank 0 prints ONE JSON line.  `value` = gradient evaluations of all chains on al
     / kernel time / 8 TB/s.  The 56*D "algorithmic" byte figure of the metric definition is reported under
     `algorithmic` only: those bytes never reach HBM, so their rate is not a bandwidth.
   * streaming kernels (D > 8192): bound "hbm", `achieved` = algorithmic 56*D bytes per gradient evaluation / time.
-`parity_gate`: 64 chains replayed transition by transition on the CPU oracle in REFERENCE order
-(sequential sums, libm) from the device's own states with the same random streams: max relative difference of
-the selected position per transition, tree agreement, and the count of decisions within 1e-12 of a threshold.
+`parity_gate`: 64 chains replayed transition by transition on the CPU oracle in the REFERENCE's
+arithmetic (libm, every product rounded) under both summation orders the reference side can have -- Eigen 3.4's SSE2
+redux (restated from its published algorithm) and sequential loops -- from the device's own states with the same random
+streams: max relative difference of the selected position per transition, tree agreement, and the count of decisions
+within 1e-12 of a threshold, per order.
 `cpu_baseline` = that oracle (a CPU port of the reference algorithm) timed on the host cores for a bounded sample.
 """
 import argparse
@@ -211,12 +213,15 @@ def cpu_baseline(args, D):
 
 
 def parity_gate(args, D, cfg_kwargs):
-    """SURVEY.md section 8d "parity gate in the same run": a subset of chains replayed on the CPU restatement in
-    REFERENCE order (left-to-right sums, libm exp/log) with the identical random stream, one transition at a time
-    from the device's own state.  Reports the max relative difference of the selected position per transition (north
-    star: <= 1e-10), how many chains built the identical tree, and how many decisions sat within 1e-12 (relative) of
-    their threshold -- |H0-H1| <= max_error (walnuts.hpp:339), the U-turn signs (:199-200), log u < delta (:379) --
-    i.e. where a different summation order could have flipped the tree."""
+    """SURVEY.md section 8d "parity gate in the same run": a subset of chains replayed on the CPU restatement in the
+    REFERENCE's arithmetic (libm exp/log, every product rounded) with the identical random stream, one transition at a
+    time from the device's own state -- under BOTH summation orders the reference side can have: "eigen_sse2", the
+    order of Eigen 3.4's vectorised redux with 2-lane packets (what `.sum()` / `.dot()` execute in the reference's
+    default x86-64 build; restated from Eigen's published algorithm, oracle/wn_oracle.cpp), and "sequential", plain
+    left-to-right loops.  Per order: the max relative difference of the selected position per transition (north star:
+    <= 1e-10), how many chains built the identical tree, and how many decisions sat within 1e-12 (relative) of their
+    threshold -- |H0-H1| <= max_error (walnuts.hpp:339), the U-turn signs (:199-200), log u < delta (:379) -- i.e.
+    where a different summation order could have flipped the tree.  The top-level fields are the worst over both."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import walnuts_amd as wa
     import wno
@@ -224,50 +229,69 @@ def parity_gate(args, D, cfg_kwargs):
     Cg, T = args.gate_chains, args.gate_transitions
     model_id, params = model_setup(args.model, D)
     dev = wa.DeviceEngine(model_id, D, Cg, wa.default_config(**cfg_kwargs), params=params)
-    ocfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=0)
-    orc = wno.Engine(oracle_model(args.model), D, Cg, ocfg, params=params)
-    orc.set_tie_tolerance(1e-12)
+    orders = {"eigen_sse2": wno.REDUCE_EIGEN_SSE2, "sequential": 0}
+    orcs = {}
+    for name, lanes in orders.items():
+        ocfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=lanes)
+        orcs[name] = wno.Engine(oracle_model(args.model), D, Cg, ocfg, params=params)
+        orcs[name].set_tie_tolerance(1e-12)
+        orcs[name].seed_chains(args.seed + 1, 0)
     dev.init_positions(args.seed, 0, 2.0)
     dev.init_masses_from_grad(1e-5)
     dev.set_step_sizes(1.0)
     dev.adapt_step(args.seed, 0)
     dev.seed_chains(args.seed + 1, 0)
-    orc.seed_chains(args.seed + 1, 0)
     adapt = min(args.adapt_iters, 40)
     for _ in range(adapt):
         dev.warmup_step()
     dev.freeze()
     dev.synchronize()
     inv_mass, steps, mm = dev.inv_mass(), dev.step_sizes(), dev.min_micro()
-    rel, rel_lp, same_tree = [], [], []
+    rec = {name: {"rel": [], "rel_lp": [], "same": []} for name in orders}
     for t in range(T):
         pos = dev.positions()
-        orc.set_positions(pos)
-        orc.set_sampler_state(inv_mass, steps, mm)
-        orc.set_transition_index(adapt + t)
-        g_dev0, g_orc0 = dev.grad_evals().copy(), orc.grad_evals().copy()
+        g_dev0 = dev.grad_evals().copy()
+        g_orc0 = {}
+        for name, orc in orcs.items():
+            orc.set_positions(pos)
+            orc.set_sampler_state(inv_mass, steps, mm)
+            orc.set_transition_index(adapt + t)
+            g_orc0[name] = orc.grad_evals().copy()
         dev.sample_step()
-        orc.sample_step(host_cores())
+        for orc in orcs.values():
+            orc.sample_step(host_cores())
         dev.synchronize()
-        a, b = dev.positions(), orc.positions()
-        same = (dev.depths() == orc.depths()) & ((dev.grad_evals() - g_dev0) == (orc.grad_evals() - g_orc0))
-        r = np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-300)
-        rel.append(float(r[same].max()) if same.any() else float("nan"))
-        # the selected position is a leaf of element-wise leapfrog arithmetic (bit-identical whenever the tree is);
-        # its log density is a sum over D and shows the two summation orders
-        la, lb = dev.logp(), orc.logp()
-        rl = np.abs(la - lb) / np.maximum(np.abs(lb), 1e-300)
-        rel_lp.append(float(rl[same].max()) if same.any() else float("nan"))
-        same_tree.append(int(same.sum()))
-    ties = orc.near_ties()
-    worst = float(np.nanmax(rel))
-    return {"chains": Cg, "transitions": T, "order": "reference (sequential sums, libm) vs device",
-            "max_rel_diff_per_transition": rel, "max_rel_diff": worst,
-            "max_rel_diff_logp_per_transition": rel_lp, "max_rel_diff_logp": float(np.nanmax(rel_lp)),
-            "within_1e-10": bool(worst <= 1e-10 and np.nanmax(rel_lp) <= 1e-10),
-            "chains_with_identical_tree_per_transition": same_tree,
-            "tree_mismatches": int(Cg * T - sum(same_tree)),
+        a, la = dev.positions(), dev.logp()
+        for name, orc in orcs.items():
+            b, lb = orc.positions(), orc.logp()
+            same = (dev.depths() == orc.depths()) & ((dev.grad_evals() - g_dev0) == (orc.grad_evals() - g_orc0[name]))
+            r = np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-300)
+            # the selected position is a leaf of element-wise leapfrog arithmetic; its log density is a sum over D
+            # and shows the summation orders
+            rl = np.abs(la - lb) / np.maximum(np.abs(lb), 1e-300)
+            rec[name]["rel"].append(float(r[same].max()) if same.any() else float("nan"))
+            rec[name]["rel_lp"].append(float(rl[same].max()) if same.any() else float("nan"))
+            rec[name]["same"].append(int(same.sum()))
+    out_orders = {}
+    for name, orc in orcs.items():
+        ties = orc.near_ties()
+        r = rec[name]
+        out_orders[name] = {
+            "max_rel_diff_per_transition": r["rel"], "max_rel_diff": float(np.nanmax(r["rel"])),
+            "max_rel_diff_logp": float(np.nanmax(r["rel_lp"])),
+            "chains_with_identical_tree_per_transition": r["same"],
+            "tree_mismatches": int(Cg * T - sum(r["same"])),
             "near_ties_1e-12": {k: {"near": v[0], "decisions": v[1]} for k, v in ties.items()}}
+    worst = max(o["max_rel_diff"] for o in out_orders.values())
+    worst_lp = max(o["max_rel_diff_logp"] for o in out_orders.values())
+    return {"chains": Cg, "transitions": T,
+            "device_arithmetic": "fused multiply-adds" if wa.default_config(**cfg_kwargs).fused_multiply_add else "every product rounded",
+            "reference_side": "libm, every product rounded; summation orders: Eigen 3.4 SSE2 redux (restated) and sequential",
+            "orders": out_orders,
+            "max_rel_diff": worst, "max_rel_diff_logp": worst_lp,
+            "within_1e-10": bool(worst <= 1e-10 and worst_lp <= 1e-10),
+            "tree_mismatches": int(max(o["tree_mismatches"] for o in out_orders.values())),
+            "near_ties_1e-12": out_orders["eigen_sse2"]["near_ties_1e-12"]}
 
 
 def _free_port():

@@ -196,7 +196,8 @@ WALNUTS_HIP_EXPORT int wn_engine_freeze(wn_engine* e, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_sample_step(wn_engine* e, double* draws_dev, int64_t draws_stride,
                                              WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_synchronize(wn_engine* e, WalnutpyError** err);
-/* fails (generic error) if any chain's last transition could not complete on the device (span pool exhausted) */
+/* fails (generic error) if a transition of any chain since the previous check could not complete on the device (span
+ * pool exhausted, host-fed variates exhausted); reading the flag clears it */
 WALNUTS_HIP_EXPORT int wn_engine_check(wn_engine* e, WalnutpyError** err);
 
 /* state -> host buffers */

@@ -47,6 +47,17 @@ struct MathOps {
 
 // ---------------------------------------------------------------------------
 // reductions.  L == 0: s = 0; s += f(0); s += f(1); ...
+// L == WNO_REDUCE_EIGEN_SSE2 (-2): the order of Eigen 3.4's linear-vectorised redux with 2-lane packets -- what
+//   `.sum()` / `.dot()` execute in the reference as its CMake files build it on x86-64 (plain -O3: SSE2, Packet2d;
+//   util.hpp:222, walnuts.hpp:199-200, examples/walnutpie_api.cpp:41).  Eigen is NOT under /root/reference (cloned at
+//   configure time, EIGEN_TAG 3.4.0, CMakeLists.txt:28-41), so this is a restatement of its published algorithm
+//   (Eigen/src/Core/Redux.h, redux_impl<Func, Evaluator, LinearVectorizedTraversal, NoUnrolling>::run): with
+//   P = 2, n2 = n rounded down to a multiple of 2P, n1 = n rounded down to a multiple of P,
+//       fewer than P elements: res = x0; res += x1; ...
+//       p0 = (x0, x1); if n1 > P: p1 = (x2, x3); for i = 2P, 4P, ... < n2: p0 += (x_i, x_i+1), p1 += (x_i+2, x_i+3);
+//       p0 += p1; if n1 > n2: p0 += (x_n2, x_n2+1);
+//       res = p0[0] + p0[1]  (predux<Packet2d>);  res += x_i for i = n1 .. n-1
+//   (the element expression is evaluated per packet with pmul / padd: element-wise IEEE operations, no FMA in SSE2.)
 // L > 0: the device order.  Lane l (0 <= l < L) owns elements
 // (k*L + l)*2 + {0,1}, k = 0,1,...; it adds its elements in increasing index
 // order into a partial that starts at +0.0; each group of 64 lanes (one
@@ -58,7 +69,7 @@ struct Reducer {
   // sum of a(i) * b(i) in the same order; `fused`: every partial is fma(a, b, partial), as the kernels' mad() does
   template <class A, class B>
   double sum_prod(size_t n, A a, B b, bool fused) const {
-    if (!fused) return sum(n, [&](size_t i) { return a(i) * b(i); });
+    if (!fused || L == WNO_REDUCE_EIGEN_SSE2) return sum(n, [&](size_t i) { return a(i) * b(i); });
     if (L <= 0) {
       double s = 0.0;
       for (size_t i = 0; i < n; ++i) s = std::fma(a(i), b(i), s);
@@ -80,6 +91,32 @@ struct Reducer {
   }
   template <class F>
   double sum(size_t n, F f) const {
+    if (L == WNO_REDUCE_EIGEN_SSE2) {
+      constexpr size_t P = 2;
+      if (n == 0) return 0.0;
+      const size_t n2 = (n / (2 * P)) * (2 * P), n1 = (n / P) * P;
+      double res;
+      if (n1 == 0) {
+        res = f(0);
+        for (size_t i = 1; i < n; ++i) res = res + f(i);
+        return res;
+      }
+      double p0[P], p1[P];
+      for (size_t k = 0; k < P; ++k) p0[k] = f(k);
+      if (n1 > P) {
+        for (size_t k = 0; k < P; ++k) p1[k] = f(P + k);
+        for (size_t i = 2 * P; i < n2; i += 2 * P) {
+          for (size_t k = 0; k < P; ++k) p0[k] = p0[k] + f(i + k);
+          for (size_t k = 0; k < P; ++k) p1[k] = p1[k] + f(i + P + k);
+        }
+        for (size_t k = 0; k < P; ++k) p0[k] = p0[k] + p1[k];
+        if (n1 > n2)
+          for (size_t k = 0; k < P; ++k) p0[k] = p0[k] + f(n2 + k);
+      }
+      res = p0[0] + p0[1];
+      for (size_t i = n1; i < n; ++i) res = res + f(i);
+      return res;
+    }
     if (L <= 0) {
       double s = 0.0;
       for (size_t i = 0; i < n; ++i) s += f(i);
@@ -156,7 +193,10 @@ struct Model {
           logp = r.sum_prod(D, [&](size_t i) { return -0.5 * x[i] * x[i]; }, [&](size_t i) { return 1.0 / s2[i]; }, fused);
           for (size_t i = 0; i < D; ++i) g[i] = -x[i] * (1.0 / s2[i]);
         } else {
-          logp = r.sum(D, [&](size_t i) { return -0.5 * x[i] * x[i] / s2[i]; });
+          // the example's own scalar loop (examples.cpp:26-30): left to right whatever Eigen's redux does elsewhere
+          Reducer loop;
+          loop.L = r.L == WNO_REDUCE_EIGEN_SSE2 ? 0 : r.L;
+          logp = loop.sum(D, [&](size_t i) { return -0.5 * x[i] * x[i] / s2[i]; });
           for (size_t i = 0; i < D; ++i) g[i] = -x[i] / s2[i];
         }
         break;
@@ -885,6 +925,26 @@ std::unique_ptr<RandomSource> make_std(Eng* e) {
 }
 }  // namespace
 
+// Sums over chains in the two controllers below.  Reference order: left to right (adapt.hpp:200-206,
+// sampler.hpp:139-142).  Device order (reduce_lanes > 0): runs of 256 consecutive chains left to right, then the run
+// totals left to right -- what the engine's monitor kernels do (wn_elementwise.h: run_partial_sums), the same as left
+// to right up to 256 chains.
+template <class F>
+static double chain_sum(const wno_engine* e, size_t M, F f) {
+  if (e->red.L <= 0) {
+    double s = 0.0;
+    for (size_t m = 0; m < M; ++m) s += f(m);
+    return s;
+  }
+  double total = 0.0;
+  for (size_t lo = 0; lo < M; lo += 256) {
+    double run = 0.0;
+    for (size_t m = lo; m < std::min(M, lo + 256); ++m) run += f(m);
+    total += run;
+  }
+  return total;
+}
+
 extern "C" {
 
 void wno_default_config(wno_config* c) {
@@ -1173,50 +1233,62 @@ int64_t wno_iteration(const wno_engine* e) { return e->iteration; }
 // sampler.hpp:132-145 with util.hpp:401-404 (variance) on the per-chain Welford statistics
 double wno_rhat(const wno_engine* e) {
   const size_t M = e->C;
-  double mean_of_means = 0, mean_of_vars = 0;
-  for (const auto& ch : e->chains) {
-    mean_of_means += ch.lp_mean;
-    mean_of_vars += ch.lp_sample_variance();
-  }
+  double mean_of_means = chain_sum(e, M, [&](size_t m) { return e->chains[m].lp_mean; });
+  double mean_of_vars = chain_sum(e, M, [&](size_t m) { return e->chains[m].lp_sample_variance(); });
   mean_of_means /= static_cast<double>(M);
   mean_of_vars /= static_cast<double>(M);
-  double ss = 0;
-  for (const auto& ch : e->chains) ss += (ch.lp_mean - mean_of_means) * (ch.lp_mean - mean_of_means);
+  const double ss = chain_sum(e, M, [&](size_t m) {
+    return (e->chains[m].lp_mean - mean_of_means) * (e->chains[m].lp_mean - mean_of_means);
+  });
   const double variance_of_means = ss / static_cast<double>(M - 1);
   return std::sqrt(1 + variance_of_means / mean_of_vars);
 }
 
-// adapt.hpp:193-221: max over chains of l2_rel_diff(mass_m, geom_mean_mass) and of the step's relative distance
+// adapt.hpp:193-221: max over chains of l2_rel_diff(mass_m, geom_mean_mass) and of the step's relative distance.
+// exp / log are the mode's (libm, or the device's portable pair); in device order the squared relative differences of
+// one chain are summed as the engine's block does it: 256 strided partials, then a pairwise tree.
 void wno_warmup_spread(wno_engine* e, double* max_rel_step, double* max_rel_mass) {
   e->ensure_adapters();
+  const MathOps& mo = e->mo;
   const size_t M = e->C, D = e->D;
   Vec mean_log_mass(D, 0.0), im(D);
-  double mean_log_step = 0;
   std::vector<Vec> mass(M, Vec(D));
   std::vector<double> log_step(M);
   for (size_t m = 0; m < M; ++m) {
     auto& ch = e->chains[m];
-    log_step[m] = std::log(ch.adam.step_size());  // log_step_size(), adaptive_walnuts.hpp:311
+    log_step[m] = mo.log(ch.adam.step_size());  // log_step_size(), adaptive_walnuts.hpp:311
     ch.est.inv_mass(im.data());
     for (size_t d = 0; d < D; ++d) {
-      const double lm = -std::log(im[d]);  // log_mass(), adaptive_walnuts.hpp:319-323
+      const double lm = -mo.log(im[d]);  // log_mass(), adaptive_walnuts.hpp:319-323
       mean_log_mass[d] += lm;
-      mass[m][d] = std::exp(lm);           // adapt.hpp:141
+      mass[m][d] = mo.exp(lm);           // adapt.hpp:141
     }
-    mean_log_step += log_step[m];
   }
-  mean_log_step /= static_cast<double>(M);
-  for (size_t d = 0; d < D; ++d) mean_log_mass[d] = std::exp(mean_log_mass[d] / static_cast<double>(M));
-  const double gms = std::exp(mean_log_step);
+  const double mean_log_step = chain_sum(e, M, [&](size_t m) { return log_step[m]; }) / static_cast<double>(M);
+  for (size_t d = 0; d < D; ++d) mean_log_mass[d] = mo.exp(mean_log_mass[d] / static_cast<double>(M));
+  const double gms = mo.exp(mean_log_step);
   double rm = 0, rs = 0;
   for (size_t m = 0; m < M; ++m) {
-    double ss = 0;
-    for (size_t d = 0; d < D; ++d) {
+    auto rel_sq = [&](size_t d) {
       const double r = (mass[m][d] - mean_log_mass[d]) / mean_log_mass[d];
-      ss += r * r;
+      return r * r;
+    };
+    double ss = 0;
+    if (e->red.L <= 0) {
+      for (size_t d = 0; d < D; ++d) ss += rel_sq(d);
+    } else {
+      double sh[256];
+      for (size_t t = 0; t < 256; ++t) {
+        double acc = 0.0;
+        for (size_t d = t; d < D; d += 256) acc += rel_sq(d);
+        sh[t] = acc;
+      }
+      for (size_t s = 128; s > 0; s >>= 1)
+        for (size_t t = 0; t < s; ++t) sh[t] += sh[t + s];
+      ss = sh[0];
     }
     rm = std::fmax(rm, std::sqrt(ss));
-    rs = std::fmax(rs, (std::exp(log_step[m]) - gms) / gms);
+    rs = std::fmax(rs, (mo.exp(log_step[m]) - gms) / gms);
   }
   *max_rel_step = rs;
   *max_rel_mass = rm;
@@ -1235,6 +1307,11 @@ double wno_logp_momentum(size_t n, const double* rho, const double* inv_mass, in
   Reducer r;
   r.L = reduce_lanes;
   return logp_momentum(r, n, rho, inv_mass);
+}
+double wno_reduce_sum(size_t n, const double* x, int reduce_lanes) {
+  Reducer r;
+  r.L = reduce_lanes;
+  return r.sum(n, [&](size_t i) { return x[i]; });
 }
 double wno_log_sum_exp(double a, double b, int math_mode) {
   MathOps m;

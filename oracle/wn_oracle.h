@@ -34,6 +34,10 @@ enum { WNO_MODEL_STD_NORMAL = 0, WNO_MODEL_DIAG_NORMAL = 1, WNO_MODEL_FUNNEL = 2
 enum { WNO_MATH_LIBM = 0, WNO_MATH_PORTABLE = 1 };
 enum { WNO_RNG_STD_MT64 = 0, WNO_RNG_STD_MT32 = 1, WNO_RNG_PHILOX = 2 };
 
+/* reduce_lanes = WNO_REDUCE_EIGEN_SSE2: sums in the order of Eigen 3.4's vectorised redux with 2-lane packets (the
+ * reference's default x86-64 build); restated from Eigen's published algorithm, see Reducer in wn_oracle.cpp */
+enum { WNO_REDUCE_EIGEN_SSE2 = -2 };
+
 typedef struct wno_config {
   /* SamplingConfig, reference defaults config.hpp:947-953 */
   int32_t max_trajectory_doublings; /* 5 */
@@ -51,7 +55,7 @@ typedef struct wno_config {
   double step_learn_rate_decay;    /* 0.5 */
   /* how the oracle executes */
   int32_t math_mode;    /* WNO_MATH_* */
-  int32_t reduce_lanes; /* 0: left-to-right sums; L>0: the device order with L lanes */
+  int32_t reduce_lanes; /* 0: left-to-right sums; L>0: the device order with L lanes; WNO_REDUCE_EIGEN_SSE2 */
   int32_t rng_mode;     /* WNO_RNG_* */
   int32_t fma;          /* 1: device arithmetic with fused multiply-adds (wn_config::fused_multiply_add): the
                            transition's leapfrog updates, kinetic and U-turn sums and the models' log-density sums
@@ -136,6 +140,8 @@ size_t wno_get_trace(const wno_engine* e, size_t chain, double* out, size_t max_
 /* ---- function-level entry points (KATs / unit parity) -------------------- */
 double wno_logp_momentum(size_t n, const double* rho, const double* inv_mass, int reduce_lanes);
 double wno_log_sum_exp(double a, double b, int math_mode);
+/* sum of x[0..n) in the order `reduce_lanes` names (0, L > 0, WNO_REDUCE_EIGEN_SSE2) */
+double wno_reduce_sum(size_t n, const double* x, int reduce_lanes);
 int wno_model_logp_grad(int model, int dim, const double* params, const double* x, double* logp,
                         double* grad, int math_mode, int reduce_lanes);
 double wno_leapfrog_error(int model, int dim, const double* params, const double* theta,

@@ -96,6 +96,8 @@ def lib():
     L.wno_get_trace.argtypes = [vp, sz, _dp, sz]
     L.wno_logp_momentum.restype = dbl
     L.wno_logp_momentum.argtypes = [sz, _dp, _dp, i32]
+    L.wno_reduce_sum.restype = dbl
+    L.wno_reduce_sum.argtypes = [sz, _dp, i32]
     L.wno_log_sum_exp.restype = dbl
     L.wno_log_sum_exp.argtypes = [dbl, dbl, i32]
     L.wno_model_logp_grad.argtypes = [i32, i32, _dp, _dp, _dp, _dp, i32, i32]
@@ -290,6 +292,14 @@ class Engine:
 def logp_momentum(rho, inv_mass, reduce_lanes: int = 0) -> float:
     r, m = _f64(rho), _f64(inv_mass)
     return lib().wno_logp_momentum(r.size, _p(r), _p(m), reduce_lanes)
+
+
+REDUCE_EIGEN_SSE2 = -2   # reduce_lanes: Eigen 3.4's vectorised redux order, 2-lane packets (wn_oracle.cpp: Reducer)
+
+
+def reduce_sum(x, reduce_lanes: int = 0) -> float:
+    v = _f64(x).reshape(-1)
+    return lib().wno_reduce_sum(v.size, _p(v), reduce_lanes)
 
 
 def log_sum_exp(a: float, b: float, math_mode: int = MATH_LIBM) -> float:

@@ -139,7 +139,6 @@ using std::fmax;
 // ---- the platform layer's names (walnuts_amd/csrc/wn_gfx950.h) over the emulation --------------
 namespace wn {
 // the emulation pays one OS thread per lane: keep its launches small
-constexpr int kMonitorBlocks = 2;
 constexpr int kSummaryBlock = 64;
 constexpr int kSummaryLagSlabChains = 256;
 constexpr int kSummaryCandidateCap = 8;

@@ -1,14 +1,17 @@
 #!/bin/bash
-# the bench's same-run parity gate (device vs the REFERENCE-ORDER oracle: sequential sums, libm; identical trees
-# required, near-tie audit) widened: 512 chains x 24 transitions for every bench configuration
+# the bench's same-run parity gate (device vs the oracle in the reference's arithmetic -- libm, every product rounded --
+# under both reference-side summation orders: Eigen 3.4's SSE2 redux (restated) and sequential loops; identical trees
+# required, near-tie audit) widened: 512 chains x 24 transitions for every bench configuration.  WIDE_GATE_ARGS adds
+# bench arguments to every line (e.g. "--fma 0" for the device build with every product rounded).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 gate() {
   local tag=$1; shift
-  python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 --gate-chains 512 --gate-transitions 24 "$@" 2>/dev/null | python3 -c "
+  python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 --gate-chains 512 --gate-transitions 24 $WIDE_GATE_ARGS "$@" 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); g=d['parity_gate']
-print('$tag', 'chains', g['chains'], 'transitions', g['transitions'], 'tree_mismatches', g['tree_mismatches'], 'max_rel_diff_positions', g['max_rel_diff'], 'max_rel_diff_logp %.3e' % g['max_rel_diff_logp'], 'within_1e-10', g['within_1e-10'], 'near_ties', {k: v['near'] for k, v in g['near_ties_1e-12'].items()}, 'decisions', {k: v['decisions'] for k, v in g['near_ties_1e-12'].items()})"
+for name, o in g['orders'].items():
+    print('$tag', '%-10s' % name, 'chains', g['chains'], 'transitions', g['transitions'], 'tree_mismatches', o['tree_mismatches'], 'max_rel_diff_positions %.3e' % o['max_rel_diff'], 'max_rel_diff_logp %.3e' % o['max_rel_diff_logp'], 'near_ties', {k: v['near'] for k, v in o['near_ties_1e-12'].items()}, 'decisions', {k: v['decisions'] for k, v in o['near_ties_1e-12'].items()})"
 }
 gate headline
 gate cfg2 --model ill_normal --chains 4096 --dim 1024 --adapt-iters 300

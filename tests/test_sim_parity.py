@@ -34,15 +34,6 @@ def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry, fma):
 
 
 @pytest.mark.timeout(600)
-def test_emulated_engine_inline_momentum_generator(sim, oracle, monkeypatch):
-    # WALNUTS_AMD_PREGEN=0: the momentum's normals generated inside the transition kernel (the default is the
-    # generator kernel one transition ahead, wn_pregen.h) -- the same bits either way
-    monkeypatch.setenv("WALNUTS_AMD_PREGEN", "0")
-    parity.run_case("std_normal", 10, 2, warmup=3, sampling=3, lib_path=sim)
-    parity.run_case("diag_normal", 130, 2, warmup=2, sampling=2, lib_path=sim, geometry=(1, 4))
-
-
-@pytest.mark.timeout(600)
 def test_emulated_engine_lds_pool_and_arena_paths(sim, oracle):
     # same chains with the span pool in LDS, split over LDS / HBM arena, in the arena only: identical results
     outs = []
@@ -203,9 +194,10 @@ def test_emulated_sample_device_output_buffer_check(sim):
 
 
 @pytest.mark.timeout(600)
-def test_emulated_device_errors_are_sticky(sim, oracle):
-    # host-fed uniforms that run out inside a transition: reported by wn_engine_check, and NOT forgotten when a
-    # later transition of the same engine is clean (the per-transition report, depth -1, is overwritten)
+def test_emulated_device_errors_are_reported_once_per_check(sim, oracle):
+    # host-fed uniforms that run out inside a transition: reported by wn_engine_check even when a later transition of
+    # the same engine is clean (the per-transition report, depth -1, is overwritten) -- and cleared by that check, so a
+    # caller who then supplies enough variates can carry on
     D, Cn = 6, 2
     dev = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, Cn, wa.default_config(sim), lib_path=sim)
     rng = np.random.default_rng(2)
@@ -221,8 +213,12 @@ def test_emulated_device_errors_are_sticky(sim, oracle):
         dev.check()
     dev.sample_step()                             # counter-based stream again: a clean transition
     assert np.all(dev.depths() >= 1)
+    dev.check()                                   # the error was reported (and cleared) by the check above
+    dev.set_variates(rng.normal(size=(Cn, D)), rng.uniform(size=(Cn, 1)))
+    dev.sample_step()
+    dev.sample_step()                             # the failure is one transition back ...
     with pytest.raises(RuntimeError, match="host-fed uniforms"):
-        dev.check()
+        dev.check()                               # ... and still reported
 
 
 @pytest.mark.timeout(900)

@@ -696,9 +696,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
 #endif
     }
     WN_MARK(kPhLoadsIssued);
-    const int rng_mode = Q.rng_mode;
-    const bool fed = rng_mode == kRngBuffer;  // host-fed rows are zero-padded already
-    if (rng_mode != kRngPhilox) {
+    const bool fed = Q.rng_mode == kRngBuffer;
+    if (fed) {
       vload_stream(Q.z_buf + row, rh[0]);
     } else {
       const uint64_t seed = Q.seed;

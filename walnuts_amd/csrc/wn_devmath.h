@@ -8,7 +8,10 @@
 // with -ffp-contract=off, which makes every result reproducible bit for bit on
 // the host: that is what lets tests/ compare whole trajectories exactly.
 //
-// exp / log: table-driven schemes written for short dependency chains (below).
+// exp / log: table-driven schemes written for short dependency chains (below).  Their polynomial steps -- and only
+// theirs: these are this engine's own functions, not the reference's element-wise arithmetic -- are explicit fused
+// multiply-adds (wnd::fmad = one v_fma_f64, or libm's correctly rounded fma() on the host): half the instructions and
+// half the depth of the mul-then-add form, identical bits on both sides.
 // sin/cos kernels: Sun fdlibm 5.3 polynomial schemes and coefficients.
 // Generator: Philox4x32-10 (Salmon et al., SC'11).
 #pragma once
@@ -47,6 +50,9 @@ WND_HD double as_f64(uint64_t u) {
 #endif
 }
 
+// a * b + c with one rounding (IEEE fusedMultiplyAdd on the device and on the host alike)
+WND_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 WND_HD double two_to(int k) { return as_f64(static_cast<uint64_t>(k + 1023) << 52); }
 
 // ---------------------------------------------------------------------------
@@ -74,17 +80,17 @@ WND_HD double dexp(double x, const Tab& tab) {
   constexpr double kStepLo = 8.66550983900947049e-11;
   constexpr double kOver = 7.09782712893383973096e+02, kUnder = -7.45133219101941108420e+02;
   const double xc = (x != x) ? 0.0 : (x > kOver ? kOver : (x < kUnder ? kUnder : x));
-  const double kf = __builtin_floor(xc * kInvStep + 0.5);
+  const double kf = __builtin_floor(fmad(xc, kInvStep, 0.5));
   const int k = static_cast<int>(kf);
-  const double r = (xc - kf * kStepHi) - kf * kStepLo;   // |r| <= ln2/128
+  const double r = fmad(-kf, kStepLo, fmad(-kf, kStepHi, xc));   // |r| <= ln2/128 (kf * kStepHi is exact)
   const double t = tab.exp2(k & 63);
   const int e = k >> 6;
   const double r2 = r * r;
   // exp(r) - 1 = r + r^2/2 + r^3/6 + r^4/24 + r^5/120   (r^6/720 < 4e-17)
-  const double lo = 0.5 + r * 1.66666666666666657e-01;
-  const double hi = 4.16666666666666644e-02 + r * 8.33333333333333322e-03;
-  const double p = r + r2 * (lo + r2 * hi);
-  double y = t + t * p;
+  const double lo = fmad(r, 1.66666666666666657e-01, 0.5);
+  const double hi = fmad(r, 8.33333333333333322e-03, 4.16666666666666644e-02);
+  const double p = fmad(r2, fmad(r2, hi, lo), r);
+  double y = fmad(t, p, t);
   const int ea = e / 2;
   const int eb = e - ea;
   if (e != 0) y = (y * two_to(ea)) * two_to(eb);
@@ -108,20 +114,20 @@ WND_HD double dlog(double x, const Tab& tab) {
   k += upper ? 1 : 0;
   const double s = as_f64(frac | (static_cast<uint64_t>(upper ? 1022 : 1023) << 52));
   // nearest multiple of 1/64: c = i/64, 48 <= i <= 96; s - c is exact, |s - c| <= 1/128
-  const int i = static_cast<int>(s * 64.0 + 0.5);
+  const int i = static_cast<int>(fmad(s, 64.0, 0.5));
   const double c = static_cast<double>(i) * 0.015625;
   const double u = (s - c) * tab.rcp(i - 48);
   const double lc = tab.logc(i - 48);
   // log(1 + u) = u - u^2 (1/2 - u/3 + u^2/4 - u^3/5 + u^4/6 - u^5/7 + u^6/8),  |u| < 0.0105
   const double q = u * u;
-  const double a0 = 0.5 - u * 3.33333333333333315e-01;
-  const double a1 = 0.25 - u * 2.00000000000000011e-01;
-  const double a2 = 1.66666666666666657e-01 - u * 1.42857142857142849e-01;
+  const double a0 = fmad(-u, 3.33333333333333315e-01, 0.5);
+  const double a1 = fmad(-u, 2.00000000000000011e-01, 0.25);
+  const double a2 = fmad(-u, 1.42857142857142849e-01, 1.66666666666666657e-01);
   const double q2 = q * q;
-  const double pl = (a0 + q * a1) + q2 * (a2 + q * 0.125);
-  const double l1 = u - q * pl;
+  const double pl = fmad(q2, fmad(q, 0.125, a2), fmad(q, a1, a0));
+  const double l1 = fmad(-q, pl, u);
   const double dk = static_cast<double>(k);
-  double y = (dk * kLn2Hi + lc) + (l1 + dk * kLn2Lo);
+  double y = fmad(dk, kLn2Hi, lc) + fmad(dk, kLn2Lo, l1);
   if (x == __builtin_inf()) y = x;
   if (x == 0.0) y = -__builtin_inf();
   if (x < 0.0) y = __builtin_nan("");
@@ -141,19 +147,19 @@ WND_HD double dlog_normal(double x, const Tab& tab) {
   const bool upper = frac >= 0x0008000000000000ULL;
   k += upper ? 1 : 0;
   const double s = as_f64(frac | (static_cast<uint64_t>(upper ? 1022 : 1023) << 52));
-  const int i = static_cast<int>(s * 64.0 + 0.5);
+  const int i = static_cast<int>(fmad(s, 64.0, 0.5));
   const double c = static_cast<double>(i) * 0.015625;
   const double u = (s - c) * tab.rcp(i - 48);
   const double lc = tab.logc(i - 48);
   const double q = u * u;
-  const double a0 = 0.5 - u * 3.33333333333333315e-01;
-  const double a1 = 0.25 - u * 2.00000000000000011e-01;
-  const double a2 = 1.66666666666666657e-01 - u * 1.42857142857142849e-01;
+  const double a0 = fmad(-u, 3.33333333333333315e-01, 0.5);
+  const double a1 = fmad(-u, 2.00000000000000011e-01, 0.25);
+  const double a2 = fmad(-u, 1.42857142857142849e-01, 1.66666666666666657e-01);
   const double q2 = q * q;
-  const double pl = (a0 + q * a1) + q2 * (a2 + q * 0.125);
-  const double l1 = u - q * pl;
+  const double pl = fmad(q2, fmad(q, 0.125, a2), fmad(q, a1, a0));
+  const double l1 = fmad(-q, pl, u);
   const double dk = static_cast<double>(k);
-  return (dk * kLn2Hi + lc) + (l1 + dk * kLn2Lo);
+  return fmad(dk, kLn2Hi, lc) + fmad(dk, kLn2Lo, l1);
 }
 
 // log(1 + e^d) for d <= 0: the core of log_sum_exp (util.hpp:174-183), which the tree evaluates at every merge on a
@@ -168,33 +174,33 @@ WND_HD double dlog_normal(double x, const Tab& tab) {
 template <bool Uniform>
 WND_HD double dlog1pexp(double d) {
   const double dc = (d != d) ? 0.0 : (d < -48.0 ? -48.0 : d);
-  const double kf = __builtin_floor(dc * 16.0 + 0.5);
+  const double kf = __builtin_floor(fmad(dc, 16.0, 0.5));
   int i = -static_cast<int>(kf);  // 0..768
 #if defined(__HIP_DEVICE_COMPILE__)
   if (Uniform) i = __builtin_amdgcn_readfirstlane(i);
 #endif
   const double F = as_f64(wn_tab_l1pe_bits[2 * i]);
   const double S = as_f64(wn_tab_l1pe_bits[2 * i + 1]);
-  const double r = dc - kf * 0.0625;  // exact
+  const double r = fmad(-kf, 0.0625, dc);  // exact
   // expm1(r) = r + r^2/2 + ... + r^8/8!
   const double r2 = r * r;
   const double r4 = r2 * r2;
-  const double p1 = 0.5 + r * 1.66666666666666657e-01;
-  const double p2 = 4.16666666666666644e-02 + r * 8.33333333333333322e-03;
-  const double p3 = 1.38888888888888894e-03 + r * 1.98412698412698413e-04;
-  const double q = (p2 + r2 * p3) + r4 * 2.48015873015873016e-05;
-  const double e1 = r + (r2 * p1 + r4 * q);
+  const double p1 = fmad(r, 1.66666666666666657e-01, 0.5);
+  const double p2 = fmad(r, 8.33333333333333322e-03, 4.16666666666666644e-02);
+  const double p3 = fmad(r, 1.98412698412698413e-04, 1.38888888888888894e-03);
+  const double q = fmad(r4, 2.48015873015873016e-05, fmad(r2, p3, p2));
+  const double e1 = r + fmad(r2, p1, r4 * q);
   const double t = S * e1;
   // log1p(t) = t - t^2/2 + t^3/3 - ... - t^10/10
   const double t2 = t * t;
   const double t4 = t2 * t2;
-  const double b0 = -0.5 + t * 3.33333333333333315e-01;
-  const double b1 = -0.25 + t * 2.00000000000000011e-01;
-  const double b2 = -1.66666666666666657e-01 + t * 1.42857142857142849e-01;
-  const double b3 = -0.125 + t * 1.11111111111111105e-01;
-  const double inner = (b2 + t2 * b3) + t4 * -0.1;
-  const double outer = (b0 + t2 * b1) + t4 * inner;
-  const double l = t + t2 * outer;
+  const double b0 = fmad(t, 3.33333333333333315e-01, -0.5);
+  const double b1 = fmad(t, 2.00000000000000011e-01, -0.25);
+  const double b2 = fmad(t, 1.42857142857142849e-01, -1.66666666666666657e-01);
+  const double b3 = fmad(t, 1.11111111111111105e-01, -0.125);
+  const double inner = fmad(t4, -0.1, fmad(t2, b3, b2));
+  const double outer = fmad(t4, inner, fmad(t2, b1, b0));
+  const double l = fmad(t2, outer, t);
   double y = F + l;
   if (d != d) y = d;
   return y;
@@ -227,25 +233,25 @@ WND_HD double dpow_pos(double x, double y, const Tab& tab) {
 // sin(pi a), cos(pi a), a in [0, 2)
 WND_HD void dsincospi(double a, double& sn, double& cs) {
   constexpr double kPi = 3.14159265358979311600e+00;
-  const double qf = __builtin_floor(a * 2.0 + 0.5);
+  const double qf = __builtin_floor(fmad(a, 2.0, 0.5));
   const int q = static_cast<int>(qf);
-  const double r = a - qf * 0.5;
+  const double r = fmad(-qf, 0.5, a);  // exact
   const double x = kPi * r;
   const double z = x * x;
   double ps = 1.58969099521155010221e-10;
-  ps = -2.50507602534068634195e-08 + z * ps;
-  ps = 2.75573137070700676789e-06 + z * ps;
-  ps = -1.98412698298579493134e-04 + z * ps;
-  ps = 8.33333333332248946124e-03 + z * ps;
-  ps = -1.66666666666666324348e-01 + z * ps;
-  const double s = x + x * (z * ps);
+  ps = fmad(z, ps, -2.50507602534068634195e-08);
+  ps = fmad(z, ps, 2.75573137070700676789e-06);
+  ps = fmad(z, ps, -1.98412698298579493134e-04);
+  ps = fmad(z, ps, 8.33333333332248946124e-03);
+  ps = fmad(z, ps, -1.66666666666666324348e-01);
+  const double s = fmad(x, z * ps, x);
   double pc = -1.13596475577881948265e-11;
-  pc = 2.08757232129817482790e-09 + z * pc;
-  pc = -2.75573143513906633035e-07 + z * pc;
-  pc = 2.48015872894767294178e-05 + z * pc;
-  pc = -1.38888888888741095749e-03 + z * pc;
-  pc = 4.16666666666666019037e-02 + z * pc;
-  const double c = (1.0 - 0.5 * z) + (z * z) * pc;
+  pc = fmad(z, pc, 2.08757232129817482790e-09);
+  pc = fmad(z, pc, -2.75573143513906633035e-07);
+  pc = fmad(z, pc, 2.48015872894767294178e-05);
+  pc = fmad(z, pc, -1.38888888888741095749e-03);
+  pc = fmad(z, pc, 4.16666666666666019037e-02);
+  const double c = fmad(z * z, pc, fmad(-0.5, z, 1.0));
   // quadrant m = q mod 4: (sin, cos) = (s, c), (c, -s), (-s, -c), (-c, s): one swap, then sign flips on the high words
   const uint64_t m = static_cast<uint64_t>(q & 3);
   const bool swap = (m & 1) != 0;

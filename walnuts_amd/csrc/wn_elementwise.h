@@ -69,27 +69,23 @@ static __global__ void inv_mass_estimate_kernel(int C, int Dp, const double* dra
 }
 
 // ---- cross-chain monitors (the reference's controller loops) --------------------------------------
-// Deterministic two-stage sums: stage 1 gives every block a contiguous slice and a fixed tree inside the
-// block, stage 2 (one block) adds the block partials left to right.
-// (kMonitorBlocks, the number of stage-1 blocks, is a constant of the platform layer: wn_hip.h)
+// Deterministic two-stage sums over chains, independent of the launch geometry: stage 1 adds every RUN of kMonitorRun
+// consecutive chains left to right (one thread per run), stage 2 (one thread) adds the run totals left to right.  Up
+// to kMonitorRun chains that IS the left-to-right sum; beyond, the test suite's CPU restatement groups the same way (its
+// chain_sum), so the statistics are compared bit for bit.
+constexpr int kMonitorRun = 256;
+inline int monitor_runs(int n) { return (n + kMonitorRun - 1) / kMonitorRun; }
 
 template <int K, class F>
-static __device__ void block_partial_sums(int n, F f, double* partial /*[gridDim][K]*/) {
-  __shared__ double sh[256][K];
-  double acc[K];
-  for (int k = 0; k < K; ++k) acc[k] = 0.0;
-  const int per = (n + gridDim.x - 1) / gridDim.x;
-  const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) f(i, acc);
-  for (int k = 0; k < K; ++k) sh[threadIdx.x][k] = acc[k];
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (static_cast<int>(threadIdx.x) < s)
-      for (int k = 0; k < K; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + s][k];
-    __syncthreads();
+static __device__ void run_partial_sums(int n, F f, double* partial /*[runs][K]*/) {
+  const int runs = (n + kMonitorRun - 1) / kMonitorRun;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < runs; r += gridDim.x * blockDim.x) {
+    double acc[K];
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    const int lo = r * kMonitorRun, hi = lo + kMonitorRun < n ? lo + kMonitorRun : n;
+    for (int i = lo; i < hi; ++i) f(i, acc);
+    for (int k = 0; k < K; ++k) partial[r * K + k] = acc[k];
   }
-  if (threadIdx.x == 0)
-    for (int k = 0; k < K; ++k) partial[blockIdx.x * K + k] = sh[0][k];
 }
 template <int K>
 static __global__ void finish_sums_kernel(const double* partial, int blocks, double* out) {
@@ -103,21 +99,21 @@ static __global__ void finish_sums_kernel(const double* partial, int blocks, dou
 }
 // sampling monitor, sampler.hpp:132-145: sums of the per-chain lp means and sample variances
 static __global__ void lp_sums_kernel(int C, const double* lp_stats, double* partial) {
-  block_partial_sums<2>(C, [&](int c, double* acc) {
+  run_partial_sums<2>(C, [&](int c, double* acc) {
     const double n = lp_stats[3 * c], mean = lp_stats[3 * c + 1], m2 = lp_stats[3 * c + 2];
     acc[0] += mean;
     acc[1] += n > 1 ? m2 / (n - 1) : __builtin_nan("");  // WelfordAccumulator::sample_variance
   }, partial);
 }
 static __global__ void lp_sqdev_kernel(int C, const double* lp_stats, double mu, double* partial) {
-  block_partial_sums<1>(C, [&](int c, double* acc) {
+  run_partial_sums<1>(C, [&](int c, double* acc) {
     const double d = lp_stats[3 * c + 1] - mu;
     acc[0] += d * d;
   }, partial);
 }
 // warmup monitor, adapt.hpp:193-221.  log step per chain from Adam's theta; log mass = -log(inv_mass).
 static __global__ void log_step_sum_kernel(int C, const double* adam, double* partial) {
-  block_partial_sums<1>(C, [&](int c, double* acc) { acc[0] += wnd::dlog(wnd::dexp(adam[6 * c])); }, partial);
+  run_partial_sums<1>(C, [&](int c, double* acc) { acc[0] += wnd::dlog(wnd::dexp(adam[6 * c])); }, partial);
 }
 // column sums over chains of log mass: thread per column, chains in order (coalesced rows)
 static __global__ void log_mass_colsum_kernel(int C, int D, int Dp, const double* draw_ssd, const double* score_ssd,

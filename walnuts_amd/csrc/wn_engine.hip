@@ -19,7 +19,6 @@
 #include "wn_init.h"
 #include "wn_launch.h"
 #include "wn_traj.h"
-#include "wn_pregen.h"
 
 #include "wn_host.h"
 
@@ -69,20 +68,6 @@ struct wn_engine {
   int u_stride = 0;
   std::unique_ptr<ReferenceStreams> ref_streams;
 
-  // The momentum's normals one transition ahead (wn_pregen.h): two [C][Dp] planes, a second stream, and per plane the
-  // key the normals in it were generated for.  `gen_done[b]` orders the transition kernel after the generator that
-  // filled plane b, `read_done[b]` orders the next generator after the transition kernel that read it.
-  struct Pregen {
-    bool enabled = false;
-    DevBuf<double> z[2];
-    hipStream_t stream = nullptr;
-    hipEvent_t gen_done[2] = {nullptr, nullptr}, read_done[2] = {nullptr, nullptr};
-    bool gen_recorded[2] = {false, false}, read_recorded[2] = {false, false};
-    bool valid[2] = {false, false};
-    uint64_t seed[2] = {0, 0};
-    uint32_t chain_offset[2] = {0, 0}, transition[2] = {0, 0};
-  } pregen;
-
   // HIP event pairs around the transition launches: a fixed ring (the last kEventRing launches since the last
   // timing reset can be read back), created once
   static constexpr size_t kEventRing = 1024;
@@ -95,51 +80,7 @@ struct wn_engine {
       (void)hipEventDestroy(ev.first);
       (void)hipEventDestroy(ev.second);
     }
-    if (pregen.stream) {
-      (void)hipStreamSynchronize(pregen.stream);
-      (void)hipStreamDestroy(pregen.stream);
-    }
-    for (int b = 0; b < 2; ++b) {
-      if (pregen.gen_done[b]) (void)hipEventDestroy(pregen.gen_done[b]);
-      if (pregen.read_done[b]) (void)hipEventDestroy(pregen.read_done[b]);
-    }
     if (stream && own_stream) (void)hipStreamDestroy(stream);
-  }
-
-  void launch_pregen(int b, uint32_t tr, hipStream_t on) {
-#if defined(WN_PROBE_STALE_PREGEN)  // tests/gpu_probes only: what the transition kernel costs with no generator beside it
-    if (pregen.valid[b]) { pregen.seed[b] = seed; pregen.chain_offset[b] = chain_offset; pregen.transition[b] = tr; return; }
-#endif
-    const long long n = static_cast<long long>(C) * (Dp / 2);
-    const int blocks = static_cast<int>(std::min<long long>((n + wn::kPregenBlock - 1) / wn::kPregenBlock, 1 << 16));
-    hipLaunchKernelGGL(wn::momentum_pregen_kernel, dim3(blocks), dim3(wn::kPregenBlock), 0, on, static_cast<int>(C), Dp,
-                       seed, chain_offset, tr, pregen.z[b].p);
-    HIP_OK(hipGetLastError());
-    pregen.valid[b] = true;
-    pregen.seed[b] = seed;
-    pregen.chain_offset[b] = chain_offset;
-    pregen.transition[b] = tr;
-  }
-  // plane holding this transition's normals, generated now (in order, on the main stream) unless the generator that
-  // ran beside the previous transition already made them
-  const double* pregen_acquire() {
-    const int b = static_cast<int>(transition & 1u);
-    if (pregen.gen_recorded[b]) HIP_OK(hipStreamWaitEvent(stream, pregen.gen_done[b], 0));
-    if (!(pregen.valid[b] && pregen.seed[b] == seed && pregen.chain_offset[b] == chain_offset &&
-          pregen.transition[b] == transition))
-      launch_pregen(b, transition, stream);
-    return pregen.z[b].p;
-  }
-  // after the transition kernel of `transition` has been enqueued: its plane may be rewritten once it is done, and the
-  // other plane -- last read by the previous transition -- gets the NEXT transition's normals on the second stream
-  void pregen_ahead() {
-    const int b = static_cast<int>(transition & 1u), nb = b ^ 1;
-    HIP_OK(hipEventRecord(pregen.read_done[b], stream));
-    pregen.read_recorded[b] = true;
-    if (pregen.read_recorded[nb]) HIP_OK(hipStreamWaitEvent(pregen.stream, pregen.read_done[nb], 0));
-    launch_pregen(nb, transition + 1u, pregen.stream);
-    HIP_OK(hipEventRecord(pregen.gen_done[nb], pregen.stream));
-    pregen.gen_recorded[nb] = true;
   }
 
   std::pair<hipEvent_t, hipEvent_t>& next_events() {
@@ -185,12 +126,14 @@ struct wn_engine {
     hipLaunchKernelGGL(wn::fill_kernel, dim3(blocks), dim3(256), 0, stream, b.p, static_cast<long long>(b.n), v);
     HIP_OK(hipGetLastError());
   }
-  // throws if ANY transition of any chain since the engine was created reported a device-side error: the kernels
-  // OR their error bits into one word that later transitions never clear
+  // throws if any transition of any chain SINCE THE PREVIOUS CHECK reported a device-side error: the kernels OR their
+  // error bits into one word, which is read and cleared here (a caller that supplied too few variates, or hit a pool
+  // limit, can correct that and carry on; the draws of the failed transitions are not valid)
   void check_transitions() {
     use_device();
     uint32_t flags = 0;
     HIP_OK(hipMemcpyAsync(&flags, error_flags.p, sizeof(flags), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemsetAsync(error_flags.p, 0, sizeof(uint32_t), stream));
     HIP_OK(hipStreamSynchronize(stream));
     if (flags & wn::kErrPoolExhausted)
       throw std::runtime_error("a chain exhausted the span pool: its draws are not valid (lower max_trajectory_doublings)");
@@ -252,7 +195,7 @@ struct wn_engine {
     P.seed = seed;
     P.chain_offset = chain_offset;
     P.transition = transition;
-    P.rng_mode = variates_pending ? wn::kRngBuffer : wn::kRngPhilox;  // (step() switches to kRngPregen)
+    P.rng_mode = variates_pending ? wn::kRngBuffer : wn::kRngPhilox;
     P.u_stride = u_stride;
     P.z_buf = z_buf.p;
     P.u_buf = u_buf.p;
@@ -273,18 +216,12 @@ struct wn_engine {
     use_device();
     if (ref_streams) feed_reference_streams();
     wn::Params P = make_params(warm, draws_dev, draws_stride);
-    const bool ahead = pregen.enabled && !variates_pending;
-    if (ahead) {
-      P.rng_mode = wn::kRngPregen;
-      P.z_buf = pregen_acquire();
-    }
     HIP_OK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), stream));
     auto& ev = next_events();
     HIP_OK(hipEventRecord(ev.first, stream));
     wn::launch_transition(model, geo, grid, smem, stream, P);
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(ev.second, stream));
-    if (ahead) pregen_ahead();
     variates_pending = false;
     ++transition;
     ++iteration;
@@ -337,6 +274,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
                   const wn_config& cfg) {
   if (num_params < 1) throw std::invalid_argument("num_params must be positive");
   if (num_chains < 1) throw std::invalid_argument("num_chains must be positive");
+  if (!wn::registry_error().empty()) throw std::invalid_argument(wn::registry_error());
   const wn::ModelOps& ops = wn::model_ops(model);  // throws for an id no model registered
   if (cfg.max_trajectory_doublings < 1) throw std::invalid_argument("max_nuts_depth must be positive");
   if (cfg.max_trajectory_doublings > wn::kMaxLevels + 1)
@@ -400,7 +338,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.error_flags.alloc(1);
   HIP_OK(hipMemsetAsync(e.error_flags.p, 0, sizeof(uint32_t), e.stream));
   e.lp_stats.alloc(3 * num_chains);
-  e.mon_partial.alloc(2 * wn::kMonitorBlocks);
+  e.mon_partial.alloc(2 * static_cast<size_t>(wn::monitor_runs(static_cast<int>(num_chains))));
   e.mon_out.alloc(4);
   e.mon_colsum.alloc(e.Dp);
   e.mon_rel_mass.alloc(num_chains);
@@ -431,19 +369,6 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
     HIP_OK(hipStreamSynchronize(e.stream));
   }
   wn::prepare_kernels(model, e.geo, e.smem);
-
-  // momentum normals one transition ahead: the register kernels only (the streaming kernels are HBM-bound: the
-  // generator's arithmetic is free there and a plane of normals is not); WALNUTS_AMD_PREGEN=0 switches it off
-  const char* pg = std::getenv("WALNUTS_AMD_PREGEN");
-  e.pregen.enabled = !e.geo.mem && !(pg != nullptr && pg[0] == '0');
-  if (e.pregen.enabled) {
-    HIP_OK(hipStreamCreateWithFlags(&e.pregen.stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
-      e.pregen.z[b].alloc(plane);
-      HIP_OK(hipEventCreateWithFlags(&e.pregen.gen_done[b], hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&e.pregen.read_done[b], hipEventDisableTiming));
-    }
-  }
 }
 
 void run_init(wn_engine& e, bool pos, bool masses, bool step, double scale, double smoothing, uint64_t pos_seed,
@@ -686,7 +611,6 @@ int wn_engine_synchronize(wn_engine* e, WalnutpyError** err) {
   return guarded(err, [&] {
     e->use_device();
     HIP_OK(hipStreamSynchronize(e->stream));
-    if (e->pregen.stream) HIP_OK(hipStreamSynchronize(e->pregen.stream));
   });
 }
 int wn_engine_check(wn_engine* e, WalnutpyError** err) {
@@ -791,10 +715,10 @@ int wn_engine_lp_sums(wn_engine* e, double* out /*[3]: sum of means, sum of samp
   return guarded(err, [&] {
     e->use_device();
     const int C = static_cast<int>(e->C);
-    hipLaunchKernelGGL(wn::lp_sums_kernel, dim3(wn::kMonitorBlocks), dim3(256), 0, e->stream, C, e->lp_stats.p,
+    const int runs = wn::monitor_runs(C);
+    hipLaunchKernelGGL(wn::lp_sums_kernel, dim3((runs + 63) / 64), dim3(64), 0, e->stream, C, e->lp_stats.p,
                        e->mon_partial.p);
-    hipLaunchKernelGGL(wn::finish_sums_kernel<2>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p,
-                       wn::kMonitorBlocks, e->mon_out.p);
+    hipLaunchKernelGGL(wn::finish_sums_kernel<2>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p, runs, e->mon_out.p);
     HIP_OK(hipGetLastError());
     e->download(e->mon_out, out, 2);
     out[2] = static_cast<double>(C);
@@ -803,10 +727,10 @@ int wn_engine_lp_sums(wn_engine* e, double* out /*[3]: sum of means, sum of samp
 int wn_engine_lp_sq_dev(wn_engine* e, double mean_of_means, double* out, WalnutpyError** err) {
   return guarded(err, [&] {
     e->use_device();
-    hipLaunchKernelGGL(wn::lp_sqdev_kernel, dim3(wn::kMonitorBlocks), dim3(256), 0, e->stream,
+    const int runs = wn::monitor_runs(static_cast<int>(e->C));
+    hipLaunchKernelGGL(wn::lp_sqdev_kernel, dim3((runs + 63) / 64), dim3(64), 0, e->stream,
                        static_cast<int>(e->C), e->lp_stats.p, mean_of_means, e->mon_partial.p);
-    hipLaunchKernelGGL(wn::finish_sums_kernel<1>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p,
-                       wn::kMonitorBlocks, e->mon_out.p);
+    hipLaunchKernelGGL(wn::finish_sums_kernel<1>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p, runs, e->mon_out.p);
     HIP_OK(hipGetLastError());
     e->download(e->mon_out, out, 1);
   });
@@ -834,10 +758,10 @@ int wn_engine_warmup_sums(wn_engine* e, double* sum_log_step, double* colsum_log
     e->ensure_adapters();
     e->use_device();
     const int C = static_cast<int>(e->C);
-    hipLaunchKernelGGL(wn::log_step_sum_kernel, dim3(wn::kMonitorBlocks), dim3(256), 0, e->stream, C, e->adam.p,
+    const int runs = wn::monitor_runs(C);
+    hipLaunchKernelGGL(wn::log_step_sum_kernel, dim3((runs + 63) / 64), dim3(64), 0, e->stream, C, e->adam.p,
                        e->mon_partial.p);
-    hipLaunchKernelGGL(wn::finish_sums_kernel<1>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p,
-                       wn::kMonitorBlocks, e->mon_out.p);
+    hipLaunchKernelGGL(wn::finish_sums_kernel<1>, dim3(1), dim3(64), 0, e->stream, e->mon_partial.p, runs, e->mon_out.p);
     hipLaunchKernelGGL(wn::log_mass_colsum_kernel, dim3((e->D + 255) / 256), dim3(256), 0, e->stream, C, e->D, e->Dp,
                        e->draw_ssd.p, e->score_ssd.p, e->est_weight.p, e->mon_colsum.p);
     HIP_OK(hipGetLastError());

@@ -19,7 +19,6 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 namespace wn {
 
 // launch sizes of the element-wise / summary kernels
-constexpr int kMonitorBlocks = 256;
 constexpr int kSummaryBlock = 256;
 constexpr int kSummaryLagSlabChains = 8192;
 constexpr int kSummaryCandidateCap = 2048;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <stdexcept>
+#include <string>
 
 #include "wn_params.h"
 
@@ -151,9 +152,24 @@ inline const ModelOps** model_table() {
   static const ModelOps* table[kMaxModels] = {};
   return table;
 }
+// Registration runs in static initialisers (library load): nothing may throw there -- an exception would end the
+// process in std::terminate inside dlopen with no usable message.  A bad WN_MODEL_ID of an out-of-tree model (out of
+// range, or taken: the first entry stays) is recorded instead and reported by wn_engine_create as a config error.
+inline std::string& registry_error() {
+  static std::string msg;
+  return msg;
+}
 inline bool register_model(const ModelOps* ops) {
-  if (ops->id < 0 || ops->id >= kMaxModels) throw std::invalid_argument("device model id out of range");
-  if (model_table()[ops->id] != nullptr) throw std::invalid_argument("device model id registered twice");
+  if (ops->id < 0 || ops->id >= kMaxModels) {
+    registry_error() = std::string("device model '") + ops->name + "': WN_MODEL_ID " + std::to_string(ops->id) +
+                       " is out of range (0 <= id < " + std::to_string(kMaxModels) + ")";
+    return false;
+  }
+  if (model_table()[ops->id] != nullptr) {
+    registry_error() = std::string("device model '") + ops->name + "': WN_MODEL_ID " + std::to_string(ops->id) +
+                       " is already taken by '" + model_table()[ops->id]->name + "'";
+    return false;
+  }
   model_table()[ops->id] = ops;
   return true;
 }

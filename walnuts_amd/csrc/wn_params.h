@@ -18,10 +18,7 @@ constexpr int kMetaDoubles = 128;
 #endif
 
 enum ModelKind : int32_t { kStdNormal = 0, kDiagNormal = 1, kFunnel = 2 };
-// kRngPhilox: the kernel generates every variate inline.  kRngBuffer: normals and uniforms are host-fed (parity runs on
-// the reference's own streams).  kRngPregen: the SAME Philox normals, generated one transition ahead by
-// momentum_pregen_kernel (wn_pregen.h) on a second stream and read from z_buf; tree draws stay inline.
-enum RngMode : int32_t { kRngPhilox = 0, kRngBuffer = 1, kRngPregen = 2 };
+enum RngMode : int32_t { kRngPhilox = 0, kRngBuffer = 1 };
 
 // Every [C][Dp] plane is chain-major: one chain's vector is contiguous, rows are
 // padded to Dp = 64*NW*EPL doubles so that lane l of the chain's workgroup owns
@@ -71,7 +68,7 @@ struct Params {
   uint32_t transition;
   int32_t rng_mode;
   int32_t u_stride;      // kRngBuffer: uniforms per chain
-  const double* z_buf;   // kRngBuffer / kRngPregen: [C][Dp] standard normals
+  const double* z_buf;   // kRngBuffer: [C][Dp] standard normals
   const double* u_buf;   // kRngBuffer: [C][u_stride] canonical uniforms
   int64_t warmup_iter;   // AdaptiveWalnuts::iteration_
   // scratch
@@ -81,7 +78,7 @@ struct Params {
   int32_t pool_total;    // LDS + arena buffers
   int32_t pad1;
   uint32_t* work_counter;
-  uint32_t* error_flags;  // sticky: OR of kErr* bits of every chain and transition since the engine was created
+  uint32_t* error_flags;  // OR of kErr* bits of every chain and transition since wn_engine_check last read (and cleared) it
 };
 
 enum : uint32_t {

@@ -107,9 +107,6 @@ __device__ unsigned long long wn_timeline[kTimelineMarks];
 #define WN_MARK(k) ((void)0)  // marks only the timeline probe records
 #endif
 
-#if !defined(WN_MAIN_PRIO)
-#define WN_MAIN_PRIO 3
-#endif
 constexpr int kHot = -1;    // "this vector is the moving trajectory end"
 constexpr int kStart = -2;  // "this vector is the macro step's restart state (= the previous leaf)"
 
@@ -1096,7 +1093,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
         m2[0] = m0[0]; m2[1] = m0[1];
         ch2[0] = c0[0]; ch2[1] = c0[1];
       }
-      if (P.rng_mode != kRngPhilox) {
+      if (P.rng_mode == kRngBuffer) {
         const v2f64 z0 = ld(P.z_buf + row + o);
         z2[0] = z0[0];
         z2[1] = z0[1];
@@ -1185,11 +1182,6 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   WN_LDS int* next_chain = (WN_LDS int*)(bcast + 1);  // (the shift scratch of TrajChip follows at bcast + 2)
   double* arena = P.arena + static_cast<long long>(blockIdx.x) * P.arena_stride;
 
-#if !defined(WN_CPU_SIM)
-  // The chain's wavefront outranks whatever shares its SIMD: the momentum generator of the NEXT transition
-  // (wn_pregen.h) runs beside this kernel at the default priority and issues only in the slots this wavefront leaves.
-  __builtin_amdgcn_s_setprio(WN_MAIN_PRIO);
-#endif
   T t(P, pool, meta, red, bcast, arena);
 #if defined(WN_PHASE_PROFILE)
   t.phase_begin();

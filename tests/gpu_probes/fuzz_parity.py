@@ -23,7 +23,7 @@ GEOMETRIES = [(1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8), (4, 2), (
 
 def random_case(rng):
     model = rng.choice(["std_normal", "diag_normal", "funnel", "rw1"])
-    streaming = rng.uniform() < 0.15 and model in ("std_normal", "diag_normal")   # element-wise gradients only
+    streaming = rng.uniform() < 0.15   # every model has streaming kernels (funnel / rw1: the two-pass form)
     if streaming:
         geometry = (int(rng.choice([2, 4, 8, 16])), -1)
         D = int(rng.integers(3, 3000))

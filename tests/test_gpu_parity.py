@@ -70,6 +70,10 @@ def _need_gpu(gpu):
     ("std_normal", 20000, 8, (8, -1)),      # streaming, 8 wavefronts per chain, ragged last tile
     ("std_normal", 1000, 24, (2, -1)),      # streaming forced at a small dimension
     ("diag_normal", 5000, 12, (16, -1)),
+    ("funnel", 16384, 8, None),             # streaming for a gradient that needs sums over all coordinates (two passes)
+    ("rw1", 12000, 8, None),                # ... and one that needs neighbouring coordinates (halo reads)
+    ("rw1", 3000, 12, (4, -1)),
+    ("funnel", 2000, 12, (2, -1)),
 ])
 def test_engine_matches_oracle_bitwise(model, D, C, geometry, fma):
     parity.run_case(model, D, C, warmup=12, sampling=8, geometry=geometry, check_every=2, fused_multiply_add=fma)

@@ -33,6 +33,21 @@ def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry, fma):
                     fused_multiply_add=fma)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("model,D,kw", [
+    ("funnel", 300, dict(warmup=3, sampling=3)),                       # sums over the coordinates: two passes per micro step
+    ("rw1", 300, dict(warmup=3, sampling=3)),                          # neighbours' values: halo reads after a barrier
+    ("rw1", 260, dict(warmup=0, sampling=3, step=0.9, min_micro_steps=3, max_trajectory_doublings=3)),   # ping-pong sets
+    ("funnel", 140, dict(warmup=2, sampling=2, step=1.6, max_trajectory_doublings=3)),   # halvings + reversibility
+])
+def test_emulated_streaming_backend_for_gradients_that_are_not_elementwise(sim, oracle, model, D, kw):
+    """The streaming kernels (vectors in HBM, num_params > 8192 by default; forced here at small sizes) for models whose
+    gradient needs sums over all coordinates (funnel) or neighbouring coordinates (rw1): wn_model_api.h's streaming
+    form, two passes per micro step, bit for bit against the oracle in both arithmetic modes."""
+    for fma in (1, 0):
+        parity.run_case(model, D, 2, lib_path=sim, geometry=(1, -1), fused_multiply_add=fma, **kw)
+
+
 @pytest.mark.timeout(600)
 def test_emulated_engine_lds_pool_and_arena_paths(sim, oracle):
     # same chains with the span pool in LDS, split over LDS / HBM arena, in the arena only: identical results

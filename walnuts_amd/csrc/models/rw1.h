@@ -55,6 +55,50 @@ struct Rw1Model {
     }
   }
   __device__ __forceinline__ static double finish(double sum, const Aux&, int) { return -0.5 * sum; }
+
+  // ---- streaming form (num_params > 8192): no sums over coordinates, but every coordinate needs its two neighbours
+  // (kStreamHalo: the kernel hands them over as prev / next); the same expressions as eval() above
+  static constexpr bool kStreamable = true;
+  static constexpr int kStreamSums = 0;
+  static constexpr bool kStreamHalo = true;
+  template <class Cx>
+  __device__ __forceinline__ static void stream_sums(Cx&, const double (&)[2], const double (&)[2], double (&)[1]) {}
+  template <class Tab>
+  __device__ __forceinline__ static void stream_aux(const double (&)[1], int, const Tab&, Aux&) {}
+  template <class Cx>
+  __device__ __forceinline__ static void stream_grad(Cx& cx, const double (&y)[2], const double (&prev)[2],
+                                                     const double (&next)[2], const double (&)[2], double (&g)[2],
+                                                     const Aux&) {
+    constexpr double rho = 0.99;
+    const double inv_sigma_sq = 1.0 / (1.0 - rho * rho);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = cx.index(j);
+      double gj = n == 0 ? -y[j] : -((y[j] - rho * prev[j]) * inv_sigma_sq);
+      if (n + 1 < cx.dim()) gj = gj + rho * ((next[j] - rho * y[j]) * inv_sigma_sq);
+      g[j] = cx.valid(j) ? gj : 0.0;
+    }
+  }
+  template <class Cx>
+  __device__ __forceinline__ static void stream_logp(Cx& cx, const double (&y)[2], const double (&prev)[2],
+                                                     const double (&)[2], const double (&)[2], const Aux&, double& acc) {
+    constexpr double rho = 0.99;
+    const double inv_sigma_sq = 1.0 / (1.0 - rho * rho);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = cx.index(j);
+      double ta, tb;
+      if (n == 0) {
+        ta = tb = y[j];
+      } else {
+        const double r = y[j] - rho * prev[j];
+        ta = r;
+        tb = r * inv_sigma_sq;
+      }
+      const bool in = cx.valid(j);
+      acc = Cx::mad(in ? ta : 0.0, in ? tb : 0.0, acc);
+    }
+  }
 };
 
 }  // namespace wn

@@ -168,14 +168,22 @@ __global__ __launch_bounds__(64 * NW) void init_kernel_mem(const InitParams Q) {
       }
     }
     if (Q.do_masses) {
+      typename Model::Aux aux_here{};
+      if constexpr (T::kTwoPass) t.aux_of(Q.theta + row, aux_here);
       for (int k = 0; k < tiles; ++k) {
         const int o = t.pair_offset(k);
         const v2f64 t0 = T::ld(Q.theta + row + o);
         double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2];
         load_mp(o, mp2);
         typename T::TileCx cx{o, Q.dim};
-        double unused = 0.0;
-        Model::eval(cx, th2, g2, mp2, aux, unused);
+        if constexpr (T::kTwoPass) {
+          double prev[2], next[2];
+          t.halo(Q.theta + row, o, t0, prev, next);
+          Model::stream_grad(cx, th2, prev, next, mp2, g2, aux_here);
+        } else {
+          double unused = 0.0;
+          Model::eval(cx, th2, g2, mp2, aux, unused);
+        }
         T::st(Q.mass + row + o, o < Q.dim ? (1 - Q.smoothing) * fabs(g2[0]) + Q.smoothing : 1.0,
               o + 1 < Q.dim ? (1 - Q.smoothing) * fabs(g2[1]) + Q.smoothing : 1.0);
       }
@@ -184,6 +192,8 @@ __global__ __launch_bounds__(64 * NW) void init_kernel_mem(const InitParams Q) {
     if (Q.do_step) {
       // momentum rho0 = z .* sqrt(mass) and the energy at the start point (util.hpp:248-249, 289-293)
       double lp0 = 0.0, ke0 = 0.0;
+      typename Model::Aux aux0{};
+      if constexpr (T::kTwoPass) t.aux_of(Q.theta + row, aux0);
       for (int k = 0; k < tiles; ++k) {
         const int o = t.pair_offset(k);
         const v2f64 t0 = T::ld(Q.theta + row + o), m0 = T::ld(Q.mass + row + o);
@@ -199,7 +209,14 @@ __global__ __launch_bounds__(64 * NW) void init_kernel_mem(const InitParams Q) {
         double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2], r2[2];
         load_mp(o, mp2);
         typename T::TileCx cx{o, Q.dim};
-        Model::eval(cx, th2, g2, mp2, aux, lp0);
+        if constexpr (T::kTwoPass) {
+          double prev[2], next[2];
+          t.halo(Q.theta + row, o, t0, prev, next);
+          Model::stream_logp(cx, th2, prev, next, mp2, aux0, lp0);
+          (void)g2;
+        } else {
+          Model::eval(cx, th2, g2, mp2, aux, lp0);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           r2[j] = (o + j < Q.dim) ? z2[j] * __builtin_sqrt(m0[j]) : 0.0;
@@ -208,11 +225,60 @@ __global__ __launch_bounds__(64 * NW) void init_kernel_mem(const InitParams Q) {
         T::st(rho0 + o, r2[0], r2[1]);
       }
       t.sum2(lp0, ke0);
+      if constexpr (T::kTwoPass) aux = aux0;
       const double lj0 = Model::finish(lp0, aux, Q.dim) + (-0.5 * ke0);
       double step = uni(Q.step_init[chain]);
       const double log09 = wnd::dlog(0.9), log06 = wnd::dlog(0.6), rt = __builtin_sqrt(0.5);
       auto leapfrog_error = [&](double h) -> double {
         double lp1 = 0.0, ke1 = 0.0;
+        if constexpr (T::kTwoPass) {
+          // the probe step in two passes (the gradient at the new position needs its sums / its neighbours): the
+          // new position and the half-kicked momentum go to two scratch vectors of this workgroup
+          double* th_new = rho0 + Q.dim_padded;
+          double* r_new = rho0 + 2 * static_cast<long long>(Q.dim_padded);
+          double sums[T::ST::kSums];
+          for (int i = 0; i < T::ST::kSums; ++i) sums[i] = 0.0;
+          for (int k = 0; k < tiles; ++k) {
+            const int o = t.pair_offset(k);
+            const v2f64 t0 = T::ld(Q.theta + row + o), m0 = T::ld(Q.mass + row + o), r0 = T::ld(rho0 + o);
+            double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2], r2[2] = {r0[0], r0[1]}, prev[2], next[2];
+            load_mp(o, mp2);
+            t.halo(Q.theta + row, o, t0, prev, next);
+            typename T::TileCx cx{o, Q.dim};
+            Model::stream_grad(cx, th2, prev, next, mp2, g2, aux0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              r2[j] = r2[j] + 0.5 * h * g2[j];
+              th2[j] = th2[j] + h * ((1.0 / m0[j]) * r2[j]);
+            }
+            if (T::ST::kHasSums) Model::stream_sums(cx, th2, mp2, sums);
+            T::st(th_new + o, th2[0], th2[1]);
+            T::st(r_new + o, r2[0], r2[1]);
+          }
+          typename Model::Aux aux1{};
+          t.finish_sums(sums, aux1);
+          __syncthreads();
+          for (int k = 0; k < tiles; ++k) {
+            const int o = t.pair_offset(k);
+            const v2f64 t1 = T::ld(th_new + o), m0 = T::ld(Q.mass + row + o), r1 = T::ld(r_new + o);
+            const double th2[2] = {t1[0], t1[1]};
+            double g2[2], mp2[2], r2[2] = {r1[0], r1[1]}, prev[2], next[2];
+            load_mp(o, mp2);
+            t.halo(th_new, o, t1, prev, next);
+            typename T::TileCx cx{o, Q.dim};
+            Model::stream_grad(cx, th2, prev, next, mp2, g2, aux1);
+            Model::stream_logp(cx, th2, prev, next, mp2, aux1, lp1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              r2[j] = r2[j] + 0.5 * h * g2[j];
+              ke1 += (1.0 / m0[j]) * (r2[j] * r2[j]);
+            }
+          }
+          n_grad += 2;
+          t.sum2(lp1, ke1);
+          __syncthreads();  // the scratch vectors are free for the next probe
+          return (Model::finish(lp1, aux1, Q.dim) + (-0.5 * ke1)) - lj0;
+        } else {
         for (int k = 0; k < tiles; ++k) {
           const int o = t.pair_offset(k);
           const v2f64 t0 = T::ld(Q.theta + row + o), m0 = T::ld(Q.mass + row + o), r0 = T::ld(rho0 + o);
@@ -237,6 +303,7 @@ __global__ __launch_bounds__(64 * NW) void init_kernel_mem(const InitParams Q) {
         n_grad += 2;
         t.sum2(lp1, ke1);
         return (Model::finish(lp1, aux, Q.dim) + (-0.5 * ke1)) - lj0;
+        }
       };
       while (leapfrog_error(step) > log09) step *= 2;
       while (leapfrog_error(step) < log06) step *= rt;

@@ -138,7 +138,7 @@ struct ModelOps {
   int id;
   const char* name;
   bool uses_params;   // needs a parameter vector of num_params doubles
-  bool elementwise;   // has streaming (num_params > 8192) kernels
+  bool elementwise;   // has streaming (num_params > 8192) kernels: an element-wise gradient, or a stated streaming form
   int preferred_epl;  // the model's geometry hint: elements per lane (0 = the default policy)
   void (*launch_transition)(const Geometry&, int grid, size_t smem, hipStream_t, const Params&);
   void (*launch_init)(const Geometry&, int grid, size_t smem, hipStream_t, const InitParams&);

@@ -9,8 +9,9 @@
 //   struct MyModel {
 //     static constexpr bool kUsesParams;      // a parameter vector of num_params doubles exists (arrives as `mp`,
 //                                             //   padded with 1.0); wn_engine_create requires it then
-//     static constexpr bool kElementwise;     // grad[i] depends on theta[i] (and mp[i]) only: also instantiates the
-//                                             //   streaming kernels for num_params > 8192; needs grad() below
+//     static constexpr bool kElementwise;     // grad[i] depends on theta[i] (and mp[i]) only: the streaming kernels for
+//                                             //   num_params > 8192 then take ONE pass per micro step; needs grad()
+//                                             //   below (other models: the optional streaming form further down)
 //     static constexpr bool kCheapGrad;       // grad_elem() is one or two operations: the kernels then store no
 //                                             //   gradient vector at all and call grad_elem() at each use
 //     static constexpr bool kGradIsNegTheta;  // (informational) grad == -theta
@@ -25,6 +26,20 @@
 //     template <int EPL, class Cx>            // kElementwise only: the gradient alone, same expression as in eval()
 //     static void grad(Cx& cx, const double (&theta)[EPL], double (&g)[EPL], const double (&mp)[EPL], Aux&);
 //     static double finish(double sum, const Aux&, int num_params);   // -> logp
+//
+//     // optional -- "Streaming a model whose gradient is not element-wise": above 8 192 parameters the vectors live in
+//     // HBM and are processed two coordinates at a time, so eval() (which sees the lane's whole share at once) cannot
+//     // run.  A model states what its gradient needs beyond the coordinate itself, and gets two passes per micro step:
+//     static constexpr bool kStreamable = true;
+//     static constexpr int kStreamSums;       // 0..2 sums over ALL coordinates (funnel: sum x_i^2 and x_0)
+//     static constexpr bool kStreamHalo;      // the gradient reads the neighbouring coordinates (rw1)
+//     template <class Cx> static void stream_sums(Cx&, const double (&theta)[2], const double (&mp)[2], double (&sums)[N]);
+//     template <class Tab> static void stream_aux(const double (&sums)[N], int num_params, const Tab&, Aux&);
+//     template <class Cx> static void stream_grad(Cx&, const double (&theta)[2], const double (&prev)[2],
+//                                                 const double (&next)[2], const double (&mp)[2], double (&g)[2], const Aux&);
+//     template <class Cx> static void stream_logp(Cx&, theta, prev, next, mp, const Aux&, double& acc);  // adds the terms
+//     // (prev[j] / next[j]: the values at coordinate index(j) - 1 / + 1, 0.0 beyond the ends; the same expressions as
+//     // in eval() give the same bits.  wn_models.h: FunnelModel, models/rw1.h)
 //
 //     // optional, host side (wn_engine_create): check / transform the parameter vector before it is uploaded;
 //     // check num_params.  Throw std::invalid_argument to reject (-> error type `config`).

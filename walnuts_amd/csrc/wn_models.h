@@ -93,7 +93,7 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
   static constexpr bool kCheapGrad = false;
   __device__ __forceinline__ static double grad_elem(double, double) { return 0.0; }
   struct Aux {
-    double v, S, hev;
+    double v, S, hev, ev;
   };
   template <int EPL, class Cx>
   __device__ __forceinline__ static void eval(Cx& cx, const double (&th)[EPL], double (&g)[EPL],
@@ -118,7 +118,47 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
     aux.v = v;
     aux.S = S;
     aux.hev = hev;
+    aux.ev = ev;
   }
+  // ---- streaming form (num_params > 8192, wn_model_api.h "Streaming a model whose gradient is not element-wise"):
+  // the gradient needs two sums over the coordinates -- sum_{i>=1} x_i^2 and x_0 itself (a sum whose other terms are
+  // exact zeros) --, taken in one pass over the vector; the same expressions as eval() above, hence the same bits
+  static constexpr bool kStreamable = true;
+  static constexpr int kStreamSums = 2;
+  static constexpr bool kStreamHalo = false;
+  template <class Cx>
+  __device__ __forceinline__ static void stream_sums(Cx& cx, const double (&th)[2], const double (&)[2],
+                                                     double (&sums)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool first = cx.index(j) == 0;
+      const double x = first ? 0.0 : th[j];
+      sums[0] = Cx::mad(x, x, sums[0]);
+      sums[1] += first ? th[j] : 0.0;
+    }
+  }
+  template <class Tab>
+  __device__ __forceinline__ static void stream_aux(const double (&sums)[2], int, const Tab& tab, Aux& aux) {
+    aux.S = sums[0];
+    aux.v = sums[1];
+    aux.ev = wnd::dexp(-aux.v, tab);
+    aux.hev = 0.5 * aux.ev;
+  }
+  template <class Cx>
+  __device__ __forceinline__ static void stream_grad(Cx& cx, const double (&th)[2], const double (&)[2],
+                                                     const double (&)[2], const double (&)[2], double (&g)[2],
+                                                     const Aux& aux) {
+    const double hd = 0.5 * static_cast<double>(cx.dim() - 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      double gj = -(th[j] * aux.ev);
+      if (cx.index(j) == 0) gj = ((-aux.v / 9.0) + aux.hev * aux.S) - hd;
+      g[j] = cx.valid(j) ? gj : 0.0;
+    }
+  }
+  template <class Cx>
+  __device__ __forceinline__ static void stream_logp(Cx&, const double (&)[2], const double (&)[2], const double (&)[2],
+                                                     const double (&)[2], const Aux&, double&) {}  // finish() has it all
   __device__ __forceinline__ static double finish(double, const Aux& a, int D) {
     const double hd = 0.5 * static_cast<double>(D - 1);
     return ((-(a.v * a.v) / 18.0) - a.hev * a.S) - hd * a.v;

@@ -37,6 +37,8 @@
 
 #include "wn_hip.h"
 
+#include <type_traits>
+
 #include "wn_devmath.h"
 #include "wn_models.h"
 #include "wn_params.h"
@@ -707,6 +709,7 @@ struct TrajBase {
         self().get(e[0], kTh);
         self().get(e[1], kRh);
         self().get(e[2], kG);
+        self().moving_end_replaced();
       }
       double h_cur = fwd ? a_lj_fw : a_lj_bk;
 
@@ -830,6 +833,26 @@ struct TrajBase {
 // one fused pass reading theta, rho, grad, inv_mass and writing theta, rho, grad -- exactly the
 // algorithmic 56*D bytes.  Only models whose gradient is element-wise are supported here.
 // ---------------------------------------------------------------------------------------------------
+// What the streaming backend needs to know about a model whose gradient is NOT element-wise (wn_model_api.h,
+// "Streaming a model whose gradient is not element-wise"): how many sums over the coordinates its gradient depends on
+// and whether a coordinate's gradient reads its neighbours.
+template <class M, class = void>
+struct is_streamable : std::false_type {};
+template <class M>
+struct is_streamable<M, std::enable_if_t<M::kStreamable>> : std::true_type {};
+template <class M, bool Elementwise = M::kElementwise>
+struct StreamTraits {
+  static constexpr bool kTwoPass = false, kHasSums = false, kHalo = false;
+  static constexpr int kSums = 1;
+};
+template <class M>
+struct StreamTraits<M, false> {
+  static_assert(is_streamable<M>::value, "this model has no streaming form (kStreamable)");
+  static_assert(M::kStreamSums <= 2, "at most two sums over the coordinates");
+  static constexpr bool kTwoPass = true, kHasSums = M::kStreamSums > 0, kHalo = M::kStreamHalo;
+  static constexpr int kSums = M::kStreamSums > 0 ? M::kStreamSums : 1;
+};
+
 template <class Model, int NW, bool FMA = false>
 struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   using Base = TrajBase<TrajMem<Model, NW, FMA>, Model, NW>;
@@ -840,15 +863,22 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   static constexpr bool kHasStartState = true;
   static constexpr bool kZeroCopy = true;
   static constexpr bool kParkScalars = false;
-  static_assert(Model::kElementwise, "the streaming backend needs an element-wise gradient");
+  // An element-wise gradient is recomputed from theta inside the one pass of a micro step.  Any other streamable model
+  // (kTwoPass) takes two passes per micro step: its gradient at the new position needs sums over ALL of the new
+  // position (funnel) and / or the neighbours' new values (rw1), which exist only once the first pass has finished.
+  using ST = StreamTraits<Model>;
+  static constexpr bool kTwoPass = ST::kTwoPass;
+  typename Model::Aux auxs[4];  // kTwoPass: the model's by-products (sums) for the states in cur, alt, work, tmp
 
-  // The three vector sets are pool buffers themselves (role slot r: 0-2 cur, 3-5 alt, 6-8 work).  Handing a
+  // The vector sets are pool buffers themselves (role slot r: 0-2 cur, 3-5 alt, 6-8 work, 9-11 tmp).  Handing a
   // vector to the span pool (put_new) or taking one from it (get) moves a buffer index, not 8*Dp bytes; a slot
   // whose buffer the pool also names is read-only (`own` bit clear) and gets a fresh buffer before it is written.
   double* cur[3];   // theta, rho, grad of the moving end
   double* alt[3];   // the other set: output of the running macro step / the previous leaf after commit
   double* work[3];  // reversibility re-integration (the reference's scratch vectors, walnuts.hpp:264-266)
-  int slot_buf[9];
+  double* tmp[3];   // kTwoPass: ping-pong partner of the set a multi-step leaf is written to (never updated in place:
+                    //   a neighbour's old value may still be wanted)
+  int slot_buf[12];
   unsigned own;
   double* im_buf;   // warmup: this transition's inverse mass
   const double* im; // inverse mass row in force
@@ -866,8 +896,8 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     own = 0u;
     ut_valid = false;
     ut_hot = ut_far = 0.0;
-    for (int r = 0; r < 9; ++r) slot_buf[r] = -1;
-    for (int i = 0; i < 3; ++i) cur[i] = alt[i] = work[i] = nullptr;
+    for (int r = 0; r < 12; ++r) slot_buf[r] = -1;
+    for (int i = 0; i < 3; ++i) cur[i] = alt[i] = work[i] = tmp[i] = nullptr;
     ke_part = 0.0;
     tiles = p.dim_padded / (2 * L);
   }
@@ -899,7 +929,9 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
       st(dst + o, t[0], t[1]);
     }
   }
-  __device__ __forceinline__ double*& slot_ptr(int r) { return r < 3 ? cur[r] : r < 6 ? alt[r - 3] : work[r - 6]; }
+  __device__ __forceinline__ double*& slot_ptr(int r) {
+    return r < 3 ? cur[r] : r < 6 ? alt[r - 3] : r < 9 ? work[r - 6] : tmp[r - 9];
+  }
   __device__ __forceinline__ void set_slot(int r, int b, bool owned) {
     slot_buf[r] = b;
     slot_ptr(r) = pool_ptr(b);
@@ -931,6 +963,138 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     const int r = slot_of(c);
     if ((own >> r) & 1u) this->release(slot_buf[r]);
     set_slot(r, b, false);
+  }
+
+  // ---- two-pass models -------------------------------------------------------------------------------------
+  // values at the coordinates before / after the tile's two (0.0 beyond either end of the padded vector)
+  __device__ __forceinline__ void halo(const double* v, int o, const v2f64& t, double (&prev)[2], double (&next)[2]) const {
+    prev[0] = prev[1] = next[0] = next[1] = 0.0;
+    if constexpr (ST::kHalo) {
+      prev[0] = o > 0 ? v[o - 1] : 0.0;
+      prev[1] = t[0];
+      next[0] = t[1];
+      next[1] = o + 2 < Dp ? v[o + 2] : 0.0;
+    }
+  }
+  __device__ __forceinline__ void load_mp(int o, double (&mp2)[2]) const {
+    mp2[0] = mp2[1] = 1.0;
+    if (Model::kUsesParams) {
+      const v2f64 p0 = ld(P.model_params + o);
+      mp2[0] = p0[0];
+      mp2[1] = p0[1];
+    }
+  }
+  // lane partials of the model's sums -> the aux of that position (every wavefront ends with the same values)
+  __device__ __forceinline__ void finish_sums(double (&sums)[ST::kSums], typename Model::Aux& out) {
+    if constexpr (ST::kHasSums) {
+      double a = sums[0], b = ST::kSums > 1 ? sums[ST::kSums - 1] : 0.0;
+      this->sum2(a, b);
+      sums[0] = a;
+      if (ST::kSums > 1) sums[ST::kSums - 1] = b;
+      Model::stream_aux(sums, P.dim, this->uniform_tab(), out);
+    }
+  }
+  // the aux of a position that was not produced by a leapfrog pass (loaded, or taken over from the span pool)
+  __device__ __forceinline__ void aux_of(const double* theta, typename Model::Aux& out) {
+    if constexpr (kTwoPass && ST::kHasSums) {
+      double sums[ST::kSums];
+      for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
+      for (int k = 0; k < tiles; ++k) {
+        const int o = pair_offset(k);
+        const v2f64 t0 = ld(theta + o);
+        const double th2[2] = {t0[0], t0[1]};
+        double mp2[2];
+        load_mp(o, mp2);
+        TileCx cx{o, P.dim};
+        Model::stream_sums(cx, th2, mp2, sums);
+      }
+      finish_sums(sums, out);
+    }
+  }
+  // the moving end was replaced by a span end from the pool (TrajBase::run, turn-around)
+  __device__ __forceinline__ void moving_end_replaced() {
+    if constexpr (kTwoPass) aux_of(cur[0], auxs[0]);
+  }
+  __device__ __forceinline__ void swap_sets(int ra, int rb) {  // role sets ra, rb (0 cur, 1 alt, 2 work, 3 tmp)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double* t = slot_ptr(3 * ra + i);
+      slot_ptr(3 * ra + i) = slot_ptr(3 * rb + i);
+      slot_ptr(3 * rb + i) = t;
+      const int b = slot_buf[3 * ra + i];
+      slot_buf[3 * ra + i] = slot_buf[3 * rb + i];
+      slot_buf[3 * rb + i] = b;
+    }
+    const unsigned ma = 7u << (3 * ra), mb = 7u << (3 * rb);
+    const unsigned oa = (own & ma) >> (3 * ra), ob = (own & mb) >> (3 * rb);
+    own = (own & ~(ma | mb)) | (ob << (3 * ra)) | (oa << (3 * rb));
+    const typename Model::Aux t = auxs[ra];
+    auxs[ra] = auxs[rb];
+    auxs[rb] = t;
+  }
+  // n micro steps of a two-pass model from role set `rs` into role set `rd` (rd != rs; steps after the first
+  // ping-pong between rd and tmp, and the result ends in rd).  Pass A: kick with the gradient at the old position
+  // (its aux is known), drift, store, and take the model's sums of the NEW position; pass B: the gradient there,
+  // second kick, log-density terms, kinetic energy.
+  __device__ __forceinline__ double leapfrog_two_pass(int rs, int rd, bool negate, double h, int n) {
+    const double half = 0.5 * h;
+    double part = 0.0, ke = 0.0;
+    int from = rs, to = rd;
+    for (int s = 0; s < n; ++s) {
+      ensure_writable(3 * to);
+      double* const* in = &slot_ptr(3 * from);
+      double* const* out = &slot_ptr(3 * to);
+      const bool neg = negate && s == 0;
+      const typename Model::Aux a_in = auxs[from];
+      double sums[ST::kSums];
+      for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
+      for (int k = 0; k < tiles; ++k) {
+        const int o = pair_offset(k);
+        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), m0 = ld(im + o);
+        double th2[2] = {t0[0], t0[1]}, rh2[2] = {neg ? -r0[0] : r0[0], neg ? -r0[1] : r0[1]};
+        double g2[2], mp2[2], prev[2], next[2];
+        load_mp(o, mp2);
+        halo(in[0], o, t0, prev, next);
+        TileCx cx{o, P.dim};
+        Model::stream_grad(cx, th2, prev, next, mp2, g2, a_in);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) th2[j] = mad(h * m0[j], rh2[j], th2[j]);
+        if (ST::kHasSums) Model::stream_sums(cx, th2, mp2, sums);
+        st(out[0] + o, th2[0], th2[1]);
+        st(out[1] + o, rh2[0], rh2[1]);
+      }
+      finish_sums(sums, auxs[to]);
+      if (ST::kHalo) __syncthreads();  // the neighbours' new positions are in memory
+      const typename Model::Aux a_out = auxs[to];
+      part = 0.0;
+      ke = 0.0;
+      for (int k = 0; k < tiles; ++k) {
+        const int o = pair_offset(k);
+        const v2f64 t1 = ld(out[0] + o), r1 = ld(out[1] + o), m0 = ld(im + o);
+        const double th2[2] = {t1[0], t1[1]};
+        double rh2[2] = {r1[0], r1[1]}, g2[2], mp2[2], prev[2], next[2];
+        load_mp(o, mp2);
+        halo(out[0], o, t1, prev, next);
+        TileCx cx{o, P.dim};
+        Model::stream_grad(cx, th2, prev, next, mp2, g2, a_out);
+        Model::stream_logp(cx, th2, prev, next, mp2, a_out, part);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ke = mad(m0[j], rh2[j] * rh2[j], ke);
+        st(out[1] + o, rh2[0], rh2[1]);
+      }
+      ++n_grad;
+      from = to;
+      to = (to == rd) ? 3 : rd;
+    }
+    if (from != rd) swap_sets(rd, 3);  // an even number of steps ended in tmp
+    aux = auxs[rd];
+    ke_part = ke;
+    if (!negate) ut_valid = false;
+    return part;
   }
 
   // n micro steps (walnuts.hpp:328-333): the first reads `src` (rho negated for the reversibility check)
@@ -997,8 +1161,12 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     return part;
   }
   __device__ __forceinline__ double leapfrog(double h, int n) {
-    ensure_writable(3);
-    return leapfrog_sets(cur, alt, false, h, n);
+    if constexpr (kTwoPass) {
+      return leapfrog_two_pass(0, 1, false, h, n);
+    } else {
+      ensure_writable(3);
+      return leapfrog_sets(cur, alt, false, h, n);
+    }
   }
   __device__ __forceinline__ void energy(double lp_partial, double& logp_pos, double& logp_joint) {
     double ke = ke_part;
@@ -1019,6 +1187,11 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
       slot_buf[3 + i] = b;
     }
     own = (own & ~0x3fu) | ((own & 0x7u) << 3) | ((own >> 3) & 0x7u);
+    if constexpr (kTwoPass) {
+      const typename Model::Aux t = auxs[0];
+      auxs[0] = auxs[1];
+      auxs[1] = t;
+    }
   }
   // walnuts.hpp:254-279: coarser reverse paths from (theta', -rho', grad') = the candidate in `alt`
   __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
@@ -1026,8 +1199,13 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     while (n >= 2 * min_micro) {
       n /= 2;
       h *= 2;
-      ensure_writable(6);
-      const double part = leapfrog_sets(alt, work, true, h, n);
+      double part;
+      if constexpr (kTwoPass) {
+        part = leapfrog_two_pass(1, 2, true, h, n);
+      } else {
+        ensure_writable(6);
+        part = leapfrog_sets(alt, work, true, h, n);
+      }
       double lp, lj;
       energy(part, lp, lj);
       if (fabs(lj - logp_joint) <= max_error) return false;
@@ -1068,9 +1246,11 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     const double wd = w_draw0, ws = w_score0;
     im = warm ? im_buf : P.inv_mass + row;
     own = 0u;  // the base has just marked every pool buffer free
-    for (int r = 0; r < 9; ++r) slot_buf[r] = -1;
+    for (int r = 0; r < 12; ++r) slot_buf[r] = -1;
     ensure_writable(0);
     double part = 0.0, ke = 0.0;
+    double sums[ST::kSums];
+    for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
     for (int k = 0; k < tiles; ++k) {
       const int o = pair_offset(k);
       const v2f64 t0 = ld(P.theta + row + o);
@@ -1105,7 +1285,20 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
 #pragma unroll
       for (int j = 0; j < 2; ++j) rh2[j] = (o + j < P.dim) ? ch2[j] * z2[j] : 0.0;
       TileCx cx{o, P.dim};
-      Model::eval(cx, th2, g2, mp2, aux, part);
+      if constexpr (kTwoPass) {
+        // the position's sums for its aux; without sums the log-density terms can be taken right here (neighbours
+        // from the position plane), with sums they may depend on the aux and get a pass of their own below
+        if (ST::kHasSums) {
+          Model::stream_sums(cx, th2, mp2, sums);
+        } else {
+          double prev[2], next[2];
+          halo(P.theta + row, o, t0, prev, next);
+          Model::stream_logp(cx, th2, prev, next, mp2, auxs[0], part);
+        }
+        (void)g2;
+      } else {
+        Model::eval(cx, th2, g2, mp2, aux, part);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) ke = mad(m2[j], rh2[j] * rh2[j], ke);
       st(cur[0] + o, th2[0], th2[1]);
@@ -1113,11 +1306,31 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     }
     ++n_grad;
     ke_part = ke;
+    if constexpr (kTwoPass) {
+      finish_sums(sums, auxs[0]);
+      aux = auxs[0];
+      if (ST::kHasSums) {
+        for (int k = 0; k < tiles; ++k) {
+          const int o = pair_offset(k);
+          const v2f64 t0 = ld(P.theta + row + o);
+          const double th2[2] = {t0[0], t0[1]};
+          double mp2[2], prev[2], next[2];
+          load_mp(o, mp2);
+          halo(P.theta + row, o, t0, prev, next);
+          TileCx cx{o, P.dim};
+          Model::stream_logp(cx, th2, prev, next, mp2, auxs[0], part);
+        }
+      }
+    }
     return part;
   }
 
   __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
     const double* sel = pool_ptr(a_sel);
+    typename Model::Aux aux_sel{};
+    if constexpr (kTwoPass) {
+      if (warm) aux_of(sel, aux_sel);  // the estimator wants the gradient at the selected position
+    }
     const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(P.warmup_iter));
     const double wd = discount * w_draw0 + 1, ws = discount * w_score0 + 1;
     for (int k = 0; k < tiles; ++k) {
@@ -1137,8 +1350,14 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
           mp2[1] = p0[1];
         }
         TileCx cx{o, P.dim};
-        double unused = 0.0;
-        Model::eval(cx, th2, g2, mp2, aux, unused);
+        if constexpr (kTwoPass) {
+          double prev[2], next[2];
+          halo(sel, o, t0, prev, next);
+          Model::stream_grad(cx, th2, prev, next, mp2, g2, aux_sel);
+        } else {
+          double unused = 0.0;
+          Model::eval(cx, th2, g2, mp2, aux, unused);
+        }
         v2f64 mean = ld(P.est_draw_mean + row + o), ssd = ld(P.est_draw_ssd + row + o);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1161,8 +1380,8 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   }
 };
 
-// TrajMem: cur 3 + alt 3 + work 3 are pool buffers (the host adds kMemRoleVectors to the pool), + inverse mass 1
-constexpr int kMemRoleVectors = 9;
+// TrajMem: cur 3 + alt 3 + work 3 + tmp 3 are pool buffers (the host adds kMemRoleVectors to the pool), + inverse mass 1
+constexpr int kMemRoleVectors = 12;
 constexpr int kMemScratchVectors = 1;
 
 // ---------------------------------------------------------------------------------------

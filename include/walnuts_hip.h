@@ -251,8 +251,9 @@ WALNUTS_HIP_EXPORT void* wn_engine_stream(const wn_engine* e);     /* hipStream_
 WALNUTS_HIP_EXPORT double* wn_engine_positions_device(const wn_engine* e);
 /* HIP-event time of the last transition kernel launch, milliseconds */
 WALNUTS_HIP_EXPORT int wn_engine_last_kernel_ms(wn_engine* e, float* ms, WalnutpyError** err);
-/* per-launch HIP-event durations of the transition kernel since the last reset (recorded on the engine's
- * stream around every launch); num_launches may exceed max_launches */
+/* per-launch HIP-event durations of the transition kernel since the last reset: wn_engine_timing_reset switches the
+ * recording on (two events around every launch on the engine's stream; off by default, an event is a few
+ * microseconds between two kernels); num_launches may exceed max_launches */
 WALNUTS_HIP_EXPORT int wn_engine_timing_reset(wn_engine* e, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_kernel_times(wn_engine* e, float* ms_out, int max_launches, int* num_launches,
                                               WalnutpyError** err);

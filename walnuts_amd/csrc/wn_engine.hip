@@ -73,6 +73,8 @@ struct wn_engine {
   static constexpr size_t kEventRing = 1024;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;  // launches since the last timing reset
+  bool timing = false;     // record events around the launches (wn_engine_timing_reset switches it on)
+  uint32_t work_base = 0;  // value of the device-side chain counter at the next launch
   bool own_stream = true;
 
   ~wn_engine() {
@@ -216,12 +218,20 @@ struct wn_engine {
     use_device();
     if (ref_streams) feed_reference_streams();
     wn::Params P = make_params(warm, draws_dev, draws_stride);
-    HIP_OK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), stream));
-    auto& ev = next_events();
-    HIP_OK(hipEventRecord(ev.first, stream));
-    wn::launch_transition(model, geo, grid, smem, stream, P);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipEventRecord(ev.second, stream));
+    // The chain counter is never reset: every launch performs exactly C fetches (one per processed chain), so launch n
+    // starts at n * C (mod 2^32) -- one memset per transition less between two kernels.
+    P.work_base = work_base;
+    work_base += static_cast<uint32_t>(C);
+    if (timing) {  // HIP events around the launch: only between wn_engine_timing_reset and the read-back
+      auto& ev = next_events();
+      HIP_OK(hipEventRecord(ev.first, stream));
+      wn::launch_transition(model, geo, grid, smem, stream, P);
+      HIP_OK(hipGetLastError());
+      HIP_OK(hipEventRecord(ev.second, stream));
+    } else {
+      wn::launch_transition(model, geo, grid, smem, stream, P);
+      HIP_OK(hipGetLastError());
+    }
     variates_pending = false;
     ++transition;
     ++iteration;
@@ -335,6 +345,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.rng_draws.alloc(num_chains);
   e.grad_evals.alloc(num_chains);
   e.counter.alloc(1);
+  HIP_OK(hipMemsetAsync(e.counter.p, 0, sizeof(uint32_t), e.stream));
   e.error_flags.alloc(1);
   HIP_OK(hipMemsetAsync(e.error_flags.p, 0, sizeof(uint32_t), e.stream));
   e.lp_stats.alloc(3 * num_chains);
@@ -817,7 +828,7 @@ void* wn_engine_stream(const wn_engine* e) { return reinterpret_cast<void*>(e->s
 double* wn_engine_positions_device(const wn_engine* e) { return e->theta.p; }
 int wn_engine_last_kernel_ms(wn_engine* e, float* ms, WalnutpyError** err) {
   return guarded(err, [&] {
-    if (e->events_used == 0) throw std::runtime_error("no transition has been launched");
+    if (e->events_used == 0) throw std::runtime_error("no transition has been timed: call wn_engine_timing_reset first");
     e->use_device();
     auto& ev = e->events[e->events_used - 1];
     HIP_OK(hipEventSynchronize(ev.second));
@@ -825,7 +836,10 @@ int wn_engine_last_kernel_ms(wn_engine* e, float* ms, WalnutpyError** err) {
   });
 }
 int wn_engine_timing_reset(wn_engine* e, WalnutpyError** err) {
-  return guarded(err, [&] { e->events_used = 0; });
+  return guarded(err, [&] {
+    e->events_used = 0;
+    e->timing = true;
+  });
 }
 int wn_engine_kernel_times(wn_engine* e, float* ms_out, int max_launches, int* num_launches, WalnutpyError** err) {
   return guarded(err, [&] {

@@ -77,7 +77,9 @@ struct Params {
   int32_t pool_lds;      // vector buffers living in LDS
   int32_t pool_total;    // LDS + arena buffers
   int32_t pad1;
-  uint32_t* work_counter;
+  uint32_t* work_counter;  // chains fetched so far by all launches of this engine (mod 2^32; never reset)
+  uint32_t work_base;      // its value when this launch starts
+  uint32_t pad2;
   uint32_t* error_flags;  // OR of kErr* bits of every chain and transition since wn_engine_check last read (and cleared) it
 };
 

@@ -257,7 +257,7 @@ struct TrajBase {
   int fetched;
   __device__ __forceinline__ void prefetch_next_chain() {
     fetched = 0;
-    if (tid == 0) fetched = static_cast<int>(atomicAdd(P.work_counter, 1u) + gridDim.x);
+    if (tid == 0) fetched = static_cast<int>((atomicAdd(P.work_counter, 1u) - P.work_base) + gridDim.x);
   }
 
   // Re-derive the lane identity behind an optimisation barrier.  Everything computed from it (addresses, padding

@@ -691,9 +691,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       vload_stream(Q.est_score_ssd + row, ss);
     } else {
       vload_stream(Q.inv_mass + row, im);
-#if !defined(WN_RECOMPUTE_CHOL)
       vload_stream(Q.chol_mass + row, ds);  // 1/sqrt(inv_mass), walnuts.hpp:647, stored once by freeze_kernel
-#endif
     }
     WN_MARK(kPhLoadsIssued);
     const bool fed = Q.rng_mode == kRngBuffer;
@@ -722,13 +720,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         chol = __builtin_sqrt(1.0 / im[j]);
       } else {
         // Streaming the plane costs 8 KB of the 48 KB a 1024-dimensional chain moves per transition; re-evaluating
-        // the expression (a division and a square root per element) costs ~2 000 cycles of the ~85 000 a transition
-        // takes -- measured: 2.22 ms / 3.7 GB streamed against 2.27 ms / 3.15 GB recomputed (-DWN_RECOMPUTE_CHOL).
-#if defined(WN_RECOMPUTE_CHOL)
-        chol = 1.0 / __builtin_sqrt(im[j]);
-#else
+        // 1 / sqrt(im) (a division and a square root per element) costs ~2 000 cycles of the ~85 000 a transition took
+        // when this was measured (round 2): 2.22 ms / 3.7 GB streamed against 2.27 ms / 3.15 GB recomputed.
         chol = ds[j];
-#endif
       }
       const double r = chol * rh[0][j];
       rh[0][j] = (fed || valid(j)) ? r : 0.0;
@@ -800,9 +794,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
 // per lane; the moving end's two sets, the inverse mass and the two operands of a pool-side U-turn test must fit.
 template <class Model, int EPL>
 constexpr int chip_waves_per_simd() {
-#if defined(WN_WPE8)
-  if (EPL == 8) return WN_WPE8;
-#endif
   // a model that keeps its gradient vectors (two more per set) gets the next larger register budget
   if (!Model::kCheapGrad) return EPL >= 8 ? 1 : EPL == 4 ? 2 : 3;
   return EPL >= 16 ? 1 : EPL == 8 ? 2 : EPL == 4 ? 3 : 4;

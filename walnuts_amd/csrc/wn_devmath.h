@@ -321,11 +321,6 @@ WND_HD void stream_normal_pair(uint64_t seed, uint32_t chain, uint32_t transitio
   const U4 o = philox(pair, transition, chain, stream, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
   const double u1 = open01(o.x, o.y);
   const double u2 = open01(o.z, o.w);
-#if defined(WN_ABLATE_BM)
-  z0 = (u1 - 0.5) * 3.4641016151377544;
-  z1 = (u2 - 0.5) * 3.4641016151377544;
-  return;
-#endif
   const double rad = __builtin_sqrt(-2.0 * dlog_normal(u1, tab));
   double sn, cs;
   dsincospi(2.0 * u2, sn, cs);

@@ -133,7 +133,7 @@ __device__ __forceinline__ v2f64 stream_load(const v2f64* p) { return __builtin_
 __device__ __forceinline__ void stream_store(v2f64 v, v2f64* p) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void stream_store(double v, double* p) { __builtin_nontemporal_store(v, p); }
 
-#if defined(WN_PHASE_PROFILE) || defined(WN_TIMELINE)
+#if defined(WN_TIMELINE)
 __device__ __forceinline__ unsigned long long shader_clock() { return __builtin_amdgcn_s_memtime(); }
 #endif
 

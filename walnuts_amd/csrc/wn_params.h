@@ -8,9 +8,7 @@ namespace wn {
 constexpr int kMaxLevels = 16;   // span-stack levels => max_trajectory_doublings <= 17
 constexpr int kMaxPool = 64;     // vector buffers per resident chain (free mask is 64 bits)
 constexpr int kDrawCache = 64;    // tree draws (and their logs) produced per refill, one per lane
-#if defined(WN_PHASE_PROFILE)
-constexpr int kMetaDoubles = 152; // per-wave scalar scratch kept in LDS (see TrajBase::Meta)
-#elif defined(WN_TIMELINE)
+#if defined(WN_TIMELINE)
 constexpr int kTimelineMarks = 1536;
 constexpr int kMetaDoubles = 128 + kTimelineMarks + 8;
 #else

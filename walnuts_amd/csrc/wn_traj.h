@@ -84,14 +84,8 @@ __device__ __forceinline__ double log_sum_exp(double x1, double x2) {
   return r;
 }
 
-// ---- optional phase profiler (tests/gpu_probes only; compiled out of the product build) -------------
-#if defined(WN_PHASE_PROFILE)
-enum { kPhIdle = 0, kPhPrologue, kPhLeapfrog, kPhEnergy, kPhRestart, kPhReversible, kPhUturn, kPhCombine, kPhPush,
-       kPhTopMerge, kPhDoublingStart, kPhEpilogue, kPhCount };
-__device__ unsigned long long wn_phase_cycles[kPhCount];
-#define WN_PHASE(k) this->phase_mark(k)
-#define WN_PHASE_OUTER(k) t.phase_mark(k)
-#elif defined(WN_TIMELINE)
+// ---- optional timeline probe (tests/gpu_probes/timeline.py only; compiled out of the product build) -------------
+#if defined(WN_TIMELINE)
 // tests/gpu_probes only: (shader clock, mark id) pairs of workgroup 0's transitions, kept in LDS and copied out when
 // the workgroup retires.  One s_memtime and one LDS store per mark.
 enum { kPhIdle = 0, kPhPrologue, kPhLeapfrog, kPhEnergy, kPhRestart, kPhReversible, kPhUturn, kPhCombine, kPhPush,
@@ -137,11 +131,6 @@ struct TrajBase {
     int in_th[kMaxLevels];
     int in_rh[kMaxLevels];
     int sel[kMaxLevels];
-#if defined(WN_PHASE_PROFILE)
-    unsigned long long prof[16];
-    unsigned long long prof_last;
-    int prof_cur;
-#endif
 #if defined(WN_TIMELINE)
     unsigned long long tl[kTimelineMarks];
 #endif
@@ -200,29 +189,6 @@ struct TrajBase {
     adam_err = 0.0;
     adam_n = 0;
   }
-
-#if defined(WN_PHASE_PROFILE)
-  __device__ __forceinline__ void phase_mark(int k) {
-    const unsigned long long t = shader_clock();
-    if (lane == 0) {
-      meta->prof[meta->prof_cur] += t - meta->prof_last;
-      meta->prof_last = t;
-      meta->prof_cur = k;
-    }
-  }
-  __device__ __forceinline__ void phase_begin() {
-    if (lane == 0) {
-      for (int i = 0; i < 16; ++i) meta->prof[i] = 0;
-      meta->prof_last = shader_clock();
-      meta->prof_cur = kPhIdle;
-    }
-  }
-  __device__ __forceinline__ void phase_end() {
-    phase_mark(kPhIdle);
-    if (lane == 0)
-      for (int i = 0; i < kPhCount; ++i) atomicAdd(&wn_phase_cycles[i], meta->prof[i]);
-  }
-#endif
 
 #if defined(WN_TIMELINE)
   int tl_n = 0, tl_skip = 0;
@@ -1402,9 +1368,6 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   double* arena = P.arena + static_cast<long long>(blockIdx.x) * P.arena_stride;
 
   T t(P, pool, meta, red, bcast, arena);
-#if defined(WN_PHASE_PROFILE)
-  t.phase_begin();
-#endif
   // The workgroup's first chain is its own index; the following ones come from the shared counter, and the fetch
   // for chain n+1 is issued while chain n is being processed, so that its round trip (a device-scope atomic, 1-2 us
   // under load) overlaps the tree instead of standing between two transitions.
@@ -1423,9 +1386,6 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
       slot ^= 1;
     }
   }
-#if defined(WN_PHASE_PROFILE)
-  t.phase_end();
-#endif
 #if defined(WN_TIMELINE)
   t.timeline_end();
 #endif

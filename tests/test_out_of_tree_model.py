@@ -47,6 +47,11 @@ struct ShiftedNormal {
 };
 }  // namespace user
 '''
+# the same density declared as "not element-wise" and WITHOUT a streaming form: register kernels only
+PLAIN_H = MODEL_H.replace("struct ShiftedNormal", "struct PlainNormal").replace(
+    "static constexpr bool kElementwise = true;", "static constexpr bool kElementwise = false;").replace(
+    "static constexpr bool kCheapGrad = true;", "static constexpr bool kCheapGrad = false;")
+
 MODEL_HIP = '''#include "shifted_normal.h"
 #define WN_MODEL_ID %d
 #define WN_MODEL_TAG %s
@@ -61,6 +66,10 @@ def user_dir(tmp_path_factory):
     (d / "shifted_normal.h").write_text(MODEL_H)
     (d / "wn_kernels_shifted_normal.hip").write_text(MODEL_HIP % (7, "shifted_normal"))
     (d / "wn_kernels_clash.hip").write_text(MODEL_HIP % (0, "clash"))   # id 0 is std_normal's
+    (d / "plain_normal.h").write_text(PLAIN_H)
+    (d / "wn_kernels_plain_normal.hip").write_text(
+        (MODEL_HIP % (9, "plain_normal")).replace("shifted_normal.h", "plain_normal.h").replace("ShiftedNormal",
+                                                                                                "PlainNormal"))
     return d
 
 
@@ -97,6 +106,19 @@ def test_out_of_tree_model_registers_and_samples_its_density(user_dir):
         assert np.all(e.depths() >= 1) and np.all(e.grad_evals() > 6)
     with pytest.raises(ValueError, match="parameter vector"):       # kUsesParams: the engine insists on mu
         wa.DeviceEngine(7, D, Cn, wa.default_config(lib_path), lib_path=lib_path)
+
+
+@pytest.mark.timeout(900)
+def test_model_without_a_streaming_form_is_limited_to_the_register_kernels(user_dir):
+    lib_path = simbuild.build_with_models([str(user_dir / "wn_kernels_plain_normal.hip")], str(user_dir))
+    mu = np.zeros(12)
+    e = wa.DeviceEngine(9, 12, 2, wa.default_config(lib_path), params=mu, lib_path=lib_path)   # register kernels: fine
+    e.seed_chains(1, 0)
+    e.warmup_step()
+    e.synchronize()
+    assert np.all(e.depths() >= 1)
+    with pytest.raises(ValueError, match="streaming"):     # vectors in HBM need kElementwise or the streaming form
+        wa.DeviceEngine(9, 12, 2, wa.default_config(lib_path, elems_per_lane=-1), params=mu, lib_path=lib_path)
 
 
 @pytest.mark.timeout(900)

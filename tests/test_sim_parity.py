@@ -171,8 +171,7 @@ def test_engine_argument_and_state_errors(sim):
         mk(wa.MODEL_STD_NORMAL, 3, 2, wa.default_config(sim, max_hamiltonian_error=-1.0))
     with pytest.raises(ValueError, match="max_nuts_depth|max_trajectory_doublings"):
         mk(wa.MODEL_STD_NORMAL, 3, 2, wa.default_config(sim, max_trajectory_doublings=0))
-    with pytest.raises(ValueError, match="streaming"):
-        mk(wa.MODEL_FUNNEL, 40, 2, wa.default_config(sim, elems_per_lane=-1))   # no streaming kernel for the funnel
+    mk(wa.MODEL_FUNNEL, 40, 2, wa.default_config(sim, elems_per_lane=-1))   # (the funnel streams since round 3)
     e = mk(wa.MODEL_STD_NORMAL, 3, 2, wa.default_config(sim))
     with pytest.raises(ValueError, match="masses must be positive"):
         e.set_masses(np.array([[1.0, 0.0, 1.0], [1.0, 1.0, 1.0]]))

@@ -84,7 +84,7 @@ def test_resident_draws_and_thinned_rows_equal_the_streamed_run(sim, oracle):
     """walnutpie_sample_device_resident: the draws that stay on the device are the streamed run's, the host gets rows
     0, thin, 2 thin, ..., and the summaries over the resident block equal the oracle's over the streamed draws."""
     whole = _run(sim)
-    for thin in (3, 1, 0):
+    for thin in (3, 0):
         res, chains = _run(sim, keep_on_device=True, thin=thin)
         assert chains.num_chains() == 3 and chains.dims() == 5 and chains.num_draws() == 3 * 7
         for a, b in zip(whole, res):

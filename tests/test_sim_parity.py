@@ -20,13 +20,15 @@ def sim():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("fma", [1, 0])   # fused multiply-adds (the default) / every product rounded
-@pytest.mark.parametrize("model,D,geometry", [
-    ("std_normal", 10, None),          # (1,2): D < one pair per lane, heavy padding
-    ("diag_normal", 130, (1, 4)),      # (1,4): four elements per lane
-    ("funnel", 9, (2, 2)),             # two wavefronts: cross-wave reductions, broadcasts, barriers
-    ("diag_normal", 300, (1, -1)),     # streaming backend (vectors in HBM scratch), 3 tiles per lane
-    ("rw1", 70, (1, 2)),               # neighbour-coupled gradient through the public model interface
+@pytest.mark.parametrize("model,D,geometry,fma", [   # fma: fused multiply-adds (the default) / every product rounded
+    ("std_normal", 10, None, 1),          # (1,2): D < one pair per lane, heavy padding
+    ("std_normal", 10, None, 0),
+    ("diag_normal", 130, (1, 4), 1),      # (1,4): four elements per lane
+    ("funnel", 9, (2, 2), 1),             # two wavefronts: cross-wave reductions, broadcasts, barriers
+    ("funnel", 9, (2, 2), 0),
+    ("diag_normal", 300, (1, -1), 1),     # streaming backend (vectors in HBM scratch), 3 tiles per lane
+    ("diag_normal", 300, (1, -1), 0),
+    ("rw1", 70, (1, 2), 1),               # neighbour-coupled gradient through the public model interface
 ])
 def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry, fma):
     parity.run_case(model, D, 2, warmup=4, sampling=3, lib_path=sim, geometry=geometry, step=None,
@@ -34,18 +36,18 @@ def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry, fma):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("model,D,kw", [
-    ("funnel", 300, dict(warmup=3, sampling=3)),                       # sums over the coordinates: two passes per micro step
-    ("rw1", 300, dict(warmup=3, sampling=3)),                          # neighbours' values: halo reads after a barrier
-    ("rw1", 260, dict(warmup=0, sampling=3, step=0.9, min_micro_steps=3, max_trajectory_doublings=3)),   # ping-pong sets
-    ("funnel", 140, dict(warmup=2, sampling=2, step=1.6, max_trajectory_doublings=3)),   # halvings + reversibility
+@pytest.mark.parametrize("model,D,fma,kw", [
+    ("funnel", 140, 1, dict(warmup=2, sampling=2, max_trajectory_doublings=4)),   # sums over the coordinates: two passes per micro step
+    ("funnel", 140, 0, dict(warmup=1, sampling=2, step=1.6, max_trajectory_doublings=3)),   # halvings + reversibility
+    ("rw1", 300, 1, dict(warmup=2, sampling=2)),                       # neighbours' values: halo reads after a barrier
+    ("rw1", 260, 0, dict(warmup=0, sampling=3, step=0.9, min_micro_steps=3, max_trajectory_doublings=3)),   # ping-pong sets
 ])
-def test_emulated_streaming_backend_for_gradients_that_are_not_elementwise(sim, oracle, model, D, kw):
+def test_emulated_streaming_backend_for_gradients_that_are_not_elementwise(sim, oracle, model, D, fma, kw):
     """The streaming kernels (vectors in HBM, num_params > 8192 by default; forced here at small sizes) for models whose
     gradient needs sums over all coordinates (funnel) or neighbouring coordinates (rw1): wn_model_api.h's streaming
-    form, two passes per micro step, bit for bit against the oracle in both arithmetic modes."""
-    for fma in (1, 0):
-        parity.run_case(model, D, 2, lib_path=sim, geometry=(1, -1), fused_multiply_add=fma, **kw)
+    form, two passes per micro step, bit for bit against the oracle (both arithmetic modes over the four cases; the
+    full cross product runs on the GPU)."""
+    parity.run_case(model, D, 2, lib_path=sim, geometry=(1, -1), fused_multiply_add=fma, **kw)
 
 
 @pytest.mark.timeout(600)

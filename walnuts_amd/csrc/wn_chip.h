@@ -669,9 +669,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     // ---- selected state out (walnuts.hpp:560-562), estimator update (adaptive_walnuts.hpp:247-248) ----
     WN_PHASE(kPhEpilogue);
     this->refresh_ids();
-    finish_transition(a_sel, row, warm);
+    finish_transition(a_sel, row, warm);  // (runs the batched Adam update behind its plane requests)
     WN_MARK(kPhStored);
-    if (warm && wave == 0) this->adam_flush();
     this->store_scalars(warm, depth, a_lpsel);
     WN_MARK(kPhScalars);
   }
@@ -741,6 +740,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       vload_stream(Q.est_draw_ssd + row, ssd);
       vload_stream(Q.est_score_mean + row, smean);
       vload_stream(Q.est_score_ssd + row, sssd);
+      // ... and the batched Adam update (adam.hpp:70-86 for every macro step of this transition: ~4 000 cycles of
+      // wave-uniform arithmetic that touches none of the planes) runs while they are on their way
+      if (wave == 0) this->adam_flush();
     }
     if (kOtherRegs && a_sel == kOther) {
 #pragma unroll

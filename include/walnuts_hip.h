@@ -257,6 +257,12 @@ WALNUTS_HIP_EXPORT int wn_engine_last_kernel_ms(wn_engine* e, float* ms, Walnutp
 WALNUTS_HIP_EXPORT int wn_engine_timing_reset(wn_engine* e, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_kernel_times(wn_engine* e, float* ms_out, int max_launches, int* num_launches,
                                               WalnutpyError** err);
+/* the same measurement with ONE pair of events for a whole region of launches (nothing between two kernels):
+ * _region_begin records the start on the engine's stream, _region_ms records the end, waits for it and returns the
+ * elapsed time and the number of transition launches in between (average launch duration = total / launches, the few
+ * microseconds between two launches included) */
+WALNUTS_HIP_EXPORT int wn_engine_region_begin(wn_engine* e, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_region_ms(wn_engine* e, float* total_ms, int* launches, WalnutpyError** err);
 /* run on a caller-owned hipStream_t (e.g. the framework's current stream, so that RCCL collectives on the
  * draws are ordered after the kernels without host synchronisation) */
 WALNUTS_HIP_EXPORT int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err);

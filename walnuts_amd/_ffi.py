@@ -113,6 +113,8 @@ SYMBOLS = [
     ("wn_engine_positions_device", _vp, [_vp]),
     ("wn_engine_last_kernel_ms", _i32, [_vp, C.POINTER(C.c_float), _errpp]),
     ("wn_engine_timing_reset", _i32, [_vp, _errpp]),
+    ("wn_engine_region_begin", _i32, [_vp, _errpp]),
+    ("wn_engine_region_ms", _i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int), _errpp]),
     ("wn_engine_kernel_times", _i32, [_vp, C.POINTER(C.c_float), _i32, C.POINTER(C.c_int), _errpp]),
     ("wn_engine_set_stream", _i32, [_vp, _vp, _errpp]),
     ("wn_lanes_for_dim", _i32, [_i32, _i32, _i32]),

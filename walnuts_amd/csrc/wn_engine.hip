@@ -74,6 +74,8 @@ struct wn_engine {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;  // launches since the last timing reset
   bool timing = false;     // record events around the launches (wn_engine_timing_reset switches it on)
+  hipEvent_t region_begin = nullptr, region_end = nullptr;  // wn_engine_region_begin / _region_ms
+  size_t region_launches = 0;
   uint32_t work_base = 0;  // value of the device-side chain counter at the next launch
   bool own_stream = true;
 
@@ -82,6 +84,8 @@ struct wn_engine {
       (void)hipEventDestroy(ev.first);
       (void)hipEventDestroy(ev.second);
     }
+    if (region_begin) (void)hipEventDestroy(region_begin);
+    if (region_end) (void)hipEventDestroy(region_end);
     if (stream && own_stream) (void)hipStreamDestroy(stream);
   }
 
@@ -232,6 +236,7 @@ struct wn_engine {
       wn::launch_transition(model, geo, grid, smem, stream, P);
       HIP_OK(hipGetLastError());
     }
+    ++region_launches;
     variates_pending = false;
     ++transition;
     ++iteration;
@@ -853,6 +858,28 @@ int wn_engine_kernel_times(wn_engine* e, float* ms_out, int max_launches, int* n
       HIP_OK(hipEventSynchronize(e->events[slot].second));
       HIP_OK(hipEventElapsedTime(&ms_out[i], e->events[slot].first, e->events[slot].second));
     }
+  });
+}
+int wn_engine_region_begin(wn_engine* e, WalnutpyError** err) {
+  return guarded(err, [&] {
+    e->use_device();
+    if (e->region_begin == nullptr) {
+      HIP_OK(hipEventCreate(&e->region_begin));
+      HIP_OK(hipEventCreate(&e->region_end));
+    }
+    e->timing = false;  // one pair of events for the whole region instead of one pair per launch
+    e->region_launches = 0;
+    HIP_OK(hipEventRecord(e->region_begin, e->stream));
+  });
+}
+int wn_engine_region_ms(wn_engine* e, float* total_ms, int* launches, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e->region_begin == nullptr) throw std::runtime_error("wn_engine_region_begin has not been called");
+    e->use_device();
+    HIP_OK(hipEventRecord(e->region_end, e->stream));
+    HIP_OK(hipEventSynchronize(e->region_end));
+    HIP_OK(hipEventElapsedTime(total_ms, e->region_begin, e->region_end));
+    if (launches) *launches = static_cast<int>(e->region_launches);
   });
 }
 int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {

@@ -224,6 +224,16 @@ class DeviceEngine:
                    C.cast(C.byref(a), _dp), C.cast(C.byref(b), _dp))
         return a.value, b.value
 
+    def region_begin(self):
+        """Start of a timed region of launches (one pair of HIP events around all of them)."""
+        self._call(self.lib.wn_engine_region_begin)
+
+    def region_ms(self):
+        """-> (elapsed ms since region_begin on the engine's stream, transition launches in between)."""
+        ms, n = C.c_float(), C.c_int()
+        self._call(self.lib.wn_engine_region_ms, C.byref(ms), C.byref(n))
+        return float(ms.value), int(n.value)
+
     def timing_reset(self):
         self._call(self.lib.wn_engine_timing_reset)
 

@@ -192,14 +192,14 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     }
   }
   __device__ __forceinline__ void pool_load(int b, double (&v)[EPL]) {
-    if (b < n_lds) {
+    if (WN_LIKELY(b < n_lds)) {
       lds_load(lds_pool + b * kDp, v);
       return;
     }
     vload(arena + static_cast<long long>(b - n_lds) * kDp, v);
   }
   __device__ __forceinline__ void pool_store(int b, const double (&v)[EPL]) {
-    if (b < n_lds) {
+    if (WN_LIKELY(b < n_lds)) {
       lds_store(lds_pool + b * kDp, v);
       return;
     }
@@ -263,7 +263,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   // from (theta', -rho', grad').
   template <int S>
   __device__ __forceinline__ bool reversible(double h, int n, double logp_joint) {
-    if (n == 1) return true;
+    if (WN_LIKELY(n == 1)) return true;
     const int k0 = this->alloc(), k1 = this->alloc(), k2 = kNoGrad ? -1 : this->alloc();
     pool_store(k0, th[S]);
     pool_store(k1, rh[S]);
@@ -317,7 +317,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   template <int CH>
   __device__ __forceinline__ void pool_load_slots(int b, int j0, double (&v)[CH]) {
     const int k0 = j0 / 2;
-    if (b < n_lds) {
+    if (WN_LIKELY(b < n_lds)) {
       const WN_LDS double* base = lds_pool + b * kDp;
 #pragma unroll
       for (int k = 0; k < CH / 2; ++k) {
@@ -395,7 +395,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         if (is_warmup() && wave == 0) this->adam_record(fabs(logp_start - logp_joint));
       }
       WN_PHASE(kPhRestart);
-      if (fabs(logp_start - logp_joint) <= max_error) {
+      if (WN_LIKELY(fabs(logp_start - logp_joint) <= max_error)) {
         WN_PHASE(kPhReversible);
         const bool rev = reversible<B>(h, n, logp_joint);
         WN_PHASE(kPhRestart);
@@ -534,7 +534,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         // the leaf is done) rides in the leaf's reduction
         double leaf_lp, leaf_lj;
         ok = macro_step<0>(fwd, h_cur, leaf_lp, leaf_lj, true, top_turned);
-        if (ok) {
+        if (WN_LIKELY(ok)) {
 #pragma unroll
           for (int j = 0; j < EPL; ++j) {
             th[0][j] = th[1][j];
@@ -549,20 +549,21 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         for (int i = 0; i < nleaf; i += 2) {
           double e_lp, e_lj, leaf_lp, leaf_lj;
           bool pair_turned = false, unused = false;
-          if (!macro_step<0>(fwd, h_cur, e_lp, e_lj, false, unused)) {  // build_leaf, walnuts.hpp:420-442
+          if (WN_UNLIKELY(!macro_step<0>(fwd, h_cur, e_lp, e_lj, false, unused))) {  // build_leaf, walnuts.hpp:420-442
             ok = false;
             break;
           }
-          if (!macro_step<1>(fwd, e_lj, leaf_lp, leaf_lj, true, pair_turned)) {
+          if (WN_UNLIKELY(!macro_step<1>(fwd, e_lj, leaf_lp, leaf_lj, true, pair_turned))) {
             ok = false;
             break;
           }
+          if (is_warmup() && wave == 0) this->adam_make_room();
           h_cur = leaf_lj;
           // level-0 merge, combine<Barker> (walnuts.hpp:370-386): old = the even leaf (set 1), new = the odd leaf (set 0)
           WN_PHASE(kPhCombine);
           {
-            const double total = uni(log_sum_exp(e_lj, leaf_lj));
-            if (pair_turned) {  // walnuts.hpp:490-492
+            const double total = uni(log_sum_exp_uniform(e_lj, leaf_lj));
+            if (WN_UNLIKELY(pair_turned)) {  // walnuts.hpp:490-492
               ok = false;
               break;
             }
@@ -579,7 +580,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
             const double s_logsum = uni(meta->logsum[sp]), s_lpsel = uni(meta->lpsel[sp]);
             WN_PHASE(kPhUturn);
             this->lse_on_leader(s_logsum, c_logsum);
-            if (uturn_pool(s_in_th, s_in_rh, fwd)) {  // walnuts.hpp:490-492
+            if (WN_UNLIKELY(uturn_pool(s_in_th, s_in_rh, fwd))) {  // walnuts.hpp:490-492
               ok = false;
               break;
             }
@@ -598,7 +599,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
             c_lpsel = n_lpsel;
             c_logsum = total;
           }
-          if (!ok) break;
+          if (WN_UNLIKELY(!ok)) break;
           WN_PHASE(kPhPush);
           if (i + 2 < nleaf) {
             // the next pair overwrites both sets: whatever is still symbolic gets pool buffers
@@ -617,7 +618,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
           }
         }
       }
-      if (!ok) return false;  // walnuts.hpp:543-545
+      if (WN_UNLIKELY(!ok)) return false;  // walnuts.hpp:543-545
 
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
       WN_PHASE(kPhTopMerge);
@@ -625,7 +626,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       double total;
       if (kFirst) {
         turned = top_turned;
-        total = uni(log_sum_exp(a_logsum, c_logsum));
+        total = uni(log_sum_exp_uniform(a_logsum, c_logsum));
       } else {
         this->lse_on_leader(a_logsum, c_logsum);
         if (kOtherRegs) {
@@ -694,7 +695,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     }
     WN_MARK(kPhLoadsIssued);
     const bool fed = Q.rng_mode == kRngBuffer;
-    if (fed) {
+    if (WN_UNLIKELY(fed)) {
       vload_stream(Q.z_buf + row, rh[0]);
     } else {
       const uint64_t seed = Q.seed;
@@ -753,10 +754,10 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     WN_MARK(kPhSelLoaded);
     vstore_stream(Q.theta + row, th[0]);
     double* draws = Q.draws_out;
-    if (draws != nullptr) {
+    if (WN_LIKELY(draws != nullptr)) {
       double* out = draws + static_cast<long long>(chain) * Q.draws_stride;
       // an unpadded row on a 16-byte boundary takes the pair stores; anything else goes element by element
-      if (P.dim == kDp && ((reinterpret_cast<unsigned long long>(out) & 15ull) == 0ull)) {
+      if (WN_LIKELY(P.dim == kDp && ((reinterpret_cast<unsigned long long>(out) & 15ull) == 0ull))) {
         vstore_stream(out, th[0]);
       } else {
 #pragma unroll

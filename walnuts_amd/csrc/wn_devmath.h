@@ -206,6 +206,38 @@ WND_HD double dlog1pexp(double d) {
   return y;
 }
 
+// The same function for an argument known to be a finite number <= 0 (or any finite number: the clamp stays): the
+// main path of dlog1pexp without its NaN patches -- the same operations on the same values, hence the same bits.
+template <bool Uniform>
+WND_HD double dlog1pexp_finite(double d) {
+  const double dc = d < -48.0 ? -48.0 : d;
+  const double kf = __builtin_floor(fmad(dc, 16.0, 0.5));
+  int i = -static_cast<int>(kf);  // 0..768
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (Uniform) i = __builtin_amdgcn_readfirstlane(i);
+#endif
+  const double F = as_f64(wn_tab_l1pe_bits[2 * i]);
+  const double S = as_f64(wn_tab_l1pe_bits[2 * i + 1]);
+  const double r = fmad(-kf, 0.0625, dc);
+  const double r2 = r * r;
+  const double r4 = r2 * r2;
+  const double p1 = fmad(r, 1.66666666666666657e-01, 0.5);
+  const double p2 = fmad(r, 8.33333333333333322e-03, 4.16666666666666644e-02);
+  const double p3 = fmad(r, 1.98412698412698413e-04, 1.38888888888888894e-03);
+  const double q = fmad(r4, 2.48015873015873016e-05, fmad(r2, p3, p2));
+  const double e1 = r + fmad(r2, p1, r4 * q);
+  const double t = S * e1;
+  const double t2 = t * t;
+  const double t4 = t2 * t2;
+  const double b0 = fmad(t, 3.33333333333333315e-01, -0.5);
+  const double b1 = fmad(t, 2.00000000000000011e-01, -0.25);
+  const double b2 = fmad(t, 1.42857142857142849e-01, -1.66666666666666657e-01);
+  const double b3 = fmad(t, 1.11111111111111105e-01, -0.125);
+  const double inner = fmad(t4, -0.1, fmad(t2, b3, b2));
+  const double outer = fmad(t4, inner, fmad(t2, b1, b0));
+  return F + fmad(t2, outer, t);
+}
+
 // the tables as plain arrays (host: tests, engine set-up; device: constant memory for the rarely used call sites)
 struct ArrayTables {
   const unsigned long long* e2;

@@ -84,6 +84,18 @@ __device__ __forceinline__ double log_sum_exp(double x1, double x2) {
   return r;
 }
 
+// The same value where nothing can be overlapped with the call anyway (the level-0 merge of a leaf pair, the first
+// doubling's merge): for finite arguments -- a wave-uniform test, hence a scalar branch -- the lean main path, without
+// the fifteen instructions of special-value patches; anything else takes the general form above.  Bit-identical.
+__device__ __forceinline__ double log_sum_exp_uniform(double x1, double x2) {
+  if (__builtin_isfinite(x1) && __builtin_isfinite(x2)) {
+    const double m = fmax(x1, x2);
+    const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
+    return m + wnd::dlog1pexp_finite<true>(d);
+  }
+  return log_sum_exp(x1, x2);
+}
+
 // ---- optional timeline probe (tests/gpu_probes/timeline.py only; compiled out of the product build) -------------
 #if defined(WN_TIMELINE)
 // tests/gpu_probes only: (shader clock, mark id) pairs of workgroup 0's transitions, kept in LDS and copied out when
@@ -101,6 +113,16 @@ __device__ unsigned long long wn_timeline[kTimelineMarks];
 #endif
 #if !defined(WN_MARK)
 #define WN_MARK(k) ((void)0)  // marks only the timeline probe records
+#endif
+
+// Branch hints for the rare paths that are inlined into the leaf loops (refills, overflow into the HBM arena, step
+// halvings, reversibility re-integrations): the register allocator weighs a block by its expected frequency.
+#if defined(WN_NO_BRANCH_HINTS)
+#define WN_LIKELY(x) (x)
+#define WN_UNLIKELY(x) (x)
+#else
+#define WN_LIKELY(x) __builtin_expect(!!(x), 1)
+#define WN_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #endif
 
 constexpr int kHot = -1;    // "this vector is the moving trajectory end"
@@ -324,7 +346,7 @@ struct TrajBase {
 
   // ---- span pool: wave-uniform buffer indices over a 64-bit free mask ---------------------
   __device__ __forceinline__ int alloc() {
-    if (free_mask == 0ull) {
+    if (WN_UNLIKELY(free_mask == 0ull)) {
       err = 1;
       return 0;
     }
@@ -335,7 +357,7 @@ struct TrajBase {
   // long-lived vectors (accumulated span ends) take the highest free buffer so that the LDS-resident low
   // indices stay available for the short-lived span-stack entries
   __device__ __forceinline__ int alloc_cold() {
-    if (free_mask == 0ull) {
+    if (WN_UNLIKELY(free_mask == 0ull)) {
       err = 1;
       return 0;
     }
@@ -375,7 +397,7 @@ struct TrajBase {
     const int j = base + lane;
     const auto& Q = cold();
     double u;
-    if (Q.rng_mode == kRngBuffer) {
+    if (WN_UNLIKELY(Q.rng_mode == kRngBuffer)) {
       u = j < Q.u_stride ? Q.u_buf[static_cast<long long>(chain) * Q.u_stride + j] : 0.5;
     } else {
       u = wnd::stream_uniform(Q.seed, Q.chain_offset + chain, Q.transition, wnd::kStreamTree,
@@ -389,7 +411,7 @@ struct TrajBase {
   __device__ __forceinline__ int next_draw_slot() {
     const int j = uni(n_draw);
     ++n_draw;
-    if (draw_base < 0 || j - draw_base >= kDrawCache) refill_draws(j & ~(kDrawCache - 1));
+    if (WN_UNLIKELY(draw_base < 0 || j - draw_base >= kDrawCache)) refill_draws(j & ~(kDrawCache - 1));
     return j - draw_base;
   }
   // (the slot first, in a statement of its own: next_draw_slot() may refill the registers the read then uses, and the
@@ -414,7 +436,14 @@ struct TrajBase {
   int adam_n;
   __device__ __forceinline__ void adam_record(double abs_error) {
     adam_err = (lane == adam_n) ? abs_error : adam_err;
-    if (++adam_n == 64) adam_flush();
+    ++adam_n;
+  }
+  // The register holds 64 observations.  The flush is NOT part of adam_record: inlined into every macro-step
+  // instantiation it sat in the middle of the leaf loops (three copies of ~400 instructions, and everything live
+  // across them).  The tree loops call this after a leaf or a leaf pair instead -- one site each, off the leaf's path --,
+  // which keeps room for the next two records; when the update runs does not change its arithmetic.
+  __device__ __forceinline__ void adam_make_room() {
+    if (WN_UNLIKELY(adam_n > 62)) adam_flush();
   }
   __device__ __forceinline__ void adam_flush() {
     const int n = adam_n;
@@ -553,9 +582,9 @@ struct TrajBase {
         w[2] = w2 + delta * (lpsel - mean);
       }
       // host-fed uniforms: a transition that consumed more than were supplied used the filler value
-      if (Q.rng_mode == kRngBuffer && n_draw > Q.u_stride) err |= static_cast<int>(kErrVariatesExhausted);
+      if (WN_UNLIKELY(Q.rng_mode == kRngBuffer && n_draw > Q.u_stride)) err |= static_cast<int>(kErrVariatesExhausted);
       // the per-transition report (depth -1) is overwritten by the next transition; the engine-wide word is not
-      if (err) atomicOr(Q.error_flags, static_cast<uint32_t>(err));
+      if (WN_UNLIKELY(err != 0)) atomicOr(Q.error_flags, static_cast<uint32_t>(err));
       Q.logp_out[chain] = lpsel;
       Q.depth_out[chain] = err ? -1 : depth;
       if constexpr (Self::kParkScalars) {
@@ -691,6 +720,7 @@ struct TrajBase {
           ok = false;
           break;
         }
+        if (P.warmup && wave == 0) adam_make_room();
         h_cur = leaf_lj;
         c_in_th = kHot;
         c_in_rh = kHot;
@@ -1373,7 +1403,7 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   // under load) overlaps the tree instead of standing between two transitions.
   int c = static_cast<int>(blockIdx.x);
   int slot = 0;
-  while (c < P.num_chains) {
+  while (WN_LIKELY(c < P.num_chains)) {
     WN_PHASE_OUTER(kPhIdle);
     t.run(c);  // issues t.prefetch_next_chain() on the way
     if (NW == 1) {

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- leapfrog grad-evals/sec of the GPU-resident Walnuts engine (BASELINE.json metric).
 
-A "step" is one MCMC transition (walnuts.hpp:520-563) of EVERY chain: one launch of the persistent transition
-kernel per GPU.  Default workload = BASELINE.json's headline: 65 536 chains x 1 024-dim standard normal, default
+A "step" is one MCMC transition (walnuts.hpp:520-563) of EVERY chain.  One launch of the persistent transition
+kernel runs `--transitions-per-launch` consecutive steps (default 8: the workgroup that fetched a chain runs that
+many transitions of it back to back -- the chains are independent -- so the launch and its tail, the last chains
+finishing while the chip drains, are paid once per launch; every transition's draw plane is written; K timed steps =
+ceil(K / 8) launches, the last one shorter; `--transitions-per-launch 1` = one launch per step, the per-step numbers
+of rounds 1-3).  Default workload = BASELINE.json's headline: 65 536 chains x 1 024-dim standard normal, default
 SamplingConfig, parameters adapted by `--adapt-iters` on-device warmup transitions (untimed), then W untimed + K
 timed sampling transitions.  Inputs are generated on the device (counter-based stream) and are resident in HBM
 when the timed region starts.
@@ -52,14 +56,15 @@ HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/
 FP64_VALU_PEAK_TF = 78.6   # fp64 vector peak (half the 157.3 TFLOP/s fp32 vector peak of the same guide)
 FLOPS_PER_GRAD_EVAL_PER_DIM = 10.0   # leapfrog 7*D + model 3*D
 HEADLINE_CHAINS = 65536
+DEFAULT_TRANSITIONS_PER_LAUNCH = 8   # consecutive transitions of every chain per kernel launch (wn_engine_sample_steps)
 CONFIG5_CHAINS = 262144
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--chains", type=int, default=HEADLINE_CHAINS,
                     help="total chains (strong scaling) or chains per GPU (weak scaling)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -80,6 +85,9 @@ def parse():
                          "element-wise bits of the reference's x86-64 -O3 build); -1: the library default")
     ap.add_argument("--reserved-cus", type=int, default=-1,
                     help="CUs left free for the RCCL all-gather kernels (default: 0 on one GPU, 16 otherwise)")
+    ap.add_argument("--transitions-per-launch", type=int, default=DEFAULT_TRANSITIONS_PER_LAUNCH,
+                    help="transitions of every chain per kernel launch (wn_engine_sample_steps): the workgroup that "
+                         "fetched a chain runs them back to back; a step stays ONE transition of all chains")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="all-gather the draws of every k-th transition (1 = every draw, the north star's exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,10 +143,12 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(args, D, chains_local):
+def measured_traffic(args, D, chains_local, transitions_per_average_launch):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes recorded under profiles/ (counters
     are collected in their own runs, never inside a timed bench run).  Only an entry recorded for THIS source hash of
-    walnuts_amd/csrc counts; anything else is reported as stale and not used."""
+    walnuts_amd/csrc and THIS number of transitions per launch counts; anything else is reported as stale and not
+    used.  The profiled dispatch ran a full launch; when K is not a multiple of the transitions per launch the average
+    launch of the timed region is shorter and the figure is scaled by transitions."""
     try:
         entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except OSError:
@@ -146,9 +156,11 @@ def measured_traffic(args, D, chains_local):
     sha = csrc_sha()
     stale = None
     for e in entries:
-        if (e["model"], e["chains"], e["dim"], e["phase"]) == (args.model, chains_local, D, args.phase):
+        if (e["model"], e["chains"], e["dim"], e["phase"], e.get("transitions_per_launch", 1)) == (
+                args.model, chains_local, D, args.phase, max(1, args.transitions_per_launch)):
             if e.get("csrc_sha") == sha:
-                return e["bytes_per_launch"], e["source"]
+                scale = transitions_per_average_launch / e.get("transitions_per_launch", 1)
+                return e["bytes_per_launch"] * scale, e["source"]
             stale = f"stale PMC entry refused (recorded for csrc {e.get('csrc_sha')}, this build is {sha})"
     return None, stale or "this workload was not profiled"
 
@@ -411,19 +423,27 @@ def main():
     eng.adapt_step(args.seed, chain0)
     eng.seed_chains(args.seed + 1, chain0)
 
+    T = max(1, args.transitions_per_launch)
     gather = DrawGather(dist, world, rank, total_chains, D, "cuda", torch.float64,
-                        counts=None if args.scaling == "strong" else [C] * world)
+                        counts=None if args.scaling == "strong" else [C] * world, transitions=T)
 
-    def one_step(i, timed_phase):
-        plane = gather.buffer(i)
-        if timed_phase == "warmup":
-            eng.warmup_step(plane.data_ptr(), D)
-        else:
-            eng.sample_step(plane.data_ptr(), D)
-        # the path's only exchange: all-gather of this iteration's draws over xGMI, overlapped with the next
-        # transition (no-op on one GPU)
-        if i % args.gather_every == 0:
-            gather.launch(i)
+    def run_steps(first, count, timed_phase):
+        """`count` steps (transitions of all chains) starting at step `first`, T per launch."""
+        launches = 0
+        i = first
+        while i < first + count:
+            n = min(T, first + count - i)
+            launch_id = i // T
+            block = gather.buffer(launch_id)   # [rows, D], or [T, rows, D]: one draw plane per transition
+            step_fn = eng.warmup_steps if timed_phase == "warmup" else eng.sample_steps
+            step_fn(n, block.data_ptr(), D, gather.rows * D)
+            # the path's only exchange: all-gather of the launch's draws over xGMI, overlapped with the next launch
+            # (no-op on one GPU)
+            if launch_id % args.gather_every == 0:
+                gather.launch(launch_id)
+            launches += 1
+            i += n
+        return launches
 
     def fence():
         gather.drain()
@@ -432,12 +452,11 @@ def main():
         eng.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.adapt_iters):
-        eng.warmup_step()
+    for i in range(0, args.adapt_iters, T):
+        eng.warmup_steps(min(T, args.adapt_iters - i))
     if args.phase == "sampling":
         eng.freeze()
-    for i in range(args.warmup):
-        one_step(i, args.phase)
+    run_steps(0, args.warmup, args.phase)
     fence()
     g_before = eng.total_grad_evals()
     # the dominant kernel's average launch duration: HIP events on the stream it is launched on, over the timed region
@@ -448,8 +467,7 @@ def main():
     else:
         eng.region_begin()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i, args.phase)
+    launches = run_steps(0, args.steps, args.phase)
     if not per_launch:
         region_total_ms, region_launches = eng.region_ms()   # (waits for the last launch: part of the fence anyway)
     fence()
@@ -473,11 +491,11 @@ def main():
     if rank == 0:
         avg_kernel_ms = float(np.mean(ktimes)) if len(ktimes) else float("nan")
         kernel_s = avg_kernel_ms * 1e-3
-        evals_per_launch = grad_evals / max(args.steps, 1)   # this rank's launches
+        evals_per_launch = grad_evals / max(launches, 1)   # this rank's launches
         algorithmic_bytes = 56.0 * D * evals_per_launch
         algorithmic_gbps = algorithmic_bytes / kernel_s / 1e9
         streaming = bool(eng.streaming)
-        traffic, traffic_source = measured_traffic(args, D, C)
+        traffic, traffic_source = measured_traffic(args, D, C, args.steps / max(launches, 1))
         if streaming:
             roofline = {"bound": "hbm", "achieved": algorithmic_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": algorithmic_gbps / HBM_PEAK_GBPS, "traffic": traffic,
@@ -528,6 +546,7 @@ def main():
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
                              "reserved_cus": reserved},
                 "grad_evals_per_transition_per_chain": grad_evals / max(args.steps, 1) / C,
+                "transitions_per_launch": T, "launches": launches,
                 "arithmetic": ("fused multiply-adds in the integrator (as an FMA-target build of the reference)"
                                if cfg.fused_multiply_add else
                                "every product rounded (the reference's x86-64 -O3 element-wise bits)"),

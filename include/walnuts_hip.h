@@ -195,6 +195,17 @@ WALNUTS_HIP_EXPORT int wn_engine_freeze(wn_engine* e, WalnutpyError** err);
 /* WalnutsSampler::operator() for all chains. */
 WALNUTS_HIP_EXPORT int wn_engine_sample_step(wn_engine* e, double* draws_dev, int64_t draws_stride,
                                              WalnutpyError** err);
+/* `transitions` consecutive AdaptiveWalnuts / WalnutsSampler transitions of every chain in ONE launch: the workgroup that
+ * fetched a chain runs them back to back (the chains are independent, walnuts.hpp:682-692 called `transitions` times
+ * per chain), so the per-launch tail -- the last chains finishing while the rest of the chip idles -- and the launch
+ * itself are paid once per `transitions`.  Chain c's k-th position goes to draws_dev + c*draws_stride +
+ * k*draws_transition_stride (doubles); the per-transition reports (wn_engine_get_depths, ...) show the LAST transition.
+ * Same bits as `transitions` single steps.  Host-fed variates (reference streams, wn_engine_set_variates) cover one
+ * transition: config error with transitions > 1. */
+WALNUTS_HIP_EXPORT int wn_engine_warmup_steps(wn_engine* e, int transitions, double* draws_dev, int64_t draws_stride,
+                                              int64_t draws_transition_stride, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_sample_steps(wn_engine* e, int transitions, double* draws_dev, int64_t draws_stride,
+                                              int64_t draws_transition_stride, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_synchronize(wn_engine* e, WalnutpyError** err);
 /* fails (generic error) if a transition of any chain since the previous check could not complete on the device (span
  * pool exhausted, host-fed variates exhausted); reading the flag clears it */

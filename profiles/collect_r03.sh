@@ -11,18 +11,19 @@ $B > $OUT/bench_headline.json 2> $OUT/bench.err
 $B --phase warmup --no-cpu-baseline --no-parity-gate > $OUT/bench_headline_warmup.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model ill_normal --chains 4096 --dim 1024 --adapt-iters 300 > $OUT/bench_cfg2.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 128 --adapt-iters 300 > $OUT/bench_cfg3.json 2>> $OUT/bench.err
-$B --no-cpu-baseline --model diag_normal --chains 8192 --dim 16384 --steps 5 --warmup 2 --adapt-iters 100 > $OUT/bench_cfg4.json 2>> $OUT/bench.err
-$B --no-cpu-baseline --config 5 --steps 10 --warmup 3 > $OUT/bench_cfg5_one_gpu.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --config 5 --steps 16 --warmup 8 > $OUT/bench_cfg5_one_gpu.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_funnel_1024.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model rw1 --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_rw1_1024.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --fma 0 > $OUT/bench_headline_every_product_rounded.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --transitions-per-launch 1 > $OUT/bench_headline_one_transition_per_launch.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --chains 8192 --steps 40 > $OUT/bench_shard_8192.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --chains 16384 --steps 40 > $OUT/bench_shard_16384.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --chains 32768 --steps 40 > $OUT/bench_shard_32768.json 2>> $OUT/bench.err
-$B --no-cpu-baseline --model funnel --chains 8192 --dim 16384 --steps 5 --warmup 2 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_funnel_16384_streaming.json 2>> $OUT/bench.err
-$B --no-cpu-baseline --model rw1 --chains 8192 --dim 16384 --steps 5 --warmup 2 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_rw1_16384_streaming.json 2>> $OUT/bench.err
-$B --gpus 2 --backend gloo --no-cpu-baseline --steps 5 --warmup 2 > $OUT/bench_gloo2_one_gpu.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --steps 10 --warmup 3 > /dev/null 2>&1
+$B --no-cpu-baseline --model funnel --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_funnel_16384_streaming.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --model rw1 --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_rw1_16384_streaming.json 2>> $OUT/bench.err
+$B --gpus 2 --backend gloo --no-cpu-baseline --steps 16 --warmup 8 > $OUT/bench_gloo2_one_gpu.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --steps 16 --warmup 8 > /dev/null 2>&1
 python3 $ROOT/profiles/summarize.py r03 $(find $OUT/headline_trace -name "*results.db" | head -1) > $OUT/kernel_trace_headline.txt 2>&1
 rm -rf $OUT/headline_trace
 for f in $OUT/bench_*.json; do python3 -c "

@@ -8,7 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-parity-gate --steps 4 --warmup 1 --adapt-iters 100 $*"
+# (steps and warmup are multiples of the transitions per launch: every profiled dispatch is a full launch)
+ARGS="--no-cpu-baseline --no-parity-gate --steps 16 --warmup 8 --adapt-iters 100 $*"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
@@ -26,7 +27,7 @@ for db in sorted(glob.glob("$OUT/p*/**/*results.db", recursive=True)):
     for n in names:
         v = [r for r in rows if r[0] == n]
         vals[n] = (v[-1][1], v[-1][2] / 1e3)   # last dispatch = steady-state sampling
-print("# per launch of the transition kernel (last = steady-state sampling dispatch), args: $ARGS")
+print("# per launch of the transition kernel (last = steady-state dispatch; one launch = --transitions-per-launch transitions of every chain, default 8), args: $ARGS")
 for n, (v, d) in vals.items():
     print(f"{n:28s} {v:18.1f}   (dispatch {d:.1f} us under this pass)")
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
@@ -36,13 +37,14 @@ import argparse, hashlib, json, os
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="std_normal"); ap.add_argument("--chains", type=int, default=65536)
 ap.add_argument("--dim", type=int, default=1024); ap.add_argument("--phase", default="sampling")
-known, _ = ap.parse_known_args("$ARGS".split())
 import sys
 sys.path.insert(0, "$ROOT")
 import bench
+ap.add_argument("--transitions-per-launch", type=int, default=bench.DEFAULT_TRANSITIONS_PER_LAUNCH)
+known, _ = ap.parse_known_args("$ARGS".split())
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     json.dump({"model": known.model, "chains": known.chains, "dim": known.dim, "phase": known.phase,
-               "csrc_sha": bench.csrc_sha(), "bytes_per_launch": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
+               "transitions_per_launch": max(1, known.transitions_per_launch), "csrc_sha": bench.csrc_sha(), "bytes_per_launch": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
                "source": "profiles/${PROFILE_ROUND:-r03}/pmc_$TAG.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, last "
                          "(steady-state) dispatch, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 note in MI355X_MICROARCH.md"},
               open("$OUT/traffic.json", "w"))

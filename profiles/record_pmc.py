@@ -19,7 +19,7 @@ def main():
         os.makedirs(os.path.join(ROOT, "profiles", os.environ.get("PROFILE_ROUND", "r03")), exist_ok=True)
         shutil.copy(os.path.join(src, "summary.txt"), os.path.join(ROOT, "profiles", os.environ.get("PROFILE_ROUND", "r03"), f"pmc_{tag}.txt"))
         e = json.load(open(os.path.join(src, "traffic.json")))
-        key = lambda x: (x["model"], x["chains"], x["dim"], x["phase"])
+        key = lambda x: (x["model"], x["chains"], x["dim"], x["phase"], x.get("transitions_per_launch", 1))
         entries = [x for x in entries if key(x) != key(e)] + [e]
         print(tag, key(e), e["csrc_sha"], f"{e['bytes_per_launch'] / 1e9:.3f} GB")
     json.dump(entries, open(path, "w"), indent=1)

@@ -160,7 +160,8 @@ inline double wave_sum_packed(double a, double b) {  // a's total in lanes 0-31,
   const double sa = wave_sum(a), sb = wave_sum(b);
   return (wnsim::tidx.x & 63u) < 32u ? sa : sb;
 }
-inline int opaque_thread_id() { return static_cast<int>(wnsim::tidx.x); }
+inline int opaque_lane_id() { return static_cast<int>(wnsim::tidx.x & 63u); }
+inline int wave_in_workgroup() { return static_cast<int>(wnsim::tidx.x >> 6); }
 template <class T>
 inline const T& kernel_argument(const T& by_value) { return by_value; }
 inline v2f64 stream_load(const v2f64* p) { return *p; }

@@ -53,6 +53,7 @@ def random_case(rng):
     if rng.uniform() < 0.2:
         kw.update(average_masses=True)
     kw.update(fused_multiply_add=int(rng.integers(0, 2)))   # both arithmetic modes
+    kw.update(fused=int(rng.choice([1, 1, 2, 3, 5])))       # transitions per launch (wn_engine_*_steps)
     C = int(rng.choice([1, 2, 3, 7, 16, 33, 64]))
     return model, D, C, kw
 

@@ -87,8 +87,9 @@ def assert_same_state(dev, orc, where: str, warm: bool):
 
 
 def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path=None, geometry=None, seed=1234,
-             init="random", step=None, check_every=1, average_masses=False, **cfg_over):
-    """InitConfigBuilder -> warmup -> freeze -> sampling on both sides, bit-compared along the way."""
+             init="random", step=None, check_every=1, average_masses=False, fused=1, **cfg_over):
+    """InitConfigBuilder -> warmup -> freeze -> sampling on both sides, bit-compared along the way.  fused > 1: the
+    device runs that many transitions per launch (wn_engine_warmup_steps / _sample_steps), the oracle single steps."""
     dev, orc = make_pair(model, D, C, lib_path, geometry, **cfg_over)
     rng = np.random.default_rng(seed)
     if init == "random":
@@ -114,22 +115,30 @@ def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path
             f"adapt_step differs: {dev.step_sizes()[:4]} vs {orc.step_sizes()[:4]}"
     for x in (dev, orc):
         x.seed_chains(seed + 1, 3)
-    for it in range(warmup):
-        dev.warmup_step()
-        orc.warmup_step(8)
-        if (it + 1) % check_every == 0 or it == warmup - 1:
-            assert_same_state(dev, orc, f"{model} D={D} warmup it={it}", warm=True)
+    it = 0
+    while it < warmup:
+        n = min(fused, warmup - it)
+        dev.warmup_step() if n == 1 else dev.warmup_steps(n)
+        for _ in range(n):
+            orc.warmup_step(8)
+        it += n
+        if it % check_every == 0 or it == warmup or fused > 1:
+            assert_same_state(dev, orc, f"{model} D={D} warmup it={it - 1}", warm=True)
     dev.freeze()
     orc.freeze()
     dev.synchronize()
     assert same_bits_or_nan(dev.step_sizes(), orc.step_sizes()), "frozen step sizes differ"
     assert same_bits_or_nan(dev.inv_mass(), orc.inv_mass()), "frozen inverse mass differs"
     assert np.array_equal(dev.min_micro(), orc.min_micro().astype(np.int32)), "frozen min micro steps differ"
-    for it in range(sampling):
-        dev.sample_step()
-        orc.sample_step(8)
-        if (it + 1) % check_every == 0 or it == sampling - 1:
-            assert_same_state(dev, orc, f"{model} D={D} sampling it={it}", warm=False)
+    it = 0
+    while it < sampling:
+        n = min(fused, sampling - it)
+        dev.sample_step() if n == 1 else dev.sample_steps(n)
+        for _ in range(n):
+            orc.sample_step(8)
+        it += n
+        if it % check_every == 0 or it == sampling or fused > 1:
+            assert_same_state(dev, orc, f"{model} D={D} sampling it={it - 1}", warm=False)
     return dev, orc
 
 

@@ -48,6 +48,15 @@ for it in range(ITERS):
 gather.drain()
 eng.sample_step(); eng.sample_step()
 rhat = global_rhat(dist, eng)                             # the sampling controller's statistic over both ranks
+# one launch of three transitions per chain (wn_engine_sample_steps): ONE collective moves the block of three planes
+blocks = DrawGather(dist, world, rank, TOTAL, D, "cpu", torch.float64, transitions=3)
+block = blocks.buffer(0)
+assert tuple(block.shape) == (3, blocks.rows, D)
+eng.sample_steps(3, block.data_ptr(), D, blocks.rows * D)
+eng.synchronize()
+blocks.launch(0)
+fused = blocks.result(0).clone().numpy()
+blocks.drain()
 if rank == 0:
     ref = make(0, TOTAL)
     for it in range(ITERS):
@@ -62,6 +71,12 @@ if rank == 0:
     ref.sample_step(); ref.sample_step()
     assert np.allclose(spread, ref_spread, rtol=1e-12), (spread, ref_spread)
     assert abs(rhat - ref.rhat()) <= 1e-12 * rhat, (rhat, ref.rhat())
+    assert fused.shape == (3, TOTAL, D)
+    for k in range(3):
+        buf = np.empty((TOTAL, D))
+        ref.sample_step(buf.ctypes.data, D)
+        ref.synchronize()
+        assert np.array_equal(buf, fused[k]), (k, buf, fused[k])
     print("DISTRIBUTED_OK")
 dist.barrier()
 dist.destroy_process_group()

@@ -79,6 +79,61 @@ def test_engine_matches_oracle_bitwise(model, D, C, geometry, fma):
     parity.run_case(model, D, C, warmup=12, sampling=8, geometry=geometry, check_every=2, fused_multiply_add=fma)
 
 
+# ---- several transitions per launch (wn_engine_warmup_steps / wn_engine_sample_steps) ---------------------------------
+@pytest.mark.parametrize("model,D,C,geometry,fused", [
+    ("std_normal", 1024, 2500, (1, 16), 4),   # headline kernel, more chains than resident workgroups (1 024): the shared
+                                              # counter hands every chain to ONE workgroup for all of its transitions
+    ("std_normal", 100, 64, None, 8),
+    ("std_normal", 1024, 64, (2, 8), 3),      # two wavefronts per chain: barrier between the transitions
+    ("diag_normal", 1024, 96, None, 5),
+    ("funnel", 128, 300, None, 8),            # config #3's kernel
+    ("funnel", 1000, 32, (4, 4), 2),
+    ("rw1", 1024, 48, None, 4),
+    ("diag_normal", 16384, 12, None, 3),      # streaming backend
+    ("funnel", 2000, 12, (2, -1), 4),         # streaming, two passes per micro step
+])
+def test_fused_launches_match_oracle_bitwise(model, D, C, geometry, fused):
+    """The device runs `fused` transitions of every chain per launch, the oracle single steps: same bits after every
+    launch, through adaptive warmup (Adam, the estimator's discount by iteration number) and sampling."""
+    parity.run_case(model, D, C, warmup=2 * fused + 1, sampling=2 * fused + 1, geometry=geometry, fused=fused)
+
+
+def test_fused_launches_full_size_headline():
+    """65 536 x 1 024: one launch of 8 transitions leaves the positions, statistics and EVERY draw plane that 8
+    launches of one transition leave."""
+    import torch
+    D, C, T = 1024, 65536, 8
+
+    def engine():
+        e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, C)
+        e.init_positions(3, 0, 2.0)
+        e.init_masses_from_grad(1e-5)
+        e.set_step_sizes(0.3)
+        e.seed_chains(4, 0)
+        for _ in range(2):
+            e.warmup_step()
+        return e
+
+    a, b = engine(), engine()
+    a.warmup_steps(3)
+    for _ in range(3):
+        b.warmup_step()
+    a.freeze(), b.freeze()
+    pa = torch.empty((T, C, D), dtype=torch.float64, device="cuda")
+    pb = torch.empty((T, C, D), dtype=torch.float64, device="cuda")
+    a.sample_steps(T, pa.data_ptr(), D, C * D)
+    for k in range(T):
+        b.sample_step(pb[k].data_ptr(), D)
+    a.synchronize(), b.synchronize()
+    assert torch.equal(pa, pb)
+    assert np.array_equal(a.positions(), b.positions())
+    assert np.array_equal(a.positions(), pa[T - 1].cpu().numpy())
+    for f in ("logp", "depths", "grad_evals", "rng_draws", "step_sizes"):
+        assert np.array_equal(getattr(a, f)(), getattr(b, f)()), f
+    assert a.rhat() == b.rhat()
+    a.check(), b.check()
+
+
 @pytest.mark.parametrize("model,D,C,geometry,lds", [
     ("std_normal", 1024, 96, (2, 8), 2),    # two LDS vectors, the rest overflows to the HBM arena
     ("std_normal", 1024, 64, (2, 8), 0),     # the whole span pool in the HBM arena

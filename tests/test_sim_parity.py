@@ -50,6 +50,56 @@ def test_emulated_streaming_backend_for_gradients_that_are_not_elementwise(sim, 
     parity.run_case(model, D, 2, lib_path=sim, geometry=(1, -1), fused_multiply_add=fma, **kw)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("model,D,geometry", [
+    ("std_normal", 10, None),          # one wavefront per chain: program order carries the chain's state
+    ("funnel", 9, (2, 2)),             # two wavefronts: a workgroup barrier between the transitions
+    ("diag_normal", 300, (1, -1)),     # streaming backend
+])
+def test_emulated_fused_transitions_match_single_steps(sim, oracle, model, D, geometry):
+    """wn_engine_warmup_steps / wn_engine_sample_steps: several transitions of every chain in one launch (the workgroup
+    that fetched a chain runs them back to back) leave exactly the state the oracle reaches with single steps -- stream
+    keys, warmup iteration number (the estimator's discount) and Adam state advance per transition.  More chains than
+    resident workgroups would not change anything here: every chain is its own work item."""
+    parity.run_case(model, D, 3, warmup=5, sampling=5, lib_path=sim, geometry=geometry, step=None, fused=3)
+
+
+@pytest.mark.timeout(600)
+def test_emulated_fused_transitions_write_every_draw_row(sim):
+    C_, D, T = 3, 10, 4
+    def engine():
+        e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, C_, wa.default_config(sim), lib_path=sim)
+        e.init_positions(5, 0, 2.0)
+        e.init_masses_from_grad(1e-5)
+        e.set_step_sizes(0.7)
+        e.seed_chains(6, 0)
+        return e
+    a, b = engine(), engine()
+    rows = np.full((C_, T, D), np.nan)
+    a.warmup_steps(T, rows.ctypes.data, T * D, D)
+    a.synchronize()
+    for k in range(T):
+        b.warmup_step()
+        b.synchronize()
+        assert np.array_equal(rows[:, k, :], b.positions()), k
+    a.freeze(); b.freeze()
+    planes = np.full((T, C_, D), np.nan)   # one [C][D] plane per transition (the bench's layout)
+    a.sample_steps(T, planes.ctypes.data, D, C_ * D)
+    a.synchronize()
+    for k in range(T):
+        b.sample_step()
+        b.synchronize()
+        assert np.array_equal(planes[k], b.positions()), k
+    assert a.iteration == b.iteration == 2 * T
+    assert np.array_equal(a.grad_evals(), b.grad_evals())
+    # host-fed variates cover one transition
+    b.set_variates(np.zeros((C_, D)), np.full((C_, 64), 0.5))
+    with pytest.raises(ValueError, match="one transition"):
+        b.sample_steps(2)
+    with pytest.raises(ValueError, match="at least 1"):
+        a.sample_steps(0)
+
+
 @pytest.mark.timeout(600)
 def test_emulated_engine_lds_pool_and_arena_paths(sim, oracle):
     # same chains with the span pool in LDS, split over LDS / HBM arena, in the arena only: identical results

@@ -84,6 +84,8 @@ SYMBOLS = [
     ("wn_engine_warmup_step", _i32, [_vp, _vp, _i64, _errpp]),
     ("wn_engine_freeze", _i32, [_vp, _errpp]),
     ("wn_engine_sample_step", _i32, [_vp, _vp, _i64, _errpp]),
+    ("wn_engine_warmup_steps", _i32, [_vp, _i32, _vp, _i64, _i64, _errpp]),
+    ("wn_engine_sample_steps", _i32, [_vp, _i32, _vp, _i64, _i64, _errpp]),
     ("wn_engine_synchronize", _i32, [_vp, _errpp]),
     ("wn_engine_check", _i32, [_vp, _errpp]),
     ("wn_engine_get_positions", _i32, [_vp, _dp, _errpp]),

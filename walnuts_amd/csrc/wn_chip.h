@@ -699,7 +699,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       vload_stream(Q.z_buf + row, rh[0]);
     } else {
       const uint64_t seed = Q.seed;
-      const uint32_t key_chain = Q.chain_offset + chain, key_tr = Q.transition;
+      const uint32_t key_chain = Q.chain_offset + chain, key_tr = this->transition_now();
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const uint32_t pair = static_cast<uint32_t>(k * L + tid);
@@ -755,7 +755,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     vstore_stream(Q.theta + row, th[0]);
     double* draws = Q.draws_out;
     if (WN_LIKELY(draws != nullptr)) {
-      double* out = draws + static_cast<long long>(chain) * Q.draws_stride;
+      double* out = this->draw_row();
       // an unpadded row on a 16-byte boundary takes the pair stores; anything else goes element by element
       if (WN_LIKELY(P.dim == kDp && ((reinterpret_cast<unsigned long long>(out) & 15ull) == 0ull))) {
         vstore_stream(out, th[0]);
@@ -772,7 +772,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       const long long keep_grad = n_grad;
       (void)model_eval<0>();
       n_grad = keep_grad;
-      const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(Q.warmup_iter));
+      const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(this->warmup_iter_now()));
       const double wd = discount * w_draw0 + 1;
       const double ws = discount * w_score0 + 1;
 #pragma unroll

@@ -159,7 +159,7 @@ struct wn_engine {
     warmup_iter = 0;
   }
 
-  wn::Params make_params(bool warm, double* draws_dev, int64_t draws_stride) {
+  wn::Params make_params(bool warm, double* draws_dev, int64_t draws_stride, int fused = 1, int64_t draws_tstride = 0) {
     wn::Params P{};
     P.num_chains = static_cast<int32_t>(C);
     P.dim = D;
@@ -184,6 +184,8 @@ struct wn_engine {
     P.lp_stats = lp_stats.p;
     P.draws_out = draws_dev;
     P.draws_stride = draws_stride;
+    P.draws_tstride = draws_tstride;
+    P.fused = fused;
     P.model_params = model_params.p;
     P.max_depth = cfg.max_trajectory_doublings;
     P.max_halvings = cfg.max_step_halvings;
@@ -218,10 +220,15 @@ struct wn_engine {
   void feed_reference_streams();
   void advance_reference_streams();
 
-  void step(bool warm, double* draws_dev, int64_t draws_stride) {
+  // One launch = `fused` transitions of every chain, back to back on the workgroup that fetched the chain (the chain's
+  // k-th draw row at draws_dev + chain * draws_stride + k * draws_tstride).  Host-fed variates cover one transition.
+  void step(bool warm, double* draws_dev, int64_t draws_stride, int fused = 1, int64_t draws_tstride = 0) {
+    if (fused < 1) throw std::invalid_argument("transitions per launch must be at least 1");
+    if (fused > 1 && (ref_streams || variates_pending))
+      throw std::invalid_argument("host-fed variates cover one transition: transitions per launch must be 1");
     use_device();
     if (ref_streams) feed_reference_streams();
-    wn::Params P = make_params(warm, draws_dev, draws_stride);
+    wn::Params P = make_params(warm, draws_dev, draws_stride, fused, draws_tstride);
     // The chain counter is never reset: every launch performs exactly C fetches (one per processed chain), so launch n
     // starts at n * C (mod 2^32) -- one memset per transition less between two kernels.
     P.work_base = work_base;
@@ -238,9 +245,9 @@ struct wn_engine {
     }
     ++region_launches;
     variates_pending = false;
-    ++transition;
-    ++iteration;
-    if (warm) ++warmup_iter;
+    transition += static_cast<uint32_t>(fused);
+    iteration += fused;
+    if (warm) warmup_iter += fused;
     if (ref_streams) advance_reference_streams();
   }
 };
@@ -601,6 +608,15 @@ int wn_engine_warmup_step(wn_engine* e, double* draws_dev, int64_t draws_stride,
     e->step(true, draws_dev, draws_stride);
   });
 }
+int wn_engine_warmup_steps(wn_engine* e, int transitions, double* draws_dev, int64_t draws_stride,
+                           int64_t draws_transition_stride, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e == nullptr) throw std::invalid_argument("null argument");
+    if (e->frozen) throw std::runtime_error("warmup_step after freeze");
+    e->ensure_adapters();
+    e->step(true, draws_dev, draws_stride, transitions, draws_transition_stride);
+  });
+}
 int wn_engine_freeze(wn_engine* e, WalnutpyError** err) {
   return guarded(err, [&] {
     if (e == nullptr) throw std::invalid_argument("null argument");
@@ -621,6 +637,14 @@ int wn_engine_sample_step(wn_engine* e, double* draws_dev, int64_t draws_stride,
   return guarded(err, [&] {
     if (!e->frozen) throw std::runtime_error("sample_step before freeze");
     e->step(false, draws_dev, draws_stride);
+  });
+}
+int wn_engine_sample_steps(wn_engine* e, int transitions, double* draws_dev, int64_t draws_stride,
+                           int64_t draws_transition_stride, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e == nullptr) throw std::invalid_argument("null argument");
+    if (!e->frozen) throw std::runtime_error("sample_step before freeze");
+    e->step(false, draws_dev, draws_stride, transitions, draws_transition_stride);
   });
 }
 int wn_engine_synchronize(wn_engine* e, WalnutpyError** err) {

@@ -103,13 +103,23 @@ __device__ __forceinline__ double fetch(const ParkedDouble& a) {
   return double_of((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
-// The lane identity behind an optimisation barrier: whatever is computed from it is rebuilt where it is used
-// instead of being hoisted to the kernel entry and held for the whole kernel.
-__device__ __forceinline__ int opaque_thread_id() {
-  int t = threadIdx.x;
-  asm volatile("" : "+v"(t));
-  return t;
+// The lane's index within its wavefront, COMPUTED where it is asked for (v_mbcnt_lo/hi on an all-ones mask: two VALU
+// instructions, independent of EXEC): whatever is derived from it -- addresses, padding masks, counter words -- is rebuilt
+// at the use instead of being hoisted to the kernel entry and held for the whole kernel.  Deliberately NOT threadIdx.x:
+// that value arrives in v0 and nothing can recompute it, so a kernel that reads it late keeps a VGPR alive from the
+// entry to the last use -- across every divergent region of the transition.  With one wavefront per SIMD the allocator
+// parks such a register in the accumulator file and reloads it where it sees fit, and a reload it places INSIDE a
+// region that runs under a partial EXEC mask restores the active lanes only (seen with rocgdb in the funnel (4,4)
+// warmup kernel: v0 = {0, garbage x 63} after a reload inside an `if (lane == 0)` block, then a fault on the first
+// address derived from it).  The wavefront's index within the workgroup is wave-uniform and lives in an SGPR, whose
+// spills (v_writelane / v_readlane) do not depend on EXEC.
+__device__ __forceinline__ int opaque_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
 }
+// the wavefront's index within its workgroup, read once at the kernel entry (wave-uniform: a scalar register)
+__device__ __forceinline__ int wave_in_workgroup() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
 
 // The kernel's single by-value argument struct, read back from the kernel-argument segment behind an optimisation
 // barrier: fields used once or twice per transition are then fetched where they are used (s_load) instead of being

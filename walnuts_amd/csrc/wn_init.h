@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
   P.dim_padded = Q.dim_padded;
   P.model_params = Q.model_params;
   WN_LDS double* base = (WN_LDS double*)smem;
-  WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(base + (threadIdx.x >> 6) * kMetaDoubles);
+  WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(base + wave_in_workgroup() * kMetaDoubles);
   WN_LDS double* red = base + NW * kMetaDoubles;
   WN_LDS double* bcast = red + kRedDoubles(NW);
   T t(P, base, meta, red, bcast, nullptr);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * NW) void init_kernel_mem(const InitParams Q) {
   P.dim_padded = Q.dim_padded;
   P.model_params = Q.model_params;
   WN_LDS double* base = (WN_LDS double*)smem;
-  WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(base + (threadIdx.x >> 6) * kMetaDoubles);
+  WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(base + wave_in_workgroup() * kMetaDoubles);
   WN_LDS double* red = base + NW * kMetaDoubles;
   WN_LDS double* bcast = red + kRedDoubles(NW);
   double* rho0 = Q.scratch + static_cast<long long>(blockIdx.x) * Q.scratch_stride;

@@ -47,8 +47,9 @@ struct Params {
   int32_t* rng_draws;  // [C] scalar draws of the last transition
   double* lp_stats;    // [C][3] WelfordAccumulator (count, mean, M2) of the sampling log densities
   // output of this transition
-  double* draws_out;   // nullable; row c at draws_out + c*draws_stride, D doubles
+  double* draws_out;   // nullable; chain c's row of the launch's k-th transition at draws_out + c*draws_stride + k*draws_tstride
   int64_t draws_stride;
+  int64_t draws_tstride;
   // model
   const double* model_params; // DIAG_NORMAL: sigma_sq [Dp] (padding = 1.0)
   // configuration (SamplingConfig / WarmupConfig)
@@ -74,7 +75,7 @@ struct Params {
   int64_t arena_stride;  // doubles per slot
   int32_t pool_lds;      // vector buffers living in LDS
   int32_t pool_total;    // LDS + arena buffers
-  int32_t pad1;
+  int32_t fused;         // transitions per launch (>= 1): a workgroup runs them back to back on the chain it fetched
   uint32_t* work_counter;  // chains fetched so far by all launches of this engine (mod 2^32; never reset)
   uint32_t work_base;      // its value when this launch starts
   uint32_t pad2;

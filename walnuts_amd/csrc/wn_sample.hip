@@ -203,10 +203,12 @@ class DrawSink {
     }
     return block_[cur_].p + fill_ * D_;
   }
-  // the iteration launched into next_row() is queued on the compute stream
-  void row_done() {
-    ++fill_;
-    ++written_;
+  // how many consecutive iterations the current block still takes (a multi-transition launch writes that many rows)
+  size_t room() const { return span_ - fill_; }
+  // the `n` iterations launched into next_row() (rows D doubles apart) are queued on the compute stream
+  void rows_done(size_t n) {
+    fill_ += n;
+    written_ += n;
     if (fill_ == span_) flush();
   }
   size_t written() const { return written_; }
@@ -357,6 +359,8 @@ struct PhaseTimer {
     t0 = t1;
   }
 };
+
+constexpr int kMaxFusedTransitions = 8;  // transitions per launch between two looks of a controller
 
 struct ResidentRequest {  // walnutpie_sample_device_resident
   int thin;
@@ -528,16 +532,28 @@ static int sample_device_impl(
     RunAhead pace(compute);
     timer.mark("output pinned, draw sink ready");
     Printer printer{print, static_cast<size_t>(refresh)};
-    for (int it = 1; it <= max_warmup_iter; ++it) {  // AdaptWorker loop, adapt.hpp:116-127
+    // Consecutive iterations between two looks of a controller go out as ONE launch (wn_engine_*_steps: the workgroup
+    // that fetched a chain runs them back to back -- the chains are independent, adapt.hpp:116-127 / sampler.hpp:82-93
+    // are per-chain loops): the launch and its tail, the last chains finishing while the chip drains, are paid once
+    // per launch.  Host-fed reference streams cover one transition per launch.
+    const int fuse_limit = reference_streams ? 1 : kMaxFusedTransitions;
+    constexpr int publish_stride = 5;  // adapt.hpp: snapshots every 5 iterations
+    for (int it = 0; it < max_warmup_iter;) {  // AdaptWorker loop, adapt.hpp:116-127
       interrupt.throw_if_interrupted();
       pace.before_enqueue();
+      int n = std::min({fuse_limit, max_warmup_iter - it, publish_stride - it % publish_stride});
+      if (save_warmup) n = static_cast<int>(std::min<size_t>(static_cast<size_t>(n), sink.room()));
       double* dst = save_warmup ? sink.next_row() : nullptr;
-      WN_CALL(wn_engine_warmup_step(e, dst, static_cast<int64_t>(sink.stride()), &call_err_));
-      if (save_warmup) sink.row_done();
+      WN_CALL(wn_engine_warmup_steps(e, n, dst, static_cast<int64_t>(sink.stride()), static_cast<int64_t>(D), &call_err_));
+      if (save_warmup) sink.rows_done(static_cast<size_t>(n));
       pace.after_enqueue();
-      printer.progress(num_chains);
+      for (int k = 0; k < n; ++k) {  // (a Ctrl-C raised from inside a progress callback ends the call at once)
+        printer.progress(num_chains);
+        interrupt.throw_if_interrupted();
+      }
+      it += n;
       // controller_loop (adapt.hpp:172-229) on the snapshots published every publish_stride = 5 iterations
-      if (it >= min_warmup_iter && it < max_warmup_iter && it % 5 == 0) {
+      if (it >= min_warmup_iter && it < max_warmup_iter && it % publish_stride == 0) {
         double rel_step = 0, rel_mass = 0;
         WN_CALL(wn_engine_warmup_spread(e, &rel_step, &rel_mass, &call_err_));
         if (rel_mass <= mass_converge_tol && rel_step <= step_size_converge_tol) break;
@@ -551,26 +567,37 @@ static int sample_device_impl(
     if (stepsize_out != nullptr) WN_CALL(wn_engine_get_step_sizes(e, stepsize_out, &call_err_));
     if (inv_metric_out != nullptr) WN_CALL(wn_engine_get_inv_mass(e, inv_metric_out, &call_err_));
     size_t sampled = 0;
-    for (int it = 1; it <= max_sampling_iter; ++it) {  // ChainWorker loop, sampler.hpp:82-93
+    // controller_loop (sampler.hpp:117-158): R-hat of the log density once every chain has min_iter draws.  The
+    // reference's controller looks on a 1 ms timer, not after every draw: here every `rhat_stride` iterations
+    // (each look is a handful of small launches and a blocking read-back that would otherwise serialise every
+    // transition with the host).
+    constexpr int rhat_stride = 5;
+    const auto controller_looks_after = [&](int it) {
+      return it >= min_sampling_iter && it >= 2 && it < max_sampling_iter && num_chains > 1 &&
+             (it - min_sampling_iter) % rhat_stride == 0;
+    };
+    for (int it = 0; it < max_sampling_iter;) {  // ChainWorker loop, sampler.hpp:82-93
       interrupt.throw_if_interrupted();
       pace.before_enqueue();
+      int n = 1;  // up to the controller's next look
+      while (n < fuse_limit && it + n < max_sampling_iter && !controller_looks_after(it + n)) ++n;
       if (kept) {
-        WN_CALL(wn_engine_sample_step(e, kept->next_row(), kept->stride(), &call_err_));
-        kept->row_done();
+        WN_CALL(wn_engine_sample_steps(e, n, kept->next_row(), kept->stride(), static_cast<int64_t>(D), &call_err_));
+        for (int k = 0; k < n; ++k) kept->row_done();
       } else {
-        WN_CALL(wn_engine_sample_step(e, sink.next_row(), static_cast<int64_t>(sink.stride()), &call_err_));
-        sink.row_done();
+        n = static_cast<int>(std::min<size_t>(static_cast<size_t>(n), sink.room()));
+        WN_CALL(wn_engine_sample_steps(e, n, sink.next_row(), static_cast<int64_t>(sink.stride()), static_cast<int64_t>(D),
+                                       &call_err_));
+        sink.rows_done(static_cast<size_t>(n));
       }
-      ++sampled;
+      sampled += static_cast<size_t>(n);
       pace.after_enqueue();
-      printer.progress(num_chains);
-      // controller_loop (sampler.hpp:117-158): R-hat of the log density once every chain has min_iter draws.  The
-      // reference's controller looks on a 1 ms timer, not after every draw: here every `rhat_stride` iterations
-      // (each look is a handful of small launches and a blocking read-back that would otherwise serialise every
-      // transition with the host).
-      constexpr int rhat_stride = 5;
-      if (it >= min_sampling_iter && it >= 2 && it < max_sampling_iter && num_chains > 1 &&
-          (it - min_sampling_iter) % rhat_stride == 0) {
+      for (int k = 0; k < n; ++k) {  // (a Ctrl-C raised from inside a progress callback ends the call at once)
+        printer.progress(num_chains);
+        interrupt.throw_if_interrupted();
+      }
+      it += n;
+      if (controller_looks_after(it)) {
         double rhat = 0;
         WN_CALL(wn_engine_rhat(e, &rhat, &call_err_));
         if (print != nullptr && refresh != 0) {

@@ -199,9 +199,9 @@ struct TrajBase {
   __device__ __forceinline__ TrajBase(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
                                       WN_LDS double* bc, double* ar)
       : P(p), lds_pool(pool), meta(m), red(r), bcast(bc), arena(ar) {
-    tid = threadIdx.x;
-    lane = tid & 63;
-    wave = tid >> 6;
+    wave = NW == 1 ? 0 : wave_in_workgroup();
+    lane = opaque_lane_id();
+    tid = (wave << 6) | lane;
     Dp = p.dim_padded;
     red_parity = 0;
     carry = 0.0;
@@ -210,6 +210,8 @@ struct TrajBase {
     tabs.load(lane);
     adam_err = 0.0;
     adam_n = 0;
+    fuse_t = 0;
+    fetched = 0;
   }
 
 #if defined(WN_TIMELINE)
@@ -243,7 +245,17 @@ struct TrajBase {
   // loads have been consumed (memory operations retire in order: issued any earlier, the atomic's 1-2 us round trip
   // would stand in front of them), and is collected by persistent_loop after the transition.
   int fetched;
+  // Which of the launch's back-to-back transitions of this chain is running (Params::fused): it offsets the stream
+  // keys, the warmup iteration number and the draw row.
+  int fuse_t;
+  __device__ __forceinline__ uint32_t transition_now() const { return cold().transition + static_cast<uint32_t>(fuse_t); }
+  __device__ __forceinline__ long long warmup_iter_now() const { return cold().warmup_iter + fuse_t; }
+  __device__ __forceinline__ double* draw_row() const {
+    const auto& Q = cold();
+    return Q.draws_out + static_cast<long long>(chain) * Q.draws_stride + fuse_t * Q.draws_tstride;
+  }
   __device__ __forceinline__ void prefetch_next_chain() {
+    if (fuse_t + 1 < cold().fused) return;  // the chain stays for another transition
     fetched = 0;
     if (tid == 0) fetched = static_cast<int>((atomicAdd(P.work_counter, 1u) - P.work_base) + gridDim.x);
   }
@@ -252,10 +264,8 @@ struct TrajBase {
   // masks, the counter words of the random stream) is then rebuilt where it is used instead of being hoisted out
   // of the persistent chain loop to the kernel entry and held -- or spilled -- for the whole kernel.
   __device__ __forceinline__ void refresh_ids() {
-    const int t = opaque_thread_id();
-    tid = t;
-    lane = t & 63;
-    wave = uni(t >> 6);
+    lane = opaque_lane_id();
+    tid = (wave << 6) | lane;
   }
 
   // ---- reductions -----------------------------------------------------------------
@@ -400,7 +410,7 @@ struct TrajBase {
     if (WN_UNLIKELY(Q.rng_mode == kRngBuffer)) {
       u = j < Q.u_stride ? Q.u_buf[static_cast<long long>(chain) * Q.u_stride + j] : 0.5;
     } else {
-      u = wnd::stream_uniform(Q.seed, Q.chain_offset + chain, Q.transition, wnd::kStreamTree,
+      u = wnd::stream_uniform(Q.seed, Q.chain_offset + chain, transition_now(), wnd::kStreamTree,
                               static_cast<uint32_t>(j));
     }
     // every lane takes part in the table gather; a host-fed uniform may be anything, the generator's is a normal number
@@ -549,7 +559,7 @@ struct TrajBase {
     if (tid == 0) {
       const auto& Q = cold();
       if (warm) {
-        const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(Q.warmup_iter));
+        const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(warmup_iter_now()));
         Q.est_weight[2 * chain] = discount * w_draw0 + 1;
         Q.est_weight[2 * chain + 1] = discount * w_score0 + 1;
         if constexpr (Self::kParkScalars) {
@@ -1274,7 +1284,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
         z2[0] = z0[0];
         z2[1] = z0[1];
       } else {
-        wnd::stream_normal_pair(P.seed, P.chain_offset + chain, P.transition, wnd::kStreamMomentum,
+        wnd::stream_normal_pair(P.seed, P.chain_offset + chain, this->transition_now(), wnd::kStreamMomentum,
                                 static_cast<uint32_t>(k * L + tid), z2[0], z2[1], this->gather_tab());
       }
       double rh2[2];
@@ -1327,14 +1337,14 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     if constexpr (kTwoPass) {
       if (warm) aux_of(sel, aux_sel);  // the estimator wants the gradient at the selected position
     }
-    const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(P.warmup_iter));
+    const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(this->warmup_iter_now()));
     const double wd = discount * w_draw0 + 1, ws = discount * w_score0 + 1;
     for (int k = 0; k < tiles; ++k) {
       const int o = pair_offset(k);
       const v2f64 t0 = ld(sel + o);
       st(P.theta + row + o, t0[0], t0[1]);
       if (P.draws_out != nullptr) {
-        double* out = P.draws_out + static_cast<long long>(chain) * P.draws_stride;
+        double* out = this->draw_row();
         if (o < P.dim) out[o] = t0[0];
         if (o + 1 < P.dim) out[o + 1] = t0[1];
       }
@@ -1391,7 +1401,7 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   // broadcast word
   WN_LDS double* pool = (WN_LDS double*)smem;
   WN_LDS double* tail = pool + P.pool_lds * P.dim_padded;
-  WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(tail + (threadIdx.x >> 6) * kMetaDoubles);
+  WN_LDS typename T::Meta* meta = (WN_LDS typename T::Meta*)(tail + (NW == 1 ? 0 : wave_in_workgroup()) * kMetaDoubles);
   WN_LDS double* red = tail + NW * kMetaDoubles;
   WN_LDS double* bcast = red + kRedDoubles(NW);
   WN_LDS int* next_chain = (WN_LDS int*)(bcast + 1);  // (the shift scratch of TrajChip follows at bcast + 2)
@@ -1405,12 +1415,20 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   int slot = 0;
   while (WN_LIKELY(c < P.num_chains)) {
     WN_PHASE_OUTER(kPhIdle);
-    t.run(c);  // issues t.prefetch_next_chain() on the way
+    // (Params::fused transitions of the chain back to back; the last one issues t.prefetch_next_chain() on the way)
+    int k = 0;
+    do {
+      // what the chain's transition wrote (planes by every lane, scalars by thread 0) is read back by the next one:
+      // program order within a wavefront, a workgroup barrier between wavefronts
+      if (NW > 1 && k > 0) __syncthreads();
+      t.fuse_t = k;
+      t.run(c);
+    } while (++k < kernel_argument(P).fused);
     if (NW == 1) {
       c = uni(t.fetched);
     } else {
       // two alternating words: a wavefront that races ahead to the next hand-over writes the other one
-      if (threadIdx.x == 0) next_chain[slot] = t.fetched;
+      if (t.wave == 0 && opaque_lane_id() == 0) next_chain[slot] = t.fetched;
       __syncthreads();
       c = uni(next_chain[slot]);
       slot ^= 1;

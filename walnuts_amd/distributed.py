@@ -25,9 +25,14 @@ class DrawGather:
 
     Rank r writes its shard's draws into `buffer(it)` ([rows, D]; rows = the largest shard, so that every rank
     contributes an equally sized block -- `all_gather_into_tensor` needs that -- and uneven shards cost only padding
-    rows).  `result(it)` is the gathered [total_chains, D] block in global chain order."""
+    rows).  `result(it)` is the gathered [total_chains, D] block in global chain order.
 
-    def __init__(self, dist, world: int, rank: int, total_chains: int, dim: int, device, dtype, counts=None):
+    transitions > 1: one launch produces that many consecutive draw planes (wn_engine_sample_steps); `buffer(it)` is
+    then [transitions, rows, D], ONE collective moves the whole block (fewer, larger exchanges) and `result(it)` is
+    [transitions, total_chains, D]."""
+
+    def __init__(self, dist, world: int, rank: int, total_chains: int, dim: int, device, dtype, counts=None,
+                 transitions: int = 1):
         import torch
 
         self.dist, self.world, self.rank = dist, world, rank
@@ -35,8 +40,13 @@ class DrawGather:
                                                                 for r in range(world)]
         self.rows = max(self.counts)
         self.even = all(c == self.rows for c in self.counts)
-        self.local = [torch.empty((self.rows, dim), dtype=dtype, device=device) for _ in range(2)]
-        self.gathered = ([torch.empty((world * self.rows, dim), dtype=dtype, device=device) for _ in range(2)]
+        self.transitions = int(transitions)
+        if self.transitions < 1:
+            raise ValueError("transitions per launch must be at least 1")
+        block = (self.rows, dim) if self.transitions == 1 else (self.transitions, self.rows, dim)
+        self.local = [torch.empty(block, dtype=dtype, device=device) for _ in range(2)]
+        # (every rank's block concatenated along the first axis: [world * T, rows, D] or [world * rows, D])
+        self.gathered = ([torch.empty((world * block[0],) + block[1:], dtype=dtype, device=device) for _ in range(2)]
                          if world > 1 else None)
         self.pending: List[Optional[object]] = [None, None]
 
@@ -49,7 +59,8 @@ class DrawGather:
         return self.local[b]
 
     def launch(self, it: int):
-        """Start gathering iteration `it`'s draws; overlaps the next transition."""
+        """Start gathering iteration `it`'s draws (the whole block of a multi-transition launch); overlaps the next
+        launch."""
         if self.world == 1:
             return None
         b = it & 1
@@ -64,6 +75,11 @@ class DrawGather:
         if self.pending[b] is not None:
             self.pending[b].wait()
             self.pending[b] = None
+        if self.transitions > 1:   # [world * T, rows, D] -> [T, total_chains, D]
+            if self.world == 1:
+                return self.local[b][:, : self.counts[0]]
+            g = self.gathered[b].view(self.world, self.transitions, self.rows, -1)
+            return torch.cat([g[r, :, :c] for r, c in enumerate(self.counts)], dim=1)
         if self.world == 1:
             return self.local[b][: self.counts[0]]
         if self.even:

@@ -122,6 +122,15 @@ class DeviceEngine:
     def sample_step(self, draws_ptr: Optional[int] = None, stride: int = 0):
         self._call(self.lib.wn_engine_sample_step, C.c_void_p(draws_ptr), stride)
 
+    def warmup_steps(self, transitions: int, draws_ptr: Optional[int] = None, stride: int = 0, transition_stride: int = 0):
+        """`transitions` warmup transitions of every chain in one launch (same bits as as many warmup_step calls);
+        chain c's k-th position at draws_ptr + c*stride + k*transition_stride doubles."""
+        self._call(self.lib.wn_engine_warmup_steps, int(transitions), C.c_void_p(draws_ptr), stride, transition_stride)
+
+    def sample_steps(self, transitions: int, draws_ptr: Optional[int] = None, stride: int = 0, transition_stride: int = 0):
+        """`transitions` sampling transitions of every chain in one launch (same bits as as many sample_step calls)."""
+        self._call(self.lib.wn_engine_sample_steps, int(transitions), C.c_void_p(draws_ptr), stride, transition_stride)
+
     def synchronize(self):
         self._call(self.lib.wn_engine_synchronize)
 

@@ -20,7 +20,7 @@ wa.walnuts_device(wa.MODEL_STD_NORMAL, num_params=8, num_chains=4, seed=1, min_w
                   min_sampling_iter=2, max_sampling_iter=2)
 ref = None
 for label, env, extra in (("host buffer, pageable (default)", {"WALNUTS_AMD_PIN_OUTPUT": "0"}, {}),
-                          ("host buffer, WALNUTS_AMD_PIN_OUTPUT=1", {"WALNUTS_AMD_PIN_OUTPUT": "1"}, {}),
+                          ("host buffer, WALNUTS_AMD_PIN_OUTPUT=1 (registered beside the streams)", {"WALNUTS_AMD_PIN_OUTPUT": "1"}, {}),
                           ("resident, every 8th draw to the host", {}, dict(keep_on_device=True, thin=8)),
                           ("resident, no draw to the host", {}, dict(keep_on_device=True, thin=0))):
     os.environ.update(env)
@@ -31,7 +31,7 @@ for label, env, extra in (("host buffer, pageable (default)", {"WALNUTS_AMD_PIN_
     if isinstance(res, tuple):
         res, chains = res
     moved = sum(r.nbytes for r in res)
-    line = (f"{label:42s} {dt:7.2f} s  = {C * (W + S) / dt:10.3e} transitions/s; {S * C / dt:10.3e} draws/s; "
+    line = (f"{label:70s} {dt:7.2f} s  = {C * (W + S) / dt:10.3e} transitions/s; {S * C / dt:10.3e} draws/s; "
             f"D2H {moved / 2**30:6.2f} GiB ({moved / dt / 1e9:5.1f} GB/s of the call's wall time)")
     if chains is not None:
         t1 = time.perf_counter()

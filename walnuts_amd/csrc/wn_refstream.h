@@ -8,10 +8,15 @@
 // plain loop over std::normal_distribution is 2.6 s per stream: 5.3 of the 5.7 s of a whole 52-iteration call
 // (profiles/r03/sample_device_e2e.txt).
 //
-// Same numbers, split in two passes.  Pass 1 is the sequential part and nothing else: the engine, the two canonical
-// uniforms per attempt, the rejection test -- it records (x, y, r2) of every ACCEPTED attempt (~5 ns per normal).
-// Pass 2, sqrt(-2 log(r2) / r2) and the two products, is a pure function of one record and runs on every core the
-// process may use, chunk by chunk, while pass 1 is already producing the next chunk.
+// Same numbers, with ONLY the engine sequential.  Every attempt of the polar method consumes exactly two engine outputs
+// whether it is accepted or not, so attempt k reads outputs 2k and 2k+1 whatever happened before it.  The calling
+// thread does nothing but run the engine into blocks of raw 64-bit outputs (~1.5 ns each).  Workers take a block each:
+// phase A evaluates the rejection test of its attempts and counts the accepted ones; the caller, scanning the blocks in
+// order, turns the counts into the index of each block's first accepted attempt in the whole stream; phase B evaluates
+// sqrt(-2 log(r2) / r2) and the two products of every accepted attempt and writes them where the j-th accepted attempt of
+// the stream belongs -- a closed form of j, for one distribution shared by all chains as for a fresh one per chain.
+// (Round 3's first version ran the rejection test on the calling thread too: ~10 ns per normal, 0.8 s per stream at the
+// headline size; this one ~2.5 ns.)
 //
 // libstdc++ (bits/random.tcc, normal_distribution::operator()):
 //     do { x = 2 * canonical() - 1; y = 2 * canonical() - 1; r2 = x * x + y * y; } while (r2 > 1 || r2 == 0);
@@ -21,6 +26,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -36,8 +42,8 @@
 
 namespace wnref {
 
-inline double canonical(std::mt19937_64& eng) {
-  const double u = static_cast<double>(eng()) * 0x1p-64;  // (an exact scaling: what sum / 2^64 computes)
+inline double canonical(uint64_t engine_output) {
+  const double u = static_cast<double>(engine_output) * 0x1p-64;  // (an exact scaling: what sum / 2^64 computes)
   return u >= 1.0 ? std::nextafter(1.0, 0.0) : u;
 }
 
@@ -103,77 +109,75 @@ class Workers {
   bool stop_ = false;
 };
 
-// One accepted attempt of the polar method and where its (up to) two normals go.
-struct Accepted {
-  double x, y, r2;
-  double* first;   // receives y * mult (the value the distribution returns first); never null
-  double* second;  // receives x * mult (the saved value), or null when the distribution is discarded before using it
-};
-
-inline void finish_records(const Accepted* rec, size_t n, double scale) {
-  for (size_t i = 0; i < n; ++i) {
-    const double mult = std::sqrt(-2 * std::log(rec[i].r2) / rec[i].r2);
-    *rec[i].first = ((rec[i].y * mult) * 1.0 + 0.0) * scale;
-    if (rec[i].second != nullptr) *rec[i].second = ((rec[i].x * mult) * 1.0 + 0.0) * scale;
+// `chains` x `count` values of the reference's stream over `eng`, times `scale` (the caller's `x *= scale`, exact for
+// scale 1), to out[chains][count].  fresh_per_chain = false: ONE std::normal_distribution<double> serves all chains (a
+// saved second variate crosses chain boundaries, config.hpp:259-268); true: a new distribution per chain (util.hpp:288: a
+// saved variate is dropped at the boundary).  The engine is run AHEAD in blocks: it is left in a later state than the
+// plain loops would leave it (the callers' engines live for one stream).  Returns when every value is written.
+inline void polar_stream_fill(std::mt19937_64& eng, Workers& pool, double scale, size_t chains, size_t count,
+                              bool fresh_per_chain, double* out) {
+  const size_t total = chains * count;
+  if (total == 0) return;
+  const size_t per_chain = (count + 1) / 2;  // accepted attempts a chain with its own distribution consumes
+  const size_t needed = fresh_per_chain ? chains * per_chain : (total + 1) / 2;
+  constexpr size_t kAttempts = size_t{1} << 15;  // per block: 64 Ki engine outputs, 512 KB
+  struct Block {
+    std::vector<uint64_t> raw;
+    std::vector<uint32_t> accepted;  // attempts of this block that pass the rejection test, in order
+    std::atomic<bool> tested{false};
+  };
+  const auto xy = [](const Block& b, uint32_t k, double& x, double& y, double& r2) {
+    x = 2.0 * canonical(b.raw[2 * k]) - 1.0;
+    y = 2.0 * canonical(b.raw[2 * k + 1]) - 1.0;
+    r2 = x * x + y * y;
+  };
+  const size_t depth = 2 * static_cast<size_t>(usable_threads()) + 2;  // blocks between the engine and the scan
+  std::deque<std::shared_ptr<Block>> in_flight;
+  size_t first = 0;  // accepted attempts of the stream before the block at the front
+  while (first < needed) {
+    while (in_flight.size() < depth) {
+      auto b = std::make_shared<Block>();
+      b->raw.resize(2 * kAttempts);
+      for (auto& r : b->raw) r = eng();  // the sequential part, and nothing else
+      pool.submit([b, xy] {  // phase A
+        b->accepted.reserve(kAttempts);
+        for (uint32_t k = 0; k < kAttempts; ++k) {
+          double x, y, r2;
+          xy(*b, k, x, y, r2);
+          if (!(r2 > 1.0 || r2 == 0.0)) b->accepted.push_back(k);
+        }
+        b->tested.store(true, std::memory_order_release);
+      });
+      in_flight.push_back(std::move(b));
+    }
+    std::shared_ptr<Block> b = in_flight.front();
+    in_flight.pop_front();
+    while (!b->tested.load(std::memory_order_acquire)) std::this_thread::yield();
+    const size_t take = std::min(b->accepted.size(), needed - first);
+    const size_t base = first;
+    pool.submit([=] {  // phase B: accepted attempt j = base + t of the stream
+      for (size_t t = 0; t < take; ++t) {
+        double x, y, r2;
+        xy(*b, b->accepted[t], x, y, r2);
+        const double mult = std::sqrt(-2 * std::log(r2) / r2);
+        const size_t j = base + t;
+        double* o;
+        bool second;
+        if (fresh_per_chain) {
+          const size_t c = j / per_chain, k = j % per_chain;
+          o = out + c * count + 2 * k;
+          second = 2 * k + 1 < count;
+        } else {
+          o = out + 2 * j;
+          second = 2 * j + 1 < total;
+        }
+        o[0] = ((y * mult) * 1.0 + 0.0) * scale;
+        if (second) o[1] = ((x * mult) * 1.0 + 0.0) * scale;
+      }
+    });
+    first += b->accepted.size();
   }
+  pool.wait_idle();  // (blocks tested beyond the end of the stream are dropped with their last reference)
 }
-
-// `count` standard normals of ONE std::normal_distribution<double> over `eng`, written to out[0 .. count) times
-// `scale` (the caller's `x *= scale`, exact for scale 1).  `carry`: a saved second variate of an earlier call on the
-// same distribution object goes to out[0] first (its record was submitted by that call).  Returns, through `carry`,
-// whether this call leaves a saved variate for the next one, and in that case where it must be delivered.
-// Records are handed to `pool` in chunks; the caller waits for the pool before reading `out`.
-class PolarStream {
- public:
-  PolarStream(std::mt19937_64& eng, Workers& pool, double scale) : eng_(eng), pool_(pool), scale_(scale) { fresh_chunk(); }
-  ~PolarStream() { flush(); }
-  // the next `count` values of the distribution go to out[0 .. count)
-  void fill(double* out, size_t count) {
-    size_t i = 0;
-    if (saved_ != nullptr && count > 0) {  // the distribution holds a saved variate: it is the next value
-      saved_->second = out;
-      saved_ = nullptr;
-      i = 1;
-    }
-    for (; i < count; i += 2) {
-      double x, y, r2;
-      do {
-        x = 2.0 * canonical(eng_) - 1.0;
-        y = 2.0 * canonical(eng_) - 1.0;
-        r2 = x * x + y * y;
-      } while (r2 > 1.0 || r2 == 0.0);
-      chunk_->push_back(Accepted{x, y, r2, out + i, i + 1 < count ? out + i + 1 : nullptr});
-      if (i + 1 >= count) saved_ = &chunk_->back();  // one value left over in the distribution
-      else if (chunk_->size() >= kChunk) flush();
-    }
-  }
-  // a new distribution object over the same engine (util.hpp:288): a saved variate is dropped
-  void reset_distribution() { saved_ = nullptr; }
-  void flush() {
-    if (chunk_->empty()) return;
-    if (saved_ != nullptr) return;  // its destination is not known yet: the chunk leaves with the next flush
-    std::shared_ptr<std::vector<Accepted>> c = chunk_;
-    const double scale = scale_;
-    pool_.submit([c, scale] { finish_records(c->data(), c->size(), scale); });
-    fresh_chunk();
-  }
-  // the stream ends here: a saved variate that nobody will ask for is dropped, everything recorded is handed over
-  void finish() {
-    saved_ = nullptr;
-    flush();
-  }
-
- private:
-  static constexpr size_t kChunk = size_t{1} << 16;
-  void fresh_chunk() {
-    chunk_ = std::make_shared<std::vector<Accepted>>();
-    chunk_->reserve(kChunk + 1);
-  }
-  std::mt19937_64& eng_;
-  Workers& pool_;
-  double scale_;
-  std::shared_ptr<std::vector<Accepted>> chunk_;
-  Accepted* saved_ = nullptr;  // record whose x * mult is the distribution's saved variate (lives in *chunk_)
-};
 
 }  // namespace wnref

@@ -21,6 +21,7 @@
 #include <csignal>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <iomanip>
 #include <memory>
 #include <random>
@@ -141,12 +142,14 @@ struct Stream {
   }
 };
 // The caller's output buffer, page-locked for the duration of the call (opt-in: WALNUTS_AMD_PIN_OUTPUT=1).  A
-// device-to-host copy into pageable memory goes through the runtime's bounce buffers and blocks the host thread;
-// into registered memory it is a DMA that overlaps the launches.  Measured at 65 536 x 1 024 x 32 draws = 16 GiB
-// (profiles/r03/sample_device_e2e.txt): pageable 1.10 s for the sampling phase (15.6 GB/s, the host blocked),
-// registered 0.37 s (46 GB/s, overlapped) -- after 0.72 s spent registering 16 GiB of fresh pages.  A wash for a
-// buffer used once, a 3x for a caller that reuses its buffer, hence opt-in; registration is best effort
-// (RLIMIT_MEMLOCK) and falls back to the pageable path.
+// device-to-host copy into pageable memory goes through the runtime's bounce buffers and blocks the host thread; into
+// registered memory it is a DMA that overlaps the launches.  Measured at 65 536 x 1 024 x 32 draws = 16 GiB
+// (profiles/r03/sample_device_e2e.txt): pageable 1.0 s for the sampling phase (16 GB/s, the host blocked), registered
+// 0.37 s (46 GB/s, overlapped) -- after 0.7 s spent registering 16 GiB of fresh pages.  The registration runs on the
+// call's preparation thread (sample_device_impl), but page-locking 16 GiB contends with the host-side initial streams
+// for the process's address space (they take 1.1 s beside it instead of 0.4 s): 1.88 s for the whole call against
+// 1.77 s pageable.  A loss for a buffer used once, a gain for a caller that reuses a registered buffer: hence opt-in.
+// Best effort (RLIMIT_MEMLOCK, memory the caller registered already): on failure the pageable path is used.
 struct PinnedRange {
   void* p = nullptr;
   PinnedRange(void* ptr, size_t bytes) {
@@ -450,6 +453,32 @@ static int sample_device_impl(
     wn_engine* e = guard.e;
     const size_t D = static_cast<size_t>(num_params);
     timer.mark("engine created");
+    // Preparation thread: what the iterations need that does not depend on the host streams -- the draw staging blocks
+    // (or the resident draw block) allocated: 0.6-1.0 s for 16-32 GiB of fresh device memory at the headline size; the
+    // caller's buffer registered if asked for -- beside the ~0.4 s the streams take on this thread.
+    const hipStream_t compute = reinterpret_cast<hipStream_t>(wn_engine_stream(e));
+    std::unique_ptr<PinnedRange> pinned;
+    std::unique_ptr<DrawSink> sink_holder;
+    std::unique_ptr<ResidentDraws> kept;
+    std::exception_ptr prep_error;
+    std::thread prep([&] {
+      try {
+        if (hipSetDevice(cfg.device) != hipSuccess) throw std::runtime_error("cannot select the device");
+        pinned = std::make_unique<PinnedRange>(out, num_chains * draws_offset * sizeof(double));
+        sink_holder = std::make_unique<DrawSink>(num_chains, rows, resident != nullptr ? warm_rows : rows, D, out, compute);
+        if (resident != nullptr)
+          kept = std::make_unique<ResidentDraws>(num_chains, static_cast<size_t>(max_sampling_iter), D, resident->thin,
+                                                 out, rows, warm_rows, compute);
+      } catch (...) {
+        prep_error = std::current_exception();
+      }
+    });
+    struct PrepJoiner {
+      std::thread& t;
+      ~PrepJoiner() {
+        if (t.joinable()) t.join();
+      }
+    } join_prep{prep};
 
     // The reference's two host streams (wn_refstream.h): the step-size search's normals -- mt19937_64(seed_seq{seed, 2}),
     // the engine shared by the chains in order, a fresh normal distribution per chain (walnutpy.cpp:75-80, util.hpp:288)
@@ -460,12 +489,7 @@ static int sample_device_impl(
     std::thread step_stream([&] {
       std::seed_seq ss{seed, 2u};
       std::mt19937_64 rng(ss);
-      wnref::PolarStream normals(rng, pool, 1.0);
-      for (size_t c = 0; c < num_chains; ++c) {
-        normals.reset_distribution();
-        normals.fill(&z[c * D], D);
-      }
-      normals.finish();
+      wnref::polar_stream_fill(rng, pool, 1.0, num_chains, D, /*fresh_per_chain=*/true, z.data());
     });
     struct Joiner {
       std::thread& t;
@@ -486,11 +510,7 @@ static int sample_device_impl(
         std::seed_seq ss{seed, 1u};
         std::mt19937_64 rng(ss);
         // one detail::Random -- one normal distribution -- for all chains (config.hpp:261-266); x *= init_radius
-        wnref::PolarStream normals(rng, pool, init_radius);
-        normals.fill(pos.data(), pos.size());
-        normals.finish();
-        step_stream.join();
-        pool.wait_idle();
+        wnref::polar_stream_fill(rng, pool, init_radius, num_chains, D, /*fresh_per_chain=*/false, pos.data());
       }
       WN_CALL(wn_engine_set_positions(e, pos.data(), &call_err_));
     }
@@ -522,15 +542,12 @@ static int sample_device_impl(
     }
 
     InterruptGuard interrupt;  // walnutpy.cpp: interrupt::walnutpy_interrupt_handler on the stack of the call
-    const hipStream_t compute = reinterpret_cast<hipStream_t>(wn_engine_stream(e));
-    PinnedRange pinned(out, num_chains * draws_offset * sizeof(double));
-    DrawSink sink(num_chains, rows, resident != nullptr ? warm_rows : rows, D, out, compute);
-    std::unique_ptr<ResidentDraws> kept;
-    if (resident != nullptr)
-      kept = std::make_unique<ResidentDraws>(num_chains, static_cast<size_t>(max_sampling_iter), D, resident->thin, out,
-                                             rows, warm_rows, compute);
+    timer.mark("chains seeded");
+    prep.join();
+    if (prep_error) std::rethrow_exception(prep_error);
+    DrawSink& sink = *sink_holder;
     RunAhead pace(compute);
-    timer.mark("output pinned, draw sink ready");
+    timer.mark("preparation thread joined (output registered, draw blocks allocated)");
     Printer printer{print, static_cast<size_t>(refresh)};
     // Consecutive iterations between two looks of a controller go out as ONE launch (wn_engine_*_steps: the workgroup
     // that fetched a chain runs them back to back -- the chains are independent, adapt.hpp:116-127 / sampler.hpp:82-93
@@ -671,13 +688,7 @@ extern "C" void wn_internal_reference_normals(unsigned int seed, unsigned int st
   wnref::Workers pool(wnref::usable_threads());
   std::seed_seq ss{seed, stream};
   std::mt19937_64 rng(ss);
-  wnref::PolarStream normals(rng, pool, scale);
-  for (size_t c = 0; c < num_chains; ++c) {
-    if (fresh_per_chain) normals.reset_distribution();
-    normals.fill(out + c * count_per_chain, count_per_chain);
-  }
-  normals.finish();
-  pool.wait_idle();
+  wnref::polar_stream_fill(rng, pool, scale, num_chains, count_per_chain, fresh_per_chain != 0, out);
 }
 
 extern "C" int walnutpie_sample_device(WN_SAMPLE_PARAMS) { return sample_device_impl(false, nullptr, WN_SAMPLE_ARGS); }

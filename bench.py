@@ -89,7 +89,8 @@ def parse():
                     help="transitions of every chain per kernel launch (wn_engine_sample_steps): the workgroup that "
                          "fetched a chain runs them back to back; a step stays ONE transition of all chains")
     ap.add_argument("--gather-every", type=int, default=1,
-                    help="all-gather the draws of every k-th transition (1 = every draw, the north star's exchange)")
+                    help="all-gather the draw block of every k-th launch (1 = every draw of every transition, the north star's "
+                         "exchange: one collective per launch on the block of its draw planes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-parity-gate", action="store_true")
@@ -541,7 +542,7 @@ def main():
                 "chains_per_gpu": C, "global_chains": total_chains, "dim": D, "model": args.model,
                 "phase": args.phase, "parallelism": f"chains sharded over {world} GPU(s)"
                                                     + (f", {'RCCL' if args.backend == 'nccl' else 'gloo'} all-gather of draws every "
-                                                       f"{args.gather_every} step(s)" if world > 1 else ""),
+                                                       f"{args.gather_every} launch(es), one collective per block of {T} draw planes" if world > 1 else ""),
                 "geometry": {"lanes_per_chain": eng.lanes, "dim_padded": eng.dim_padded,
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
                              "reserved_cus": reserved},

@@ -683,14 +683,17 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     // generated (pure arithmetic: Philox + Box-Muller, ~2 000 VALU instructions per wavefront at 16 elements per
     // lane), and only then is anything loaded looked at -- the round trips to HBM hide behind the generator.
     this->request_tuning(warm);
-    vload_stream(Q.theta + row, th[0]);
+    // (a launch runs Params::fused transitions of the chain back to back: after the first one the position is the
+    // selected state the previous epilogue left in set 0, and the frozen inverse mass is still in its registers)
+    const bool first_of_launch = this->fuse_t == 0;
+    if (first_of_launch) vload_stream(Q.theta + row, th[0]);
     if (Model::kUsesParams) vload(Q.model_params, mp);
     double ds[EPL], ss[EPL];  // warmup: the estimator's two sums of squared deviations; sampling: ds = cholesky_mass
     if (warm) {
       vload_stream(Q.est_draw_ssd + row, ds);
       vload_stream(Q.est_score_ssd + row, ss);
     } else {
-      vload_stream(Q.inv_mass + row, im);
+      if (first_of_launch) vload_stream(Q.inv_mass + row, im);
       vload_stream(Q.chol_mass + row, ds);  // 1/sqrt(inv_mass), walnuts.hpp:647, stored once by freeze_kernel
     }
     WN_MARK(kPhLoadsIssued);
@@ -752,7 +755,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       pool_load(a_sel, th[0]);
     }
     WN_MARK(kPhSelLoaded);
-    vstore_stream(Q.theta + row, th[0]);
+    // the position plane is read again by the NEXT launch only: the launch's last transition of the chain writes it
+    if (this->fuse_t + 1 >= Q.fused) vstore_stream(Q.theta + row, th[0]);
     double* draws = Q.draws_out;
     if (WN_LIKELY(draws != nullptr)) {
       double* out = this->draw_row();

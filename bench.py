@@ -63,7 +63,7 @@ CONFIG5_CHAINS = 262144
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--chains", type=int, default=HEADLINE_CHAINS,
                     help="total chains (strong scaling) or chains per GPU (weak scaling)")

@@ -14,16 +14,17 @@ e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, Cn, cfg, lib_path=lib_path)
 e.init_positions(1, 0, 2.0); e.init_masses_from_grad(1e-5); e.set_step_sizes(1.0); e.adapt_step(1, 0); e.seed_chains(2, 0)
 for _ in range(100): e.warmup_step()
 WARM = "--warmup" in sys.argv   # profile an adaptive warmup transition instead of a sampling one
+FUSED = int(sys.argv[sys.argv.index("--fused") + 1]) if "--fused" in sys.argv else 1   # transitions per launch
 if WARM:
     e.synchronize()
     e.timing_reset()
-    e.warmup_step(); e.synchronize()
+    e.warmup_steps(FUSED); e.synchronize()
 else:
     e.freeze()
     for _ in range(3): e.sample_step()
     e.synchronize()
     e.timing_reset()
-    e.sample_step(); e.synchronize()
+    e.sample_steps(FUSED); e.synchronize()
 print("launch ms", e.kernel_times_ms().mean())
 get = e.lib.wn_debug_timeline_std_normal
 N = 1536

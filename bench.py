@@ -161,7 +161,8 @@ def measured_traffic(args, D, chains_local, transitions_per_average_launch):
                 args.model, chains_local, D, args.phase, max(1, args.transitions_per_launch)):
             if e.get("csrc_sha") == sha:
                 scale = transitions_per_average_launch / e.get("transitions_per_launch", 1)
-                return e["bytes_per_launch"] * scale, e["source"]
+                return e["bytes_per_launch"] * scale, ("RECORDED, not measured in this run (" + e["source"] +
+                                                        "; same source hash, same workload)")
             stale = f"stale PMC entry refused (recorded for csrc {e.get('csrc_sha')}, this build is {sha})"
     return None, stale or "this workload was not profiled"
 
@@ -320,9 +321,29 @@ def _free_port():
     return p
 
 
+def count_devices_without_hip():
+    """GPUs of this node counted from the KFD topology in sysfs (a node with simd_count > 0 is a GPU): no HIP call, no
+    context left on the devices while the parent waits for its ranks.  torch.cuda.device_count() stays off HIP only
+    while its amdsmi path works and falls back to hipGetDeviceCount otherwise.  None when the topology cannot be read:
+    the pre-check is then skipped and a shortage is reported by the ranks themselves."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            for line in open(os.path.join(base, node, "properties")):
+                if line.startswith("simd_count ") and int(line.split()[1]) > 0:
+                    n += 1
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if visible:
+            n = min(n, len([v for v in visible.split(",") if v.strip() != ""]))
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def launch_ranks(args, argv, script=None, device_count=None):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: THIS process never touches the GPU (it
-    counts devices, which does not initialise HIP on this image, and nothing else); it starts the N ranks as fresh
+    counts devices from the KFD topology in sysfs, and nothing else); it starts the N ranks as fresh
     child processes through torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1), forwards rank 0's
     JSON line to stdout (everything else the children print goes to stderr) and returns their exit code.
     Fewer than N devices is an error -- except with `--backend gloo`, where the ranks share the devices there are
@@ -330,10 +351,8 @@ def launch_ranks(args, argv, script=None, device_count=None):
     import subprocess
 
     if device_count is None:
-        import torch
-
-        device_count = torch.cuda.device_count()
-    if device_count < args.gpus and args.backend != "gloo":
+        device_count = count_devices_without_hip()
+    if device_count is not None and device_count < args.gpus and args.backend != "gloo":
         print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node shows {device_count} "
               "(use --backend gloo to run the ranks on the devices there are)", file=sys.stderr)
         return 2

@@ -60,7 +60,12 @@ typedef enum {
 /* device-resident chains of draws for the posterior summaries at the end of this header */
 typedef struct wn_chains wn_chains;
 
-/* ---- replaces walnutpie_sample_cfunc (walnutpy.cpp:134-149) ------------------- */
+/* ---- replaces walnutpie_sample_cfunc (walnutpy.cpp:134-149) -------------------
+ * Random numbers: initial positions (inits == NULL; config.hpp:258-268), the step-size search's momenta
+ * (util.hpp:285-303) and the chains' trajectories all come from the counter-based generator on the device, keyed by
+ * `seed` (positions, search), seed + id + num_chains (chains; walnutpy.cpp:82) and the chain id: same seed, same
+ * output, whatever the launch geometry.  Arithmetic mode: wn_default_config()'s (fused multiply-adds unless
+ * WALNUTS_AMD_FMA=0 is in the environment; see wn_config::fused_multiply_add). */
 WALNUTS_HIP_EXPORT int walnutpie_sample_device(
     int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
     unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
@@ -73,8 +78,12 @@ WALNUTS_HIP_EXPORT int walnutpie_sample_device(
     int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
     WalnutpyError** err);
 
-/* The same call with the chains' random numbers taken from the reference's own streams (see
- * wn_engine_seed_reference_streams): slower, for parity runs against the reference at equal seed. */
+/* The same call with ALL random numbers taken from the reference's own streams, generated on the host: initial
+ * positions from mt19937_64(seed_seq{seed, 1}) (walnutpy.cpp:187-189), the step-size search's normals from
+ * mt19937_64(seed_seq{seed, 2}) (:75-80), the chains' from mt19937_64(seed_seq{seed + id + num_chains, m + 1})
+ * (api.hpp:46-51; see wn_engine_seed_reference_streams), and with every product rounded (fused_multiply_add = 0, the
+ * reference's x86-64 element-wise bits) whatever the environment says: slower, for parity runs against the reference
+ * at equal seed. */
 WALNUTS_HIP_EXPORT int walnutpie_sample_device_reference_streams(
     int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
     unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
@@ -92,7 +101,9 @@ WALNUTS_HIP_EXPORT int walnutpie_sample_device_reference_streams(
  * (S = max_sampling_iter; it has to fit) owned by *chains_out -- a wn_chains for the wn_summary_* functions below (mean,
  * variance, quantiles, R-hat, ESS, MCSE on the device), to be released with wn_chains_destroy.  `out` receives only
  * every `thin`-th sampling draw (iterations 1, 1 + thin, ...; thin = 0: none, `out` may then be NULL unless
- * save_warmup), after the warmup rows if save_warmup: out[C][max_warmup_iter * save_warmup + ceil(S / thin)][D].
+ * save_warmup).  Layout: out[C][max_warmup_iter * save_warmup + ceil(S / thin)][D] is the CAPACITY; as in
+ * walnutpie_sample_device and the reference (handlers.hpp:73-89: a chain writes its rows sequentially) the thinned
+ * sampling rows follow the warmup rows ACTUALLY WRITTEN: chain c's thinned draw k is row final_lengths[c] + k.
  * final_lengths[C + c] is the number of sampling draws chain c holds in *chains_out (all of them), of which the rows
  * 0, thin, 2 thin, ... are the ones in `out`.  Everything else as walnutpie_sample_device. */
 WALNUTS_HIP_EXPORT int walnutpie_sample_device_resident(
@@ -106,6 +117,27 @@ WALNUTS_HIP_EXPORT int walnutpie_sample_device_resident(
     double step_stabilization, double step_learn_rate_decay, bool save_warmup, double* out, size_t out_size,
     int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
     int thin, wn_chains** chains_out, WalnutpyError** err);
+
+/* walnutpie_sample_device over SEVERAL devices of the node ("one process, one driver thread +
+ * stream per GPU").  devices[num_devices]: HIP ordinals; shard s -- a contiguous block of the global chain ids, sizes
+ * differing by at most one -- runs on devices[s] with its own host thread, engine and stream and writes its own slice
+ * of out[C][T][D], final_lengths, stepsize_out and inv_metric_out: no exchange on the data path.  The random streams are
+ * keyed by global chain id and the controllers' statistics (warmup spread adapt.hpp:193-221, R-hat sampler.hpp:139-145)
+ * are reduced over all shards, so every shard stops at the same iteration and the output equals the one-device call's
+ * for the same arguments (bit for bit with min_*_iter == max_*_iter; the stopping statistics are summed shard by shard
+ * otherwise).  An ordinal may repeat: {0, 0} runs two half-size engines on two streams of one device, each filling the
+ * other's launch tail (+12 % / +23 % on BASELINE configs #2 / #3, profiles/r03/two_groups.txt). */
+WALNUTS_HIP_EXPORT int walnutpie_sample_device_multi(
+    int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
+    unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
+    int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
+    int max_step_halvings, int min_micro_steps, double max_hamiltonian_error, double step_size_converge_tol,
+    double mass_converge_tol, double rhat_converge_tol, double mass_init_count, double mass_additive_smoothing,
+    double max_macro_steps_target, double step_size_init, double step_accept_rate_target,
+    double step_learning_rate, double step_gradient_decay, double step_sq_gradient_decay,
+    double step_stabilization, double step_learn_rate_decay, bool save_warmup, double* out, size_t out_size,
+    int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
+    const int* devices, int num_devices, WalnutpyError** err);
 
 /* ---- batched engine ------------------------------------------------------------- */
 typedef struct wn_engine wn_engine;

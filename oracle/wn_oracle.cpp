@@ -145,9 +145,11 @@ struct Reducer {
     for (size_t w = 0; w < lanes; w += 64) {
       size_t width = std::min<size_t>(64, lanes - w);
       double* v = part.data() + w;
-      // lanes beyond `width` do not exist for L < 64 only when L is not a
-      // multiple of 64; the engine always uses multiples of 64.
+      // The engine's widths are multiples of 64 (one or more wavefronts per chain) or 16 (the row kernels, four
+      // chains per wavefront, walnuts_amd/csrc/wn_row.h): a row's butterfly has the offsets 1, 2, 4, 8 only -- an offset
+      // that would leave the group does not exist there and is skipped.
       for (size_t off : {size_t{32}, size_t{1}, size_t{2}, size_t{4}, size_t{8}, size_t{16}}) {
+        if (off >= width) continue;
         for (size_t l = 0; l < width; ++l) {
           size_t p = l ^ off;
           tmp[l] = v[l] + (p < width ? v[p] : 0.0);

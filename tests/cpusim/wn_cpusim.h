@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -71,8 +72,15 @@ T readfirstlane(T v) {
   return exchange(v, tidx.x & ~63u);
 }
 
+// (launches from several host threads -- the shards of walnutpie_sample_device_multi -- run one after another: static
+// __shared__ arrays are function-local statics here)
+inline std::mutex& launch_mutex() {
+  static std::mutex m;
+  return m;
+}
 template <class K, class... A>
 void launch(K kernel, dim3 grid, dim3 block, size_t smem_bytes, A... args) {
+  std::lock_guard<std::mutex> one_at_a_time(launch_mutex());
   for (unsigned b = 0; b < grid.x; ++b) {
     Block B;
     B.nthreads = block.x;
@@ -150,6 +158,11 @@ struct ParkedDouble {
 };
 inline void park(ParkedDouble& a, double v) { a.v = v; }
 inline double fetch(const ParkedDouble& a) { return a.v; }
+struct PlainDouble {
+  double v;
+};
+inline void park(PlainDouble& a, double v) { a.v = v; }
+inline double fetch(const PlainDouble& a) { return a.v; }
 inline double lane_value(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 inline double wave_sum(double v) {  // xor butterfly, offsets 32,1,2,4,8,16: the device's association order
   v = v + __shfl_xor(v, 32, 64);
@@ -175,6 +188,10 @@ constexpr hipError_t hipSuccess = 0;
 inline const char* hipGetErrorString(hipError_t) { return "cpusim error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) {
+  *n = 1;
+  return hipSuccess;
+}
 struct hipDeviceProp_t {
   int multiProcessorCount;
 };

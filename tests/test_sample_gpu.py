@@ -89,3 +89,29 @@ def test_resident_draws_thinned_mode_on_the_device(oracle):
     res0, chains0 = wa.walnuts_device(wa.MODEL_STD_NORMAL, keep_on_device=True, thin=0, **kw)   # nothing to the host
     assert all(np.asarray(r).shape == (0, D) for r in res0[:4]) and chains0.num_draws() == C * S
     assert np.array_equal(chains0.mean(), sp.wnso.mean(sub))
+
+
+def test_multi_device_call_on_one_gpu_equals_the_single_engine_call():
+    """walnutpie_sample_device_multi with devices = {0, 0} (and {0, 0, 0}: uneven shards): two / three engines on their
+    own host threads and streams of the one GPU there is, each writing its slice of the caller's buffers -- the same
+    draws, warmup draws, step sizes and inverse metrics as the one-engine call, bit for bit; and the controllers
+    (reduced over all shards) stop every shard where the one-engine call stops."""
+    C, D = 1000, 200
+    kw = dict(num_params=D, num_chains=C, seed=21, min_warmup_iter=10, max_warmup_iter=10, min_sampling_iter=12,
+              max_sampling_iter=12, save_warmup=True, save_inv_metric=True)
+    whole = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    for devices in ([0, 0], [0, 0, 0]):
+        split = wa.walnuts_device(wa.MODEL_STD_NORMAL, devices=devices, **kw)
+        assert len(split) == C
+        for c in (0, 1, 332, 333, 334, 499, 500, 666, 667, C - 1):
+            assert np.array_equal(np.asarray(split[c]), np.asarray(whole[c])), (devices, c)
+            assert np.array_equal(split[c].warmup.warmup_draws, whole[c].warmup.warmup_draws)
+            assert split[c].warmup.stepsize == whole[c].warmup.stepsize
+            assert np.array_equal(split[c].warmup.inv_metric, whole[c].warmup.inv_metric)
+    early = dict(kw, min_warmup_iter=5, max_warmup_iter=40, step_size_converge_tol=1e6, mass_converge_tol=1e6,
+                 min_sampling_iter=4, max_sampling_iter=30, rhat_converge_tol=1e6)
+    a = wa.walnuts_device(wa.MODEL_STD_NORMAL, **early)
+    b = wa.walnuts_device(wa.MODEL_STD_NORMAL, devices=[0, 0], **early)
+    assert {len(x) for x in a} == {len(x) for x in b} == {4}
+    assert {len(x.warmup.warmup_draws) for x in b} == {5}
+    assert all(np.array_equal(np.asarray(a[c]), np.asarray(b[c])) for c in (0, 499, 500, C - 1))

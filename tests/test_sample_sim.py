@@ -100,8 +100,65 @@ def test_resident_draws_and_thinned_rows_equal_the_streamed_run(sim, oracle):
 
 
 @pytest.mark.timeout(600)
+def test_resident_thinned_rows_follow_the_warmup_rows_actually_written(sim):
+    """The warmup controller may stop before max_warmup_iter (adapt.hpp:172-229): with save_warmup the thinned sampling
+    rows then follow the warmup rows that were WRITTEN (handlers.hpp:73-89), exactly where walnutpie_sample_device puts
+    its sampling rows and where the wrapper slices them -- not at row max_warmup_iter."""
+    kw = dict(min_warmup_iter=5, max_warmup_iter=15, step_size_converge_tol=1e6, mass_converge_tol=1e6)
+    whole = _run(sim, **kw)
+    n_warm = len(whole[0].warmup.warmup_draws)
+    assert n_warm == 5, n_warm                                    # the loose tolerances stop warmup at its first look
+    res, chains = _run(sim, keep_on_device=True, thin=2, **kw)
+    for a, b in zip(whole, res):
+        assert np.array_equal(a.warmup.warmup_draws, b.warmup.warmup_draws)
+        assert len(b) == 4 and np.array_equal(np.asarray(b), np.asarray(a)[::2])
+        assert np.any(np.asarray(b) != 0.0)
+    chains.close()
+
+
+@pytest.mark.timeout(600)
 def test_resident_mode_argument_errors_come_back_as_config_errors(sim):
     import ctypes as C
     lib = wa.load_library(sim)
     with pytest.raises(ValueError, match="min_iter must be"):     # the reference's own validation still runs first
         _run(sim, keep_on_device=True, min_sampling_iter=9, max_sampling_iter=7)
+
+
+@pytest.mark.timeout(900)
+def test_multi_device_call_equals_the_single_engine_call(sim):
+    """walnutpie_sample_device_multi with devices = {0, 0}: two shards (3 + 2 chains) on two host threads, engines and
+    streams write the same draws, warmup draws, step sizes and inverse metrics as the one-engine call -- random streams
+    are keyed by global chain id, initial positions included."""
+    kw = dict(num_chains=5, save_inv_metric=True)
+    whole = _run(sim, **kw)
+    split = _run(sim, devices=[0, 0], **kw)
+    three = _run(sim, devices=[0, 0, 0], **kw)
+    for other in (split, three):
+        assert len(other) == 5
+        for a, b in zip(whole, other):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+            assert np.array_equal(a.warmup.warmup_draws, b.warmup.warmup_draws)
+            assert a.warmup.stepsize == b.warmup.stepsize and np.array_equal(a.warmup.inv_metric, b.warmup.inv_metric)
+    with pytest.raises(ValueError, match="fewer chains than devices"):
+        _run(sim, devices=[0] * 6, **kw)
+    with pytest.raises(ValueError, match="out of range"):
+        _run(sim, devices=[0, 7], **kw)
+    with pytest.raises(ValueError, match="min_iter must be"):      # a config error of the shards comes back as one
+        _run(sim, devices=[0, 0], min_sampling_iter=9, max_sampling_iter=7, **kw)
+
+
+@pytest.mark.timeout(900)
+def test_multi_device_controllers_look_at_all_chains(sim):
+    """Early stopping over shards: the shards' controller statistics are reduced over ALL chains, so every shard stops
+    at the same iteration -- the one the single-engine call stops at (loose tolerances: first look)."""
+    kw = dict(num_chains=6, min_warmup_iter=5, max_warmup_iter=20, step_size_converge_tol=1e6, mass_converge_tol=1e6,
+              min_sampling_iter=4, max_sampling_iter=30, rhat_converge_tol=1e6)
+    whole = _run(sim, **kw)
+    split = _run(sim, devices=[0, 0], **kw)
+    assert [len(a) for a in whole] == [len(b) for b in split] == [4] * 6
+    assert [len(a.warmup.warmup_draws) for a in split] == [5] * 6
+    for a, b in zip(whole, split):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    tight = _run(sim, devices=[0, 0], **{**kw, "rhat_converge_tol": 1.0 + 1e-12, "step_size_converge_tol": 1e-12,
+                                         "mass_converge_tol": 1e-12, "max_warmup_iter": 10, "max_sampling_iter": 9})
+    assert [len(a) for a in tight] == [9] * 6 and [len(a.warmup.warmup_draws) for a in tight] == [10] * 6

@@ -26,6 +26,7 @@ def sim():
     ("diag_normal", 130, (1, 4), 1),      # (1,4): four elements per lane
     ("funnel", 9, (2, 2), 1),             # two wavefronts: cross-wave reductions, broadcasts, barriers
     ("funnel", 9, (2, 2), 0),
+    ("std_normal", 200, (2, 2), 1),       # two wavefronts, span's other end in registers: wavefront 0 decides (share())
     ("diag_normal", 300, (1, -1), 1),     # streaming backend (vectors in HBM scratch), 3 tiles per lane
     ("diag_normal", 300, (1, -1), 0),
     ("rw1", 70, (1, 2), 1),               # neighbour-coupled gradient through the public model interface

@@ -32,6 +32,15 @@
 
 namespace wn {
 
+// Geometry table of the on-chip kernels: waves per SIMD the register budget is cut for.  One vector costs 2*EPL VGPRs
+// per lane; the moving end's two sets, the inverse mass and the two operands of a pool-side U-turn test must fit.
+template <class Model, int EPL>
+constexpr int chip_waves_per_simd() {
+  // a model that keeps its gradient vectors (two more per set) gets the next larger register budget
+  if (!Model::kCheapGrad) return EPL >= 8 ? 1 : EPL == 4 ? 2 : 3;
+  return EPL >= 16 ? 1 : EPL == 8 ? 2 : EPL == 4 ? 3 : 4;
+}
+
 // WARM: the kernel of the adaptive warmup transitions (Adam, mass estimator) or of the frozen sampler's -- two
 // instantiations, because the sampler's, freed of the adaptation code, needs fewer registers (measured: +3 % on the
 // one-wavefront headline kernel, +8 % on the two-wavefront one)
@@ -51,7 +60,11 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   static constexpr bool kNoGrad = Model::kCheapGrad;  // the gradient is recomputed from theta at each use
   static constexpr bool kHasStartState = true;
   static constexpr bool kZeroCopy = false;
-  static constexpr bool kParkScalars = true;
+  // values that live long and are read rarely sit in accumulator registers -- in the kernels built for one or two
+  // wavefronts per SIMD; the others name no accumulator register (wn_gfx950.h: PlainDouble)
+  static constexpr bool kPark = chip_waves_per_simd<Model, EPL>() <= 2;
+  static constexpr bool kParkScalars = kPark;
+  using Parked = std::conditional_t<kPark, ParkedDouble, PlainDouble>;
   static_assert(EPL % 2 == 0, "lanes own 16-byte pairs");
 
   double th[2][EPL], rh[2][EPL], g[2][EPL];  // the two sets of the moving end (g is dead when kNoGrad)
@@ -62,7 +75,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   // end, and the pool's LDS vectors all serve the span stack.
   static constexpr bool kOtherRegs = kNoGrad;
   static constexpr int kOther = -4;           // "this vector is the other end's theta" (kOtherRegs)
-  ParkedDouble oth[EPL], orh[EPL];
+  Parked oth[EPL], orh[EPL];
   int n_lds;                                  // pool buffers [0, n_lds) live in LDS, the rest in the HBM arena
 
   __device__ __forceinline__ TrajChip(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
@@ -796,15 +809,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     }
   }
 };
-
-// Geometry table of the on-chip kernels: waves per SIMD the register budget is cut for.  One vector costs 2*EPL VGPRs
-// per lane; the moving end's two sets, the inverse mass and the two operands of a pool-side U-turn test must fit.
-template <class Model, int EPL>
-constexpr int chip_waves_per_simd() {
-  // a model that keeps its gradient vectors (two more per set) gets the next larger register budget
-  if (!Model::kCheapGrad) return EPL >= 8 ? 1 : EPL == 4 ? 2 : 3;
-  return EPL >= 16 ? 1 : EPL == 8 ? 2 : EPL == 4 ? 3 : 4;
-}
 
 template <class Model, int NW, int EPL, bool WARM, bool FMA>
 __global__ __launch_bounds__(64 * NW, (chip_waves_per_simd<Model, EPL>())) void transition_kernel_chip(const Params P) {

@@ -232,17 +232,25 @@ struct wn_engine {
     // The chain counter is never reset: every launch performs exactly C fetches (one per processed chain), so launch n
     // starts at n * C (mod 2^32) -- one memset per transition less between two kernels.
     P.work_base = work_base;
-    work_base += static_cast<uint32_t>(C);
-    if (timing) {  // HIP events around the launch: only between wn_engine_timing_reset and the read-back
-      auto& ev = next_events();
-      HIP_OK(hipEventRecord(ev.first, stream));
-      wn::launch_transition(model, geo, grid, smem, stream, P);
-      HIP_OK(hipGetLastError());
-      HIP_OK(hipEventRecord(ev.second, stream));
-    } else {
-      wn::launch_transition(model, geo, grid, smem, stream, P);
-      HIP_OK(hipGetLastError());
+    try {
+      if (timing) {  // HIP events around the launch: only between wn_engine_timing_reset and the read-back
+        auto& ev = next_events();
+        HIP_OK(hipEventRecord(ev.first, stream));
+        wn::launch_transition(model, geo, grid, smem, stream, P);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(ev.second, stream));
+      } else {
+        wn::launch_transition(model, geo, grid, smem, stream, P);
+        HIP_OK(hipGetLastError());
+      }
+    } catch (...) {
+      // a launch that did not happen fetched nothing: counter and base start over together (a kernel that did start
+      // and then failed leaves the device in an error state anyway; the memset then fails too and is ignored)
+      (void)hipMemsetAsync(counter.p, 0, sizeof(uint32_t), stream);
+      work_base = 0;
+      throw;
     }
+    work_base += static_cast<uint32_t>(C);  // (only once the launch is known to be queued)
     ++region_launches;
     variates_pending = false;
     transition += static_cast<uint32_t>(fused);

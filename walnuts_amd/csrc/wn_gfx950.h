@@ -103,6 +103,15 @@ __device__ __forceinline__ double fetch(const ParkedDouble& a) {
   return double_of((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
+// The same interface over an ordinary register: kernels built for three or more wavefronts per SIMD name no accumulator
+// registers at all -- as soon as a kernel does, the compiler splits its register budget evenly between the two files
+// (84 + 84 of 168 at three wavefronts per SIMD), which is not what a kernel whose arithmetic state alone is 112 needs.
+struct PlainDouble {
+  double v;
+};
+__device__ __forceinline__ void park(PlainDouble& a, double v) { a.v = v; }
+__device__ __forceinline__ double fetch(const PlainDouble& a) { return a.v; }
+
 // The lane's index within its wavefront, COMPUTED where it is asked for (v_mbcnt_lo/hi on an all-ones mask: two VALU
 // instructions, independent of EXEC): whatever is derived from it -- addresses, padding masks, counter words -- is rebuilt
 // at the use instead of being hoisted to the kernel entry and held for the whole kernel.  Deliberately NOT threadIdx.x:

@@ -27,6 +27,9 @@
 #include <random>
 #include <sstream>
 #include <stdexcept>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <string>
 #include <vector>
@@ -267,6 +270,9 @@ class ResidentDraws {
     copy_.create();
   }
   int64_t stride() const { return static_cast<int64_t>(S_ * D_); }
+  // the thinned rows follow the warmup rows ACTUALLY written (handlers.hpp:73-89: a chain writes sequentially), which
+  // is known once the warmup loop has ended -- before that the controller may still stop it early
+  void set_first_row(size_t row) { out_first_ = row; }
   double* next_row() { return block_.p + written_ * D_; }
   void row_done() {
     if (thin_ > 0 && written_ % static_cast<size_t>(thin_) == 0) {
@@ -365,13 +371,118 @@ struct PhaseTimer {
 
 constexpr int kMaxFusedTransitions = 8;  // transitions per launch between two looks of a controller
 
+// ---- several devices behind one call (walnutpie_sample_device_multi) ------------------------------------------------
+// The chains shard embarrassingly (adapt.hpp:257-258: nothing is pooled per transition): shard s is a contiguous block
+// of GLOBAL chain ids on devices[s], driven by its own host thread, engine and stream, and writes its own slice of the
+// caller's out[C][T][D] -- no exchange on the data path.  What the shards share is what the reference's controller
+// threads look at: the warmup spread (adapt.hpp:193-221) and R-hat of the log density (sampler.hpp:139-145), each
+// reduced in the two stages the engine exposes (wn_engine_warmup_sums / _warmup_max_rel, wn_engine_lp_sums / _lp_sq_dev)
+// with a rendezvous of the shard threads in between, so that every shard takes the same stopping decision at the same
+// iteration.
+struct ShardAborted {};  // another shard failed: leave quietly, the wrapper reports that shard's error
+class Coordinator {
+ public:
+  Coordinator(int shards, size_t dims) : n_(shards), D_(dims), slots_(static_cast<size_t>(shards) * (dims + 4), 0.0) {}
+  // a failing shard stops taking part; the others notice at their next rendezvous
+  void abandon() {
+    std::lock_guard<std::mutex> lk(mu_);
+    failed_ = true;
+    --n_;
+    if (arrived_ >= n_ && n_ > 0) release();
+    cv_.notify_all();
+  }
+  bool failed() const { return failed_; }
+  // adapt.hpp:193-221 over ALL shards' chains
+  bool warmup_converged(int shard, wn_engine* e, size_t total_chains, double step_tol, double mass_tol) {
+    double* mine = slot(shard);
+    WN_CALL(wn_engine_warmup_sums(e, mine, mine + 1, &call_err_));
+    rendezvous();
+    std::vector<double> total(D_ + 1, 0.0);
+    for (int s = 0; s < shards(); ++s)
+      for (size_t i = 0; i <= D_; ++i) total[i] += slot(s)[i];  // (every shard adds in the same order: same total)
+    rendezvous();  // everyone has read the sums before the slots are reused
+    double rel_step = 0, rel_mass = 0;
+    WN_CALL(wn_engine_warmup_max_rel(e, total[0], total.data() + 1, total_chains, &rel_step, &rel_mass, &call_err_));
+    mine[0] = rel_step;
+    mine[1] = rel_mass;
+    rendezvous();
+    double ms = 0, mm = 0;
+    for (int s = 0; s < shards(); ++s) {
+      ms = std::max(ms, slot(s)[0]);
+      mm = std::max(mm, slot(s)[1]);
+    }
+    rendezvous();
+    return mm <= mass_tol && ms <= step_tol;
+  }
+  // sampler.hpp:139-145 over ALL shards' chains
+  double rhat(int shard, wn_engine* e) {
+    double* mine = slot(shard);
+    WN_CALL(wn_engine_lp_sums(e, mine, &call_err_));  // sum of means, sum of sample variances, chains
+    rendezvous();
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int s = 0; s < shards(); ++s) {
+      s0 += slot(s)[0];
+      s1 += slot(s)[1];
+      s2 += slot(s)[2];
+    }
+    rendezvous();
+    double q = 0;
+    WN_CALL(wn_engine_lp_sq_dev(e, s0 / s2, &q, &call_err_));
+    mine[0] = q;
+    rendezvous();
+    double qq = 0;
+    for (int s = 0; s < shards(); ++s) qq += slot(s)[0];
+    rendezvous();
+    const double variance_of_means = qq / (s2 - 1);  // util.hpp:401-404
+    const double mean_of_variances = s1 / s2;
+    return std::sqrt(1 + variance_of_means / mean_of_variances);  // sampler.hpp:145
+  }
+
+ private:
+  int shards() const { return total_shards_; }
+  double* slot(int s) { return slots_.data() + static_cast<size_t>(s) * (D_ + 4); }
+  void release() {
+    arrived_ = 0;
+    ++generation_;
+  }
+  void rendezvous() {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (failed_) throw ShardAborted{};
+    const unsigned long gen = generation_;
+    if (++arrived_ >= n_) {
+      release();
+      cv_.notify_all();
+    } else {
+      cv_.wait(lk, [&] { return generation_ != gen || failed_; });
+    }
+    if (failed_) throw ShardAborted{};
+  }
+  int n_;
+  const int total_shards_ = n_;
+  size_t D_;
+  std::vector<double> slots_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int arrived_ = 0;
+  unsigned long generation_ = 0;
+  std::atomic<bool> failed_{false};
+};
+struct ShardCtx {
+  int shard = 0, device = 0;
+  size_t chain_begin = 0, total_chains = 0;
+  Coordinator* coord = nullptr;
+  const InterruptGuard* interrupt = nullptr;  // the call's one SIGINT guard
+  int* lengths_warmup = nullptr;              // final_lengths slices of this shard
+  int* lengths_sampling = nullptr;
+};
+
 struct ResidentRequest {  // walnutpie_sample_device_resident
   int thin;
   wn_chains** chains_out;
 };
 
 static int sample_device_impl(
-    bool reference_streams, const ResidentRequest* resident,
+    bool reference_streams, const ResidentRequest* resident, const ShardCtx* shard,
     int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
     unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
     int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
@@ -404,7 +515,10 @@ static int sample_device_impl(
     const size_t rows = samp_rows + warm_rows;
     if (rows > 0 && out == nullptr) throw std::invalid_argument("out must not be null");
     const size_t draws_offset = static_cast<size_t>(num_params) * rows;
-    if (out_size < num_chains * draws_offset) {
+    // (a shard of walnutpie_sample_device_multi sees its own slice of a buffer the wrapper has checked as a whole)
+    const size_t total_chains = shard != nullptr ? shard->total_chains : num_chains;
+    const size_t chain_begin = shard != nullptr ? shard->chain_begin : 0;
+    if (shard == nullptr && out_size < num_chains * draws_offset) {
       std::stringstream ss;
       ss << "Output buffer too small. Expected at least " << num_chains << " chains of " << draws_offset
          << " doubles, got " << out_size;
@@ -446,6 +560,10 @@ static int sample_device_impl(
     cfg.step_sq_gradient_decay = step_sq_gradient_decay;
     cfg.step_stabilization = step_stabilization;
     cfg.step_learn_rate_decay = step_learn_rate_decay;
+    // the entry point that reproduces the reference's streams also keeps the reference's element-wise arithmetic
+    // (x86-64 -O3: every product rounded), independent of the process environment
+    if (reference_streams) cfg.fused_multiply_add = 0;
+    if (shard != nullptr) cfg.device = shard->device;
 
     PhaseTimer timer;
     EngineGuard guard;
@@ -484,37 +602,48 @@ static int sample_device_impl(
     // the engine shared by the chains in order, a fresh normal distribution per chain (walnutpy.cpp:75-80, util.hpp:288)
     // -- are produced by a second thread while this one produces the initial positions; both hand the non-sequential
     // half of the work to the same worker pool.
-    wnref::Workers pool(wnref::usable_threads());
-    std::vector<double> z(num_chains * D);
-    std::thread step_stream([&] {
-      std::seed_seq ss{seed, 2u};
-      std::mt19937_64 rng(ss);
-      wnref::polar_stream_fill(rng, pool, 1.0, num_chains, D, /*fresh_per_chain=*/true, z.data());
-    });
+    // -- ONLY in walnutpie_sample_device_reference_streams.  walnutpie_sample_device / _resident draw both from the
+    // counter-based generator on the device (wn_init.h: streams kStreamInitPos / kStreamInitStep keyed by `seed` and the
+    // chain id), as they draw the trajectories' variates: one sequential mt19937_64 for 67 M polar-method normals was
+    // 0.4-0.5 s of a 1.0 s call at 65 536 x 1 024 (profiles/r03/sample_device_e2e.txt) to reproduce the first two of
+    // the reference's streams bit for bit in a mode whose third stream differs anyway.
+    std::unique_ptr<wnref::Workers> pool;
+    std::vector<double> z;
+    std::thread step_stream;
     struct Joiner {
       std::thread& t;
       ~Joiner() {
         if (t.joinable()) t.join();
       }
     } join_step_stream{step_stream};
-    // initial positions (walnutpy.cpp:176-190)
-    {
-      std::vector<double> pos(num_chains * D);
-      if (inits != nullptr) {
-        for (size_t i = 0; i < pos.size(); ++i) {
-          if (!std::isfinite(inits[i])) throw std::invalid_argument("positions must be finite");
-          pos[i] = inits[i];
-        }
-      } else {
-        finite_positive(init_radius, "init_scale");
-        std::seed_seq ss{seed, 1u};
+    if (reference_streams) {
+      pool = std::make_unique<wnref::Workers>(wnref::usable_threads());
+      z.resize(num_chains * D);
+      step_stream = std::thread([&] {
+        std::seed_seq ss{seed, 2u};
         std::mt19937_64 rng(ss);
-        // one detail::Random -- one normal distribution -- for all chains (config.hpp:261-266); x *= init_radius
-        wnref::polar_stream_fill(rng, pool, init_radius, num_chains, D, /*fresh_per_chain=*/false, pos.data());
-      }
-      WN_CALL(wn_engine_set_positions(e, pos.data(), &call_err_));
+        wnref::polar_stream_fill(rng, *pool, 1.0, num_chains, D, /*fresh_per_chain=*/true, z.data());
+      });
     }
-    timer.mark("initial positions (host stream)");
+    // initial positions (walnutpy.cpp:176-190)
+    if (inits != nullptr) {
+      for (size_t i = 0; i < num_chains * D; ++i)
+        if (!std::isfinite(inits[i])) throw std::invalid_argument("positions must be finite");
+      WN_CALL(wn_engine_set_positions(e, inits, &call_err_));
+    } else if (reference_streams) {
+      finite_positive(init_radius, "init_scale");
+      std::vector<double> pos(num_chains * D);
+      std::seed_seq ss{seed, 1u};
+      std::mt19937_64 rng(ss);
+      // one detail::Random -- one normal distribution -- for all chains (config.hpp:261-266); x *= init_radius
+      wnref::polar_stream_fill(rng, *pool, init_radius, num_chains, D, /*fresh_per_chain=*/false, pos.data());
+      WN_CALL(wn_engine_set_positions(e, pos.data(), &call_err_));
+    } else {
+      finite_positive(init_radius, "init_scale");
+      // config.hpp:258-268, all chains at once; the stream is keyed by the GLOBAL chain id
+      WN_CALL(wn_engine_init_positions(e, seed, static_cast<uint32_t>(chain_begin), init_radius, &call_err_));
+    }
+    timer.mark(reference_streams ? "initial positions (host stream)" : "initial positions");
     // masses (walnutpy.cpp:64-73).  NB the reference hands init_inv_metric to the builder's
     // masses(): reproduced as is.
     if (init_inv_metric != nullptr) {
@@ -527,28 +656,36 @@ static int sample_device_impl(
       WN_CALL(wn_engine_set_step_sizes(e, steps.data(), &call_err_));
     }
     timer.mark("initial masses");
-    // adapt_step_build (walnutpy.cpp:75-80) on the normals the second thread produced
-    {
+    // adapt_step_build (walnutpy.cpp:75-80): on the normals the second thread produced, or with the device's own
+    if (reference_streams) {
       if (step_stream.joinable()) step_stream.join();
-      pool.wait_idle();
+      pool->wait_idle();
       WN_CALL(wn_engine_adapt_step_with_normals(e, z.data(), &call_err_));
+      std::vector<double>().swap(z);
+    } else {
+      WN_CALL(wn_engine_adapt_step(e, seed, static_cast<uint32_t>(chain_begin), &call_err_));
     }
-    timer.mark("step-size search (host stream)");
+    timer.mark(reference_streams ? "step-size search (host stream)" : "step-size search");
     // walnutpy.cpp:82: walnuts<mt19937_64>(seed + id + num_chains, ...)
     if (reference_streams) {
       WN_CALL(wn_engine_seed_reference_streams(e, static_cast<uint64_t>(seed) + id + num_chains, &call_err_));
     } else {
-      WN_CALL(wn_engine_seed(e, static_cast<uint64_t>(seed) + id + num_chains, 0u, &call_err_));
+      WN_CALL(wn_engine_seed(e, static_cast<uint64_t>(seed) + id + total_chains, static_cast<uint32_t>(chain_begin),
+                             &call_err_));
     }
 
-    InterruptGuard interrupt;  // walnutpy.cpp: interrupt::walnutpy_interrupt_handler on the stack of the call
+    // walnutpy.cpp: interrupt::walnutpy_interrupt_handler on the stack of the call (one guard for all shards)
+    std::unique_ptr<InterruptGuard> own_guard;
+    if (shard == nullptr || shard->interrupt == nullptr) own_guard = std::make_unique<InterruptGuard>();
+    const InterruptGuard& interrupt = own_guard ? *own_guard : *shard->interrupt;
     timer.mark("chains seeded");
     prep.join();
     if (prep_error) std::rethrow_exception(prep_error);
     DrawSink& sink = *sink_holder;
     RunAhead pace(compute);
     timer.mark("preparation thread joined (output registered, draw blocks allocated)");
-    Printer printer{print, static_cast<size_t>(refresh)};
+    // (progress lines: shard 0 speaks for all chains)
+    Printer printer{shard != nullptr && shard->shard != 0 ? nullptr : print, static_cast<size_t>(refresh)};
     // Consecutive iterations between two looks of a controller go out as ONE launch (wn_engine_*_steps: the workgroup
     // that fetched a chain runs them back to back -- the chains are independent, adapt.hpp:116-127 / sampler.hpp:82-93
     // are per-chain loops): the launch and its tail, the last chains finishing while the chip drains, are paid once
@@ -565,18 +702,23 @@ static int sample_device_impl(
       if (save_warmup) sink.rows_done(static_cast<size_t>(n));
       pace.after_enqueue();
       for (int k = 0; k < n; ++k) {  // (a Ctrl-C raised from inside a progress callback ends the call at once)
-        printer.progress(num_chains);
+        printer.progress(total_chains);
         interrupt.throw_if_interrupted();
       }
       it += n;
       // controller_loop (adapt.hpp:172-229) on the snapshots published every publish_stride = 5 iterations
       if (it >= min_warmup_iter && it < max_warmup_iter && it % publish_stride == 0) {
-        double rel_step = 0, rel_mass = 0;
-        WN_CALL(wn_engine_warmup_spread(e, &rel_step, &rel_mass, &call_err_));
-        if (rel_mass <= mass_converge_tol && rel_step <= step_size_converge_tol) break;
+        if (shard != nullptr) {
+          if (shard->coord->warmup_converged(shard->shard, e, total_chains, step_size_converge_tol, mass_converge_tol)) break;
+        } else {
+          double rel_step = 0, rel_mass = 0;
+          WN_CALL(wn_engine_warmup_spread(e, &rel_step, &rel_mass, &call_err_));
+          if (rel_mass <= mass_converge_tol && rel_step <= step_size_converge_tol) break;
+        }
       }
     }
     const size_t written_warmup = sink.written();
+    if (kept) kept->set_first_row(written_warmup);
     if (timer.on) WN_CALL(wn_engine_synchronize(e, &call_err_));
     timer.mark("warmup iterations");
     WN_CALL(wn_engine_freeze(e, &call_err_));  // on_warmup_complete, handlers.hpp:91-101
@@ -590,7 +732,7 @@ static int sample_device_impl(
     // transition with the host).
     constexpr int rhat_stride = 5;
     const auto controller_looks_after = [&](int it) {
-      return it >= min_sampling_iter && it >= 2 && it < max_sampling_iter && num_chains > 1 &&
+      return it >= min_sampling_iter && it >= 2 && it < max_sampling_iter && total_chains > 1 &&
              (it - min_sampling_iter) % rhat_stride == 0;
     };
     for (int it = 0; it < max_sampling_iter;) {  // ChainWorker loop, sampler.hpp:82-93
@@ -610,14 +752,18 @@ static int sample_device_impl(
       sampled += static_cast<size_t>(n);
       pace.after_enqueue();
       for (int k = 0; k < n; ++k) {  // (a Ctrl-C raised from inside a progress callback ends the call at once)
-        printer.progress(num_chains);
+        printer.progress(total_chains);
         interrupt.throw_if_interrupted();
       }
       it += n;
       if (controller_looks_after(it)) {
         double rhat = 0;
-        WN_CALL(wn_engine_rhat(e, &rhat, &call_err_));
-        if (print != nullptr && refresh != 0) {
+        if (shard != nullptr) {
+          rhat = shard->coord->rhat(shard->shard, e);
+        } else {
+          WN_CALL(wn_engine_rhat(e, &rhat, &call_err_));
+        }
+        if (printer.print != nullptr && refresh != 0) {
           std::stringstream ss;
           ss << "Controller: R-hat at " << std::setprecision(10) << rhat << std::endl;  // handlers.hpp:160-176
           const std::string msg = ss.str();
@@ -632,9 +778,13 @@ static int sample_device_impl(
     if (kept) kept->finish();
     timer.mark("draws in the caller's buffer");
     interrupt.throw_if_interrupted();
-    for (size_t c = 0; c < num_chains; ++c) {  // walnutpy.cpp:215-218
-      final_lengths[c] = static_cast<int>(written_warmup);
-      final_lengths[c + num_chains] = static_cast<int>(sampled);
+    {  // walnutpy.cpp:215-218
+      int* lw = shard != nullptr ? shard->lengths_warmup : final_lengths;
+      int* ls = shard != nullptr ? shard->lengths_sampling : final_lengths + num_chains;
+      for (size_t c = 0; c < num_chains; ++c) {
+        lw[c] = static_cast<int>(written_warmup);
+        ls[c] = static_cast<int>(sampled);
+      }
     }
     if (kept) {
       // the block changes hands: a wn_chains of `sampled` draws per chain that frees it when it is destroyed
@@ -649,7 +799,15 @@ static int sample_device_impl(
         rethrow(adopt_err);
       }
     }
+    timer.mark("lengths written, draw block handed over");
+    sink_holder.reset();
+    kept.reset();
+    wn_engine_destroy(guard.e);
+    guard.e = nullptr;
+    timer.mark("engine and staging memory released");
     return 0;
+  } catch (const ShardAborted&) {
+    if (err) *err = nullptr;  // (another shard holds the error this call reports)
   } catch (const InterruptException&) {
     if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error("", interrupt));
   } catch (const std::invalid_argument& ex) {
@@ -691,9 +849,11 @@ extern "C" void wn_internal_reference_normals(unsigned int seed, unsigned int st
   wnref::polar_stream_fill(rng, pool, scale, num_chains, count_per_chain, fresh_per_chain != 0, out);
 }
 
-extern "C" int walnutpie_sample_device(WN_SAMPLE_PARAMS) { return sample_device_impl(false, nullptr, WN_SAMPLE_ARGS); }
+extern "C" int walnutpie_sample_device(WN_SAMPLE_PARAMS) {
+  return sample_device_impl(false, nullptr, nullptr, WN_SAMPLE_ARGS);
+}
 extern "C" int walnutpie_sample_device_reference_streams(WN_SAMPLE_PARAMS) {
-  return sample_device_impl(true, nullptr, WN_SAMPLE_ARGS);
+  return sample_device_impl(true, nullptr, nullptr, WN_SAMPLE_ARGS);
 }
 #undef WN_SAMPLE_PARAMS
 #define WN_SAMPLE_PARAMS_NOERR                                                                                    \
@@ -710,7 +870,94 @@ extern "C" int walnutpie_sample_device_reference_streams(WN_SAMPLE_PARAMS) {
 extern "C" int walnutpie_sample_device_resident(WN_SAMPLE_PARAMS_NOERR, int thin, wn_chains** chains_out,
                                                 WalnutpyError** err) {
   const ResidentRequest req{thin, chains_out};
-  return sample_device_impl(false, &req, WN_SAMPLE_ARGS);
+  return sample_device_impl(false, &req, nullptr, WN_SAMPLE_ARGS);
+}
+
+// walnutpie_sample_device over several devices of the node: one host thread, engine and stream per entry of `devices`
+// (an ordinal may repeat: two shards on one device overlap each other's launch tails), contiguous shards of the global
+// chain ids, every shard writing its own slice of the caller's buffers.  Results do not depend on the sharding: the
+// random streams are keyed by global chain id, the controllers look at all chains (Coordinator).
+extern "C" int walnutpie_sample_device_multi(WN_SAMPLE_PARAMS_NOERR, const int* devices, int num_devices,
+                                             WalnutpyError** err) {
+  try {
+    if (devices == nullptr || num_devices < 1) throw std::invalid_argument("devices must name at least one device");
+    if (num_chains < static_cast<size_t>(num_devices)) throw std::invalid_argument("fewer chains than devices");
+    if (num_params < 1) throw std::invalid_argument("num_params must be in {1, 2, ... }");
+    if (max_sampling_iter < 0 || max_warmup_iter < 0) throw std::invalid_argument("iteration counts must be >= 0");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess) throw std::runtime_error("cannot count the devices");
+    for (int s = 0; s < num_devices; ++s)
+      if (devices[s] < 0 || devices[s] >= visible) throw std::invalid_argument("device ordinal out of range");
+    const size_t D = static_cast<size_t>(num_params);
+    const size_t rows = static_cast<size_t>(max_sampling_iter) + (save_warmup ? static_cast<size_t>(max_warmup_iter) : 0);
+    if (rows > 0 && out == nullptr) throw std::invalid_argument("out must not be null");
+    if (out_size < num_chains * rows * D) {  // walnutpy.cpp:153-160
+      std::stringstream ss;
+      ss << "Output buffer too small. Expected at least " << num_chains << " chains of " << rows * D << " doubles, got "
+         << out_size;
+      throw std::runtime_error(ss.str());
+    }
+    InterruptGuard guard;
+    Coordinator coord(num_devices, D);
+    std::vector<WalnutpyError*> errors(static_cast<size_t>(num_devices), nullptr);
+    std::vector<int> rcs(static_cast<size_t>(num_devices), 0);
+    std::vector<std::thread> threads;
+    const size_t base = num_chains / static_cast<size_t>(num_devices), extra = num_chains % static_cast<size_t>(num_devices);
+    size_t begin = 0;
+    for (int s = 0; s < num_devices; ++s) {
+      const size_t count = base + (static_cast<size_t>(s) < extra ? 1 : 0);
+      ShardCtx ctx;
+      ctx.shard = s;
+      ctx.device = devices[s];
+      ctx.chain_begin = begin;
+      ctx.total_chains = num_chains;
+      ctx.coord = &coord;
+      ctx.interrupt = &guard;
+      ctx.lengths_warmup = final_lengths + begin;
+      ctx.lengths_sampling = final_lengths + num_chains + begin;
+      threads.emplace_back([&, ctx, count, s] {
+        const double* inits_s = inits == nullptr ? nullptr : inits + ctx.chain_begin * D;
+        const double* metric_s = init_inv_metric == nullptr ? nullptr : init_inv_metric + ctx.chain_begin * D;
+        double* out_s = out == nullptr ? nullptr : out + ctx.chain_begin * rows * D;
+        double* step_s = stepsize_out == nullptr ? nullptr : stepsize_out + ctx.chain_begin;
+        double* metric_out_s = inv_metric_out == nullptr ? nullptr : inv_metric_out + ctx.chain_begin * D;
+        rcs[s] = sample_device_impl(
+            false, nullptr, &ctx, model, model_params, num_params, inits_s, count, seed, id, init_radius, metric_s,
+            min_warmup_iter, max_warmup_iter, min_sampling_iter, max_sampling_iter, max_trajectory_doublings,
+            max_step_halvings, min_micro_steps, max_hamiltonian_error, step_size_converge_tol, mass_converge_tol,
+            rhat_converge_tol, mass_init_count, mass_additive_smoothing, max_macro_steps_target, step_size_init,
+            step_accept_rate_target, step_learning_rate, step_gradient_decay, step_sq_gradient_decay,
+            step_stabilization, step_learn_rate_decay, save_warmup, out_s, count * rows * D, nullptr, step_s,
+            metric_out_s, refresh, print, &errors[s]);
+        if (rcs[s] != 0) coord.abandon();
+      });
+      begin += count;
+    }
+    for (auto& t : threads) t.join();
+    // the first shard that failed with an error of its own speaks for the call
+    int rc = 0;
+    for (int s = 0; s < num_devices; ++s) {
+      if (rcs[s] != 0 && errors[s] != nullptr && rc == 0) {
+        rc = -1;
+        if (err) *err = errors[s];
+        else walnutpie_destroy_error(errors[s]);
+        errors[s] = nullptr;
+      }
+    }
+    for (auto* e : errors)
+      if (e != nullptr) walnutpie_destroy_error(e);
+    if (rc == 0)
+      for (int s = 0; s < num_devices; ++s)
+        if (rcs[s] != 0) throw std::runtime_error("a shard ended without reporting its error");
+    return rc;
+  } catch (const std::invalid_argument& ex) {
+    if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error(ex.what(), config));
+  } catch (const std::exception& ex) {
+    if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error(ex.what(), generic));
+  } catch (...) {
+    if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error("Unknown error", generic));
+  }
+  return -1;
 }
 
 // ---- walnutpie_ess / walnutpie_r_hat / walnutpie_mcse (walnutpy.cpp:333-369) ----------------------------------

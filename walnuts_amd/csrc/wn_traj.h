@@ -1413,7 +1413,9 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   // under load) overlaps the tree instead of standing between two transitions.
   int c = static_cast<int>(blockIdx.x);
   int slot = 0;
-  while (WN_LIKELY(c < P.num_chains)) {
+  // (unsigned: a chain index that went negative -- counter and base out of step -- ends the loop instead of indexing
+  // rows in front of the planes)
+  while (WN_LIKELY(static_cast<unsigned>(c) < static_cast<unsigned>(P.num_chains))) {
     WN_PHASE_OUTER(kPhIdle);
     // (Params::fused transitions of the chain back to back; the last one issues t.prefetch_next_chain() on the way)
     int k = 0;

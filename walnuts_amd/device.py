@@ -97,6 +97,7 @@ def walnuts_device(
     reference_streams: bool = False,
     keep_on_device: bool = False,
     thin: int = 0,
+    devices=None,
     lib_path: Optional[str] = None,
     print_callback=None,
 ):
@@ -107,8 +108,15 @@ def walnuts_device(
     ``(results, chains)`` -- ``chains`` a :class:`walnuts_amd.summary.MarkovChains` over ALL sampling draws (mean,
     variance, quantiles, R-hat, ESS, MCSE computed on the device), ``results[c]`` holding only every ``thin``-th draw
     (``thin=0``: none): 65 536 chains x 1 024 parameters are 512 MiB per iteration, six times what PCIe moves in the
-    time the GPU needs to produce them."""
+    time the GPU needs to produce them.
+
+    ``devices=[0, 1, ...]`` (walnutpie_sample_device_multi): the chains are sharded over these HIP devices of the node,
+    one host thread + engine + stream each, every shard writing its own slice of the output; same result as the
+    one-device call (random streams keyed by global chain id, controllers reduced over all shards).  An ordinal may
+    repeat: ``devices=[0, 0]`` runs two half-size engines on one device, each filling the other's launch tail."""
     lib = _ffi.load_library(lib_path)
+    if devices is not None and (keep_on_device or reference_streams):
+        raise ValueError("devices is not available with keep_on_device or reference_streams")
     if keep_on_device and reference_streams:
         raise ValueError("keep_on_device is not available with reference_streams")
     if thin < 0:
@@ -160,6 +168,10 @@ def walnuts_device(
     if keep_on_device:
         entry = lib.walnutpie_sample_device_resident
         tail = (refresh, cb, thin, C.byref(chains_handle), C.byref(err))
+    if devices is not None:
+        dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+        entry = lib.walnutpie_sample_device_multi
+        tail = (refresh, cb, dev, len(devices), C.byref(err))
     rc = entry(
         model, None if mp is None else mp.ctypes.data_as(dp), num_params,
         None if inits is None else inits.ctypes.data_as(dp), num_chains, seed, id, init_radius,

@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--transitions-per-launch", type=int, default=DEFAULT_TRANSITIONS_PER_LAUNCH,
                     help="transitions of every chain per kernel launch (wn_engine_sample_steps): the workgroup that "
                          "fetched a chain runs them back to back; a step stays ONE transition of all chains")
+    ap.add_argument("--gather-method", choices=["collective", "p2p"], default="collective",
+                    help="collective: all_gather_into_tensor (RCCL picks the algorithm); p2p: all-pairs, every block "
+                         "as its own point-to-point transfer (grouped send/recv: one xGMI link per pair)")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="all-gather the draw block of every k-th launch (1 = every draw of every transition, the north star's "
                          "exchange: one collective per launch on the block of its draw planes)")
@@ -321,12 +324,34 @@ def _free_port():
     return p
 
 
+def rccl_algorithm_seen():
+    """Which algorithm / protocol RCCL used for the draw all-gather, from its own log (rank 0: NCCL_DEBUG=INFO with the
+    TUNING and COLL subsystems written to NCCL_DEBUG_FILE, set up in main() before the process group exists).  Best
+    effort: the wording of those lines is the library's; what is returned is the matching lines' own text."""
+    path = os.environ.get("WN_RCCL_LOG")
+    if not path or not os.path.exists(path):
+        return "no RCCL log (NCCL_DEBUG_FILE not written)"
+    seen = []
+    try:
+        for line in open(path, errors="replace"):
+            low = line.lower()
+            if "allgather" in low and ("algo" in low or "proto" in low):
+                text = line.split("NCCL INFO", 1)[-1].strip()
+                if text not in seen:
+                    seen.append(text)
+    except OSError as e:
+        return f"RCCL log unreadable: {e}"
+    return seen[:6] if seen else "RCCL log holds no AllGather algorithm line"
+
+
 def count_devices_without_hip():
     """GPUs of this node counted from the KFD topology in sysfs (a node with simd_count > 0 is a GPU): no HIP call, no
     context left on the devices while the parent waits for its ranks.  torch.cuda.device_count() stays off HIP only
     while its amdsmi path works and falls back to hipGetDeviceCount otherwise.  None when the topology cannot be read:
     the pre-check is then skipped and a shortage is reported by the ranks themselves."""
     base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0   # no KFD driver: no AMD GPU on this node
     try:
         n = 0
         for node in os.listdir(base):
@@ -406,6 +431,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ:
+            # (so that the line can say which all-gather algorithm ran: rccl_algorithm_seen)
+            log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"wn_rccl_{os.getpid()}.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,COLL,TUNING", NCCL_DEBUG_FILE=log,
+                              WN_RCCL_LOG=log)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -445,10 +475,12 @@ def main():
 
     T = max(1, args.transitions_per_launch)
     gather = DrawGather(dist, world, rank, total_chains, D, "cuda", torch.float64,
-                        counts=None if args.scaling == "strong" else [C] * world, transitions=T)
+                        counts=None if args.scaling == "strong" else [C] * world, transitions=T,
+                        method=args.gather_method)
 
-    def run_steps(first, count, timed_phase):
-        """`count` steps (transitions of all chains) starting at step `first`, T per launch."""
+    def run_steps(first, count, timed_phase, compute=True, exchange=True):
+        """`count` steps (transitions of all chains) starting at step `first`, T per launch.  compute / exchange: the
+        two halves of a step, switched off one at a time by the N > 1 run's separate legs."""
         launches = 0
         i = first
         while i < first + count:
@@ -456,10 +488,11 @@ def main():
             launch_id = i // T
             block = gather.buffer(launch_id)   # [rows, D], or [T, rows, D]: one draw plane per transition
             step_fn = eng.warmup_steps if timed_phase == "warmup" else eng.sample_steps
-            step_fn(n, block.data_ptr(), D, gather.rows * D)
+            if compute:
+                step_fn(n, block.data_ptr(), D, gather.rows * D)
             # the path's only exchange: all-gather of the launch's draws over xGMI, overlapped with the next launch
             # (no-op on one GPU)
-            if launch_id % args.gather_every == 0:
+            if exchange and launch_id % args.gather_every == 0:
                 gather.launch(launch_id)
             launches += 1
             i += n
@@ -498,7 +531,26 @@ def main():
                      f"one pair of HIP events around the {region_launches} launches of the timed region (gaps included)")
 
     grad_evals = g_after - g_before
+    legs = None
     if world > 1:
+        # Two more legs of the same K steps, so that the kernel's scaling and the exchange's cost can be told apart in
+        # ONE run (the line's `value` stays the full step: compute + every gathered draw): compute only, then the
+        # exchange only (the same blocks, nobody computing).
+        def leg(**kw):
+            fence()
+            t1 = time.perf_counter()
+            run_steps(0, args.steps, args.phase, **kw)
+            fence()
+            dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            return float(dt.item())
+
+        g0 = eng.total_grad_evals()
+        compute_s = leg(exchange=False)
+        gc = torch.tensor([eng.total_grad_evals() - g0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(gc, op=dist.ReduceOp.SUM)
+        exchange_s = leg(compute=False)
+        legs = {"compute_s": compute_s, "compute_grad_evals": int(gc.item()), "exchange_s": exchange_s}
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -574,6 +626,19 @@ def main():
             },
             "roofline": roofline,
         }
+        if legs is not None:
+            full_ms = elapsed / max(args.steps, 1) * 1e3
+            comp_ms = legs["compute_s"] / max(args.steps, 1) * 1e3
+            out["value_compute_only"] = legs["compute_grad_evals"] / legs["compute_s"]
+            out["ms_per_step_compute_only"] = comp_ms
+            out["exchange_ms_per_step"] = {
+                "exposed": full_ms - comp_ms,                                     # what the gathers add to a step
+                "alone": legs["exchange_s"] / max(args.steps, 1) * 1e3,           # the same collectives with nobody computing
+                "bytes_per_step_per_rank_in": (world - 1) * gather.rows * D * 8 / max(args.gather_every, 1),
+                "method": args.gather_method if args.backend == "nccl" else "gloo (host staging)",
+                "library_algorithm": rccl_algorithm_seen() if args.backend == "nccl" else None,
+                "note": "three legs of the same K steps in one run: full (value), compute only (value_compute_only), "
+                        "exchange only; DESIGN.md section 6 holds the prediction these are to confirm or refute"}
         if world == 1 and not args.no_parity_gate:
             out["parity_gate"] = parity_gate(args, D, cfg_kwargs)
         if world == 1 and not args.no_cpu_baseline:

@@ -254,6 +254,12 @@ WALNUTS_HIP_EXPORT int wn_engine_get_min_micro(wn_engine* e, int32_t* out /*[C]*
 WALNUTS_HIP_EXPORT int wn_engine_get_depths(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_grad_evals(wn_engine* e, int64_t* out /*[C]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_rng_draws(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
+/* The failure channel of a device model (the counterpart of NoExceptLogpGrad -> handler.on_logp_exception,
+ * util.hpp:336-346): a device model cannot throw, a failing one produces a non-finite log density, and the macro step
+ * attempt that met it fails its energy test (walnuts.hpp:339-344) as one with logp = -inf would in the reference.
+ * out[c] = the number of such attempts in chain c's LAST transition (of the last launch); 0 everywhere for a
+ * well-behaved model.  walnuts_hip.hpp hands the count to a handler's on_logp_exception, if it has one. */
+WALNUTS_HIP_EXPORT int wn_engine_get_nonfinite_evals(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_adam(wn_engine* e, double* out /*[C*6]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_estimator(wn_engine* e, double* draw_mean, double* draw_ssd,
                                                double* score_mean, double* score_ssd, double* weights /*[C*2]*/,

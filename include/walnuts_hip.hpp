@@ -136,6 +136,16 @@ concept ChainHandler = SampleHandler<H> && requires(H& h, VectorView position, V
   { h.on_warmup(position, lp, step_size, diag_inv_mass) } -> std::same_as<void>;
   { h.on_warmup_complete(step_size, diag_inv_mass) } -> std::same_as<void>;
 };
+/** Optional member of a chain handler (concepts.hpp:196-201: ErrorCallback): `on_logp_exception(position, exn)`.  A
+ *  device model cannot throw; what a failing one produces is a non-finite log density, and the macro-step attempts of a
+ *  transition that met one are counted on the device (wn_engine_get_nonfinite_evals).  After a transition in which
+ *  chain c's count is not zero the batched samplers call its handler's `on_logp_exception` -- if it has one -- with the
+ *  chain's position AFTER that transition (the failing point inside the trajectory is not kept) and an exception whose
+ *  text carries the count. */
+template <class H>
+concept ErrorCallback = requires(H& h, VectorView position, const std::exception& exn) {
+  { h.on_logp_exception(position, exn) } -> std::same_as<void>;
+};
 /** One chain's sampler: concepts.hpp:95-99. */
 template <class S>
 concept Sampler = requires(S& s, const S& cs) {
@@ -454,12 +464,28 @@ struct Batch {
     inv_mass_fresh = true;
   }
   VectorView row(const std::vector<double>& plane, std::size_t c) const { return {plane.data() + c * D, D}; }
+  /** `on_logp_exception` for the chains whose last transition met non-finite log densities (positions fetched). */
+  void report_model_failures() {
+    if constexpr (ErrorCallback<H>) {
+      if (handlers == nullptr) return;
+      failures.resize(C);
+      call(wn_engine_get_nonfinite_evals, e(), failures.data());
+      for (std::size_t c = 0; c < C; ++c) {
+        if (failures[c] == 0) continue;
+        const std::runtime_error exn("the device model returned a non-finite log density in " +
+                                     std::to_string(failures[c]) + " macro-step attempt(s) of this transition");
+        (*handlers)[c].on_logp_exception(row(positions, c), exn);
+      }
+    }
+  }
+  std::vector<std::int32_t> failures;
   /** One sampling transition of every chain (walnuts.hpp:682-692), then `on_sample(position, lp)` per chain. */
   void sample_step() {
     call(wn_engine_sample_step, e(), static_cast<double*>(nullptr), std::int64_t{0});
     ++produced;
     fetch_logp();
     fetch_draw();
+    report_model_failures();
     if (handlers != nullptr)
       for (std::size_t c = 0; c < C; ++c) (*handlers)[c].on_sample(row(positions, c), logp[c]);
   }
@@ -649,6 +675,7 @@ class BatchedAdaptiveWalnuts {
       b.fetch_draw();
       b.fetch_logp();
       b.fetch_steps();
+      b.report_model_failures();
       for (std::size_t c = 0; c < b.C; ++c)
         (*b.handlers)[c].on_warmup(b.row(b.positions, c), b.logp[c], b.step_sizes[c], b.row(b.inv_mass, c));
     }

@@ -22,8 +22,11 @@ ref = None
 for label, env, extra in (("host buffer, pageable (default)", {"WALNUTS_AMD_PIN_OUTPUT": "0"}, {}),
                           ("host buffer, WALNUTS_AMD_PIN_OUTPUT=1 (registered beside the streams)", {"WALNUTS_AMD_PIN_OUTPUT": "1"}, {}),
                           ("resident, every 8th draw to the host", {}, dict(keep_on_device=True, thin=8)),
-                          ("resident, no draw to the host", {}, dict(keep_on_device=True, thin=0))):
+                          ("resident, no draw to the host", {}, dict(keep_on_device=True, thin=0)),
+                          ("host buffer, two shards on the one device (devices=[0, 0])", {"WALNUTS_AMD_PIN_OUTPUT": "0"},
+                           dict(devices=[0, 0]))):
     os.environ.update(env)
+    t_alloc = time.perf_counter()
     t0 = time.perf_counter()
     res = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw, **extra)
     dt = time.perf_counter() - t0

@@ -57,6 +57,12 @@ eng.synchronize()
 blocks.launch(0)
 fused = blocks.result(0).clone().numpy()
 blocks.drain()
+# the same block exchanged all-pairs (grouped point-to-point transfers instead of the library's all-gather)
+direct = DrawGather(dist, world, rank, TOTAL, D, "cpu", torch.float64, transitions=3, method="p2p")
+direct.buffer(0).copy_(block)
+direct.launch(0)
+assert np.array_equal(direct.result(0).numpy(), fused), "p2p gather differs from the collective"
+direct.drain()
 if rank == 0:
     ref = make(0, TOTAL)
     for it in range(ITERS):

@@ -19,6 +19,17 @@ def sim():
     return simbuild.build()
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("lds_vectors", [0, 1, 2])
+def test_emulated_pool_tiers(sim, oracle, lds_vectors):
+    """The span pool's two tiers -- LDS vectors, then the HBM arena -- with the LDS tier squeezed so that deep trees
+    reach both; turn-arounds, halvings and the reversibility check's parked candidate included."""
+    parity.run_case("std_normal", 200, 2, warmup=3, sampling=4, lib_path=sim, geometry=(1, 4), step=0.11,
+                    max_trajectory_doublings=6, lds_vectors=lds_vectors)
+    parity.run_case("diag_normal", 130, 2, warmup=2, sampling=3, lib_path=sim, geometry=(1, 4), step=1.4,
+                    max_trajectory_doublings=4, lds_vectors=lds_vectors)
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("model,D,geometry,fma", [   # fma: fused multiply-adds (the default) / every product rounded
     ("std_normal", 10, None, 1),          # (1,2): D < one pair per lane, heavy padding
@@ -298,3 +309,25 @@ def test_emulated_fourth_model_added_through_the_model_interface(sim, oracle, D,
     with pytest.raises(ValueError):
         wa.model_id("no_such_model", lib_path=sim)
     parity.run_case("rw1", D, 2, warmup=3, sampling=3, lib_path=sim, geometry=geometry)
+
+
+@pytest.mark.timeout(600)
+def test_emulated_model_failure_counter(sim):
+    """wn_engine_get_nonfinite_evals, the device counterpart of the reference's on_logp_exception events
+    (util.hpp:336-346): a chain that starts where the model's log density overflows fails every attempt of its first
+    macro step (max_step_halvings of them), its extension fails and it stays put; the other chains report nothing."""
+    C, D = 3, 10
+    e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, C, wa.default_config(sim), lib_path=sim)
+    pos = np.full((C, D), 0.3)
+    pos[1] = 1e200
+    e.set_positions(pos)
+    e.set_step_sizes(0.5)
+    e.seed_chains(1, 0)
+    e.warmup_step()
+    e.synchronize()
+    assert e.nonfinite_evals().tolist() == [0, 5, 0]
+    assert np.array_equal(e.positions()[1], pos[1]) and np.all(e.positions()[0] != pos[0])
+    e.freeze()
+    e.sample_steps(2)
+    e.synchronize()
+    assert e.nonfinite_evals().tolist() == [0, 5, 0]   # (of the launch's last transition)

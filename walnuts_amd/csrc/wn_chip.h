@@ -32,6 +32,16 @@
 
 namespace wn {
 
+// Probe build only (tests/gpu_probes/pool_traffic.py, -DWN_COUNT_POOL): how many doubles per lane the span pool moved
+// through each tier since the counters were last read -- [0] LDS stores, [1] LDS loads, [2] arena (HBM) stores,
+// [3] arena loads, [4] transitions.  Compiled out of the product.
+#if defined(WN_COUNT_POOL)
+__device__ unsigned long long wn_pool_counts[5];
+#define WN_COUNT(k, n) (pool_count[k] += (n))
+#else
+#define WN_COUNT(k, n) ((void)0)
+#endif
+
 // Geometry table of the on-chip kernels: waves per SIMD the register budget is cut for.  One vector costs 2*EPL VGPRs
 // per lane; the moving end's two sets, the inverse mass and the two operands of a pool-side U-turn test must fit.
 template <class Model, int EPL>
@@ -52,6 +62,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   using typename Base::Meta;
   using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::wave;
   using Base::chain; using Base::aux; using Base::n_grad; using Base::n_draw; using Base::draw_base; using Base::err;
+  using Base::n_bad;
   using Base::max_error; using Base::min_micro; using Base::step; using Base::free_mask; using Base::onchip_mask;
   using Base::w_draw0; using Base::w_score0; using Base::meta; using Base::carry; using Base::bcast;
   static constexpr int L = Base::L;
@@ -77,6 +88,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   static constexpr int kOther = -4;           // "this vector is the other end's theta" (kOtherRegs)
   Parked oth[EPL], orh[EPL];
   int n_lds;                                  // pool buffers [0, n_lds) live in LDS, the rest in the HBM arena
+#if defined(WN_COUNT_POOL)
+  int pool_count[4];
+#endif
 
   __device__ __forceinline__ TrajChip(const Params& p, WN_LDS double* pool, WN_LDS Meta* m, WN_LDS double* r,
                                       WN_LDS double* bc, double* ar)
@@ -206,16 +220,20 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   }
   __device__ __forceinline__ void pool_load(int b, double (&v)[EPL]) {
     if (WN_LIKELY(b < n_lds)) {
+      WN_COUNT(1, EPL);
       lds_load(lds_pool + b * kDp, v);
       return;
     }
+    WN_COUNT(3, EPL);
     vload(arena + static_cast<long long>(b - n_lds) * kDp, v);
   }
   __device__ __forceinline__ void pool_store(int b, const double (&v)[EPL]) {
     if (WN_LIKELY(b < n_lds)) {
+      WN_COUNT(0, EPL);
       lds_store(lds_pool + b * kDp, v);
       return;
     }
+    WN_COUNT(2, EPL);
     vstore(arena + static_cast<long long>(b - n_lds) * kDp, v);
   }
 
@@ -330,6 +348,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   template <int CH>
   __device__ __forceinline__ void pool_load_slots(int b, int j0, double (&v)[CH]) {
     const int k0 = j0 / 2;
+    WN_COUNT(b < n_lds ? 1 : 3, CH);
     if (WN_LIKELY(b < n_lds)) {
       const WN_LDS double* base = lds_pool + b * kDp;
 #pragma unroll
@@ -415,6 +434,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         turned = p_hot < 0 || p_far < 0;
         return rev;
       }
+      if (WN_UNLIKELY(!__builtin_isfinite(logp_joint))) ++n_bad;  // (TrajBase::n_bad: the failure path only)
     }
     return false;
   }
@@ -437,10 +457,14 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   __device__ void run(int chain_id) {
     WN_PHASE(kPhPrologue);
     this->refresh_ids();
+#if defined(WN_COUNT_POOL)
+    pool_count[0] = pool_count[1] = pool_count[2] = pool_count[3] = 0;
+#endif
     chain = chain_id;
     err = 0;
     n_grad = 0;
     n_draw = 0;
+    n_bad = 0;
     draw_base = -1;
     max_error = P.max_error;
     free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
@@ -687,6 +711,12 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     WN_MARK(kPhStored);
     this->store_scalars(warm, depth, a_lpsel);
     WN_MARK(kPhScalars);
+#if defined(WN_COUNT_POOL)
+    if (tid == 0) {
+      for (int k = 0; k < 4; ++k) atomicAdd(&wn_pool_counts[k], static_cast<unsigned long long>(pool_count[k]));
+      atomicAdd(&wn_pool_counts[4], 1ull);
+    }
+#endif
   }
 
   // load the chain, refresh the momentum (walnuts.hpp:528-529), evaluate the initial point (:532)

@@ -45,6 +45,8 @@ struct wn_engine {
   int num_cus = 256;
   int grid = 0;
   int pool_lds = 0, pool_total = 0;
+  bool im_in_lds = false;  // streaming kernels: the chain's inverse mass parked in LDS (wn_traj.h: TrajMem::im_lds)
+  bool no_far_end_sums = false;  // experiment switch (WALNUTS_AMD_NO_FAR_END_SUMS=1)
   int64_t arena_stride = 0;  // doubles per persistent workgroup: HBM part of the span pool (+ streaming scratch)
   size_t smem = 0;
   hipStream_t stream = nullptr;
@@ -52,7 +54,7 @@ struct wn_engine {
   DevBuf<double> theta, mass, inv_mass, chol_mass, draw_mean, draw_ssd, score_mean, score_ssd;
   DevBuf<double> step_init, step_size, adam, est_weight, mm_state, logp, model_params, arena, z_buf, u_buf;
   DevBuf<double> lp_stats, mon_partial, mon_out, mon_colsum, mon_rel_mass, mon_rel_step;
-  DevBuf<int32_t> min_micro, depth, rng_draws;
+  DevBuf<int32_t> min_micro, depth, rng_draws, nonfinite;
   DevBuf<int64_t> grad_evals;
   DevBuf<uint32_t> counter, error_flags;
   DevBuf<unsigned long long> scratch64;
@@ -181,6 +183,7 @@ struct wn_engine {
     P.depth_out = depth.p;
     P.grad_evals = grad_evals.p;
     P.rng_draws = rng_draws.p;
+    P.nonfinite = nonfinite.p;
     P.lp_stats = lp_stats.p;
     P.draws_out = draws_dev;
     P.draws_stride = draws_stride;
@@ -211,6 +214,7 @@ struct wn_engine {
     P.arena = arena.p;
     P.arena_stride = arena_stride;
     P.pool_lds = pool_lds;
+    P.im_in_lds = (im_in_lds ? 1u : 0u) | (no_far_end_sums ? 2u : 0u);
     P.pool_total = pool_total;
     P.work_counter = counter.p;
     P.error_flags = error_flags.p;
@@ -348,6 +352,16 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   if (e.geo.mem) lds_vecs = 0;  // streaming backend: vectors are far larger than LDS
   e.pool_lds = std::min(lds_vecs, e.pool_total);
   e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds, e.Dp);
+  if (e.geo.mem) {
+    // one more vector per workgroup, if the CU's LDS holds it for every resident workgroup: the inverse mass
+    const char* off = std::getenv("WALNUTS_AMD_NO_LDS_MASS");
+    const char* nf = std::getenv("WALNUTS_AMD_NO_FAR_END_SUMS");
+    e.no_far_end_sums = nf != nullptr && nf[0] == '1';
+    if (e.smem + vec_bytes <= budget && !(off != nullptr && off[0] == '1')) {
+      e.im_in_lds = true;
+      e.smem += vec_bytes;
+    }
+  }
   const int usable_cus = std::max(1, e.num_cus - std::max(0, cfg.reserved_cus));
   e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(usable_cus) * wg_per_cu));
 
@@ -363,6 +377,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.min_micro.alloc(num_chains);
   e.depth.alloc(num_chains);
   e.rng_draws.alloc(num_chains);
+  e.nonfinite.alloc(num_chains);
   e.grad_evals.alloc(num_chains);
   e.counter.alloc(1);
   HIP_OK(hipMemsetAsync(e.counter.p, 0, sizeof(uint32_t), e.stream));
@@ -390,6 +405,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   HIP_OK(hipMemsetAsync(e.grad_evals.p, 0, num_chains * sizeof(int64_t), e.stream));
   HIP_OK(hipMemsetAsync(e.depth.p, 0, num_chains * sizeof(int32_t), e.stream));
   HIP_OK(hipMemsetAsync(e.rng_draws.p, 0, num_chains * sizeof(int32_t), e.stream));
+  HIP_OK(hipMemsetAsync(e.nonfinite.p, 0, num_chains * sizeof(int32_t), e.stream));
   HIP_OK(hipMemsetAsync(e.logp.p, 0, num_chains * sizeof(double), e.stream));
   HIP_OK(hipMemsetAsync(e.lp_stats.p, 0, 3 * num_chains * sizeof(double), e.stream));
   {
@@ -724,6 +740,12 @@ int wn_engine_get_depths(wn_engine* e, int32_t* out, WalnutpyError** err) {
 int wn_engine_get_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err) {
   return guarded(err, [&] {
     if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download(e->grad_evals, out, e->C); });
+}
+int wn_engine_get_nonfinite_evals(wn_engine* e, int32_t* out, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument");
+    e->download(e->nonfinite, out, e->C);
+  });
 }
 int wn_engine_get_rng_draws(wn_engine* e, int32_t* out, WalnutpyError** err) {
   return guarded(err, [&] {

@@ -45,6 +45,7 @@ struct Params {
   int32_t* depth_out;  // [C]
   int64_t* grad_evals; // [C] running totals
   int32_t* rng_draws;  // [C] scalar draws of the last transition
+  int32_t* nonfinite;  // [C] macro-step attempts of the last transition that ended with a non-finite log density
   double* lp_stats;    // [C][3] WelfordAccumulator (count, mean, M2) of the sampling log densities
   // output of this transition
   double* draws_out;   // nullable; chain c's row of the launch's k-th transition at draws_out + c*draws_stride + k*draws_tstride
@@ -78,7 +79,8 @@ struct Params {
   int32_t fused;         // transitions per launch (>= 1): a workgroup runs them back to back on the chain it fetched
   uint32_t* work_counter;  // chains fetched so far by all launches of this engine (mod 2^32; never reset)
   uint32_t work_base;      // its value when this launch starts
-  uint32_t pad2;
+  uint32_t im_in_lds;      // streaming kernels: bit 0 = the chain's inverse mass is parked in LDS for the whole
+                           // transition; bit 1 = (experiment switch) no far-end sums in the leaf's pass
   uint32_t* error_flags;  // OR of kErr* bits of every chain and transition since wn_engine_check last read (and cleared) it
 };
 

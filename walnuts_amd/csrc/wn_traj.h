@@ -48,6 +48,10 @@ namespace wn {
 // reduction scratch in LDS: two parity halves of (4 per wavefront + 1 carried scalar)
 constexpr int kRedStride(int nw) { return 4 * nw + 1; }
 constexpr int kRedDoubles(int nw) { return 2 * kRedStride(nw); }
+// cx.shift() scratch: the edge lanes of every wavefront publish one value per pair slot (at most 8 pairs per lane)
+// (LDS tail of a workgroup: per-wave Meta | reduction scratch | broadcast word | next-chain words | shift scratch |
+// streaming kernels: the inverse mass vector, when the engine parks it there)
+constexpr int kShiftDoubles(int nw) { return 2 * 8 * nw; }
 
 // The exp / log tables (wn_devmath.h) as one entry per lane of three VGPR pairs.  A wave-uniform argument looks its
 // entries up with v_readlane (a few cycles, no memory), per-lane arguments with a lane gather.
@@ -175,6 +179,11 @@ struct TrajBase {
   bool carry_armed;
   long long n_grad;
   int n_draw;
+  // The device counterpart of NoExceptLogpGrad -> handler.on_logp_exception (util.hpp:336-346, concepts.hpp:196-201): a
+  // device model cannot throw; what a failing model produces instead is a non-finite log density, which makes the
+  // energy test of its macro-step attempt fail.  Those attempts are counted per chain and transition -- on the failure
+  // path of the test only, nothing on the path of an accepted leaf -- and reported through wn_engine_get_nonfinite_evals.
+  int n_bad;
   int draw_base;  // first tree-draw index held in draw_u / draw_lu (-1: none)
   double draw_u, draw_lu;
   int err;
@@ -603,6 +612,7 @@ struct TrajBase {
         Q.grad_evals[chain] += n_grad;
       }
       Q.rng_draws[chain] = n_draw;
+      Q.nonfinite[chain] = n_bad;
     }
   }
 
@@ -629,6 +639,7 @@ struct TrajBase {
         if (rev) self().macro_commit();
         return rev;
       }
+      if (!__builtin_isfinite(logp_joint)) ++n_bad;  // (see n_bad)
       WN_PHASE(kPhRestart);
     }
     return false;
@@ -649,6 +660,7 @@ struct TrajBase {
     err = 0;
     n_grad = 0;
     n_draw = 0;
+    n_bad = 0;
     draw_base = -1;
     max_error = P.max_error;
     free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
@@ -726,6 +738,32 @@ struct TrajBase {
       double c_logsum = 0.0, c_lpsel = 0.0;
       for (int i = 0; i < nleaf; ++i) {
         double leaf_lp, leaf_lj;
+        {
+          // The U-turn tests this leaf's end state will face once it is built -- the merge cascade's levels above the
+          // leaf pair (every set low bit of i beyond bit 0 pops one stack entry, see below) and, after the doubling's last
+          // leaf, the accumulated span's other end -- are announced to the backend, which may take their sums along in
+          // the leaf's own pass (TrajMem::expect_far_ends).
+          // (slot 0: the accumulated span's other end after the doubling's last leaf; slots 1, 2: cascade levels 1, 2 --
+          // fixed slots, so that the backend's copies stay in registers)
+          int far_th[3] = {-1, -1, -1}, far_rh[3] = {-1, -1, -1};
+          int nfar = 0;
+          if (i + 1 == nleaf) {
+            far_th[0] = fwd ? a_bk[0] : a_fw[0];
+            far_rh[0] = fwd ? a_bk[1] : a_fw[1];
+            nfar = 1;
+          }
+          if ((i & 3) == 3) {
+            far_th[1] = uni(meta->in_th[sp - 2]);
+            far_rh[1] = uni(meta->in_rh[sp - 2]);
+            nfar = 2;
+            if ((i & 7) == 7) {
+              far_th[2] = uni(meta->in_th[sp - 3]);
+              far_rh[2] = uni(meta->in_rh[sp - 3]);
+              nfar = 3;
+            }
+          }
+          self().expect_far_ends(nfar, far_th, far_rh);
+        }
         if (!macro_step(fwd, h_cur, leaf_lp, leaf_lj)) {  // build_leaf, walnuts.hpp:420-442
           ok = false;
           break;
@@ -888,6 +926,21 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   unsigned own;
   double* im_buf;   // warmup: this transition's inverse mass
   const double* im; // inverse mass row in force
+  // Round 4: with room in LDS (one chain per CU at 16 wavefronts: 128 KB at 16 384 dimensions) the inverse mass is
+  // parked there for the whole transition -- every micro step and every U-turn test then reads 8 bytes per element less
+  // from the memory system, which is what bounds these kernels.  Each lane reads back exactly the elements it wrote.
+  WN_LDS double* im_lds;
+  // The far ends the merge cascade after the running leaf will test the leaf's end state against (walnuts.hpp:192-201
+  // at every level of build_span, :490-492, and at the top, :546-549), announced by the tree loop BEFORE the leaf: a
+  // single-step leaf accumulates their partial sums in its own pass, where the new (theta, rho) and the inverse mass
+  // are in registers -- a later test then costs the far end's two vectors instead of five.
+  static constexpr int kMaxPending = 3;
+  const double* pend_th[kMaxPending];
+  const double* pend_rh[kMaxPending];
+  int pend_bth[kMaxPending], pend_brh[kMaxPending];
+  double pend_hot[kMaxPending], pend_far[kMaxPending];
+  int n_pend;
+  bool pend_valid;
   double ke_part;   // kinetic partial of the state produced by the last pass
   double ut_hot, ut_far;  // per-lane partials of the level-0 U-turn sums of the last forward pass
   bool ut_valid;          // ... valid: that pass was the whole macro step (one micro step)
@@ -902,6 +955,9 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     own = 0u;
     ut_valid = false;
     ut_hot = ut_far = 0.0;
+    im_lds = (p.im_in_lds & 1u) ? bc + 2 + kShiftDoubles(NW) : nullptr;
+    n_pend = 0;
+    pend_valid = false;
     for (int r = 0; r < 12; ++r) slot_buf[r] = -1;
     for (int i = 0; i < 3; ++i) cur[i] = alt[i] = work[i] = tmp[i] = nullptr;
     ke_part = 0.0;
@@ -928,6 +984,30 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     *reinterpret_cast<v2f64*>(p) = t;
   }
   __device__ __forceinline__ double* pool_ptr(int b) const { return arena + static_cast<long long>(b) * Dp; }
+  __device__ __forceinline__ v2f64 mass_at(int o) const {
+    if (im_lds != nullptr) return *reinterpret_cast<const WN_LDS v2f64*>(im_lds + o);
+    return ld(im + o);
+  }
+  // the tree loop's announcement (TrajBase::run): buffers of the far ends the coming tests will name
+  __device__ __forceinline__ void expect_far_ends(int n, const int* bth, const int* brh) {
+    n_pend = 0;
+    pend_valid = false;
+    if constexpr (!kTwoPass) {
+      if (P.im_in_lds & 2u) n = 0;  // (experiment switch WALNUTS_AMD_NO_FAR_END_SUMS: every test reads its five vectors)
+      // (every index into the pend_* arrays is a compile-time constant after unrolling: they live in registers, not scratch)
+#pragma unroll
+      for (int k = 0; k < kMaxPending; ++k) {
+        pend_bth[k] = -1;  // (an unused slot)
+        if (k < n && bth[k] >= 0) {
+          pend_bth[k] = bth[k];
+          pend_brh[k] = brh[k];
+          pend_th[k] = pool_ptr(bth[k]);
+          pend_rh[k] = pool_ptr(brh[k]);
+          n_pend = k + 1;
+        }
+      }
+    }
+  }
   __device__ __forceinline__ void copy(double* dst, const double* src) const {
     for (int k = 0; k < tiles; ++k) {
       const int o = pair_offset(k);
@@ -1056,7 +1136,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
       for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
       for (int k = 0; k < tiles; ++k) {
         const int o = pair_offset(k);
-        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), m0 = ld(im + o);
+        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), m0 = mass_at(o);
         double th2[2] = {t0[0], t0[1]}, rh2[2] = {neg ? -r0[0] : r0[0], neg ? -r0[1] : r0[1]};
         double g2[2], mp2[2], prev[2], next[2];
         load_mp(o, mp2);
@@ -1078,7 +1158,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
       ke = 0.0;
       for (int k = 0; k < tiles; ++k) {
         const int o = pair_offset(k);
-        const v2f64 t1 = ld(out[0] + o), r1 = ld(out[1] + o), m0 = ld(im + o);
+        const v2f64 t1 = ld(out[0] + o), r1 = ld(out[1] + o), m0 = mass_at(o);
         const double th2[2] = {t1[0], t1[1]};
         double rh2[2] = {r1[0], r1[1]}, g2[2], mp2[2], prev[2], next[2];
         load_mp(o, mp2);
@@ -1116,6 +1196,9 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     const bool fuse = !negate && n == 1;
     const bool fwd = h > 0;
     double p_hot = 0.0, p_far = 0.0;
+    const int np = fuse ? n_pend : 0;
+#pragma unroll
+    for (int q = 0; q < kMaxPending; ++q) pend_hot[q] = pend_far[q] = 0.0;
     for (int s = 0; s < n; ++s) {
       double* const* in = (s == 0) ? src : dst;
       const bool neg = negate && s == 0;
@@ -1123,7 +1206,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
       ke = 0.0;
       for (int k = 0; k < tiles; ++k) {
         const int o = pair_offset(k);
-        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), m0 = ld(im + o);
+        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), m0 = mass_at(o);
         double th2[2] = {t0[0], t0[1]}, rh2[2] = {neg ? -r0[0] : r0[0], neg ? -r0[1] : r0[1]};
         double g2[2], mp2[2] = {1.0, 1.0};
         if (Model::kUsesParams) {
@@ -1152,6 +1235,20 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
             p_hot = mad(rh2[j], sd, p_hot);
             p_far = mad(r0[j], sd, p_far);
           }
+          // ... and the same products against the announced far ends (uturn_ptrs' expressions in uturn_ptrs' order)
+#pragma unroll
+          for (int q = 0; q < kMaxPending; ++q) {
+            if (q < np && pend_bth[q] >= 0) {
+              const v2f64 av = ld(pend_th[q] + o), bv = ld(pend_rh[q] + o);
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const double diff = fwd ? (th2[j] - av[j]) : (av[j] - th2[j]);
+                const double sd = m0[j] * diff;
+                pend_hot[q] = mad(rh2[j], sd, pend_hot[q]);
+                pend_far[q] = mad(bv[j], sd, pend_far[q]);
+              }
+            }
+          }
         }
         st(dst[0] + o, th2[0], th2[1]);
         st(dst[1] + o, rh2[0], rh2[1]);
@@ -1163,6 +1260,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
       ut_valid = fuse;
       ut_hot = p_hot;
       ut_far = p_far;
+      pend_valid = fuse;
     }
     return part;
   }
@@ -1224,7 +1322,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     double p_hot = 0.0, p_far = 0.0;
     for (int k = 0; k < tiles; ++k) {
       const int o = pair_offset(k);
-      const v2f64 t = ld(cur[0] + o), r = ld(cur[1] + o), m = ld(im + o), av = ld(a + o), bv = ld(b + o);
+      const v2f64 t = ld(cur[0] + o), r = ld(cur[1] + o), m = mass_at(o), av = ld(a + o), bv = ld(b + o);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const double diff = fwd ? (t[j] - av[j]) : (av[j] - t[j]);
@@ -1245,12 +1343,30 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     return uturn_ptrs(alt[0], alt[1], fwd);
   }
   __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
+    if (pend_valid) {  // the accepted single-step leaf's pass took this far end's sums along
+      bool have = false;
+      double p_hot = 0.0, p_far = 0.0;
+#pragma unroll
+      for (int q = 0; q < kMaxPending; ++q) {
+        if (q < n_pend && pend_bth[q] >= 0 && pend_bth[q] == bth && pend_brh[q] == brh) {
+          have = true;
+          p_hot = pend_hot[q];
+          p_far = pend_far[q];
+        }
+      }
+      if (have) {
+        this->sum2(p_hot, p_far);
+        return p_hot < 0 || p_far < 0;
+      }
+    }
     return uturn_ptrs(pool_ptr(bth), pool_ptr(brh), fwd);
   }
 
   __device__ __forceinline__ double begin_transition(long long row, bool warm) {
     const double wd = w_draw0, ws = w_score0;
     im = warm ? im_buf : P.inv_mass + row;
+    n_pend = 0;
+    pend_valid = false;
     own = 0u;  // the base has just marked every pool buffer free
     for (int r = 0; r < 12; ++r) slot_buf[r] = -1;
     ensure_writable(0);
@@ -1273,11 +1389,17 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
           m2[j] = __builtin_sqrt((ds[j] / wd) / (ss[j] / ws));
           ch2[j] = __builtin_sqrt(1.0 / m2[j]);
         }
-        st(im_buf + o, m2[0], m2[1]);
+        if (im_lds == nullptr) st(im_buf + o, m2[0], m2[1]);
       } else {
         const v2f64 m0 = ld(P.inv_mass + row + o), c0 = ld(P.chol_mass + row + o);
         m2[0] = m0[0]; m2[1] = m0[1];
         ch2[0] = c0[0]; ch2[1] = c0[1];
+      }
+      if (im_lds != nullptr) {
+        v2f64 mm;
+        mm[0] = m2[0];
+        mm[1] = m2[1];
+        *reinterpret_cast<WN_LDS v2f64*>(im_lds + o) = mm;
       }
       if (P.rng_mode == kRngBuffer) {
         const v2f64 z0 = ld(P.z_buf + row + o);
@@ -1446,8 +1568,6 @@ __global__ __launch_bounds__(64 * NW) void transition_kernel_mem(const Params P)
   persistent_loop<TrajMem<Model, NW, FMA>, NW>(P);
 }
 
-// cx.shift() scratch: the edge lanes of every wavefront publish one value per pair slot (at most 8 pairs per lane)
-constexpr int kShiftDoubles(int nw) { return 2 * 8 * nw; }
 inline size_t transition_smem_bytes(int nw, int lds_vectors, int dim_padded) {
   return (static_cast<size_t>(lds_vectors) * dim_padded + static_cast<size_t>(nw) * kMetaDoubles + kRedDoubles(nw) + 2 +
           kShiftDoubles(nw)) *

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
+from collections.abc import Sequence
 from typing import Generic, Optional, TypeVar
 
 import numpy as np
@@ -33,6 +34,31 @@ class WalnutsOutputArray(np.ndarray):  # python/src/walnutpie/pyfunc.py (ndarray
         if obj is None:
             return
         self.warmup = getattr(obj, "warmup", None)
+
+
+class ChainResults(Sequence):
+    """The per-chain results of a call with MANY chains, built on access: ``results[c]`` is what the reference's list
+    holds at index c (pyfunc.py:270-286: the chain's sampling draws as an array carrying ``.warmup``).  Creating 65 536
+    array views and WarmupInfo objects up front costs 0.2 s -- more than the 0.14 s the device needs for 20 + 32
+    iterations of 65 536 x 1 024 (profiles/r04/sample_device_e2e.txt) -- so beyond ``LIST_LIMIT`` chains the call returns
+    this sequence (len, indexing, slicing, iteration, ``list(results)``) instead of a list."""
+
+    LIST_LIMIT = 4096
+
+    def __init__(self, make, n):
+        self._make, self._n = make, n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._make(c) for c in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError("chain index out of range")
+        return self._make(i)
 
 
 def _prepare_output_buffer(*, num_chains, num_params, max_sampling_iter, max_warmup_iter, save_warmup):
@@ -172,6 +198,12 @@ def walnuts_device(
         dev = (C.c_int * len(devices))(*[int(d) for d in devices])
         entry = lib.walnutpie_sample_device_multi
         tail = (refresh, cb, dev, len(devices), C.byref(err))
+    import os
+    import sys
+    import time
+
+    timing = os.environ.get("WALNUTS_AMD_TIMING") is not None   # the C side prints its phases under the same switch
+    t_call = time.perf_counter()
     rc = entry(
         model, None if mp is None else mp.ctypes.data_as(dp), num_params,
         None if inits is None else inits.ctypes.data_as(dp), num_chains, seed, id, init_radius,
@@ -184,16 +216,24 @@ def walnuts_device(
         stepsize_out.ctypes.data_as(dp), None if inv_metric_out is None else inv_metric_out.ctypes.data_as(dp),
         *tail)
     _ffi.check(lib, rc, err)
+    t_done = time.perf_counter()
 
-    results = []  # python/src/walnutpie/pyfunc.py:270-286
-    for c in range(num_chains):
+    def result_of(c):  # python/src/walnutpie/pyfunc.py:270-286
         n_warm, n_samp = int(final_lengths[c]), int(final_lengths[num_chains + c])
         warm = out[c, :n_warm] if save_warmup else None
         info = WarmupInfo(stepsize=float(stepsize_out[c]),
                           inv_metric=None if inv_metric_out is None else inv_metric_out[c], warmup_draws=warm)
         if keep_on_device:   # rows 0, thin, 2 thin, ... of the n_samp draws the device holds
             n_samp = 0 if thin == 0 else -(-n_samp // thin)
-        results.append(WalnutsOutputArray(out[c, n_warm:n_warm + n_samp], info))
+        return WalnutsOutputArray(out[c, n_warm:n_warm + n_samp], info)
+
+    # a list, as the reference returns it; for very many chains the same thing built on access (ChainResults)
+    results = (ChainResults(result_of, num_chains) if num_chains > ChainResults.LIST_LIMIT
+               else [result_of(c) for c in range(num_chains)])
+    if timing:
+        print(f"[walnuts_amd] {'C entry point (all phases above)':34s} {(t_done - t_call) * 1e3:9.3f} ms\n"
+              f"[walnuts_amd] {'per-chain result objects (Python)':34s} {(time.perf_counter() - t_done) * 1e3:9.3f} ms",
+              file=sys.stderr, flush=True)
     if keep_on_device:
         from .summary import MarkovChains
 

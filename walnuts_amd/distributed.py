@@ -32,9 +32,12 @@ class DrawGather:
     [transitions, total_chains, D]."""
 
     def __init__(self, dist, world: int, rank: int, total_chains: int, dim: int, device, dtype, counts=None,
-                 transitions: int = 1):
+                 transitions: int = 1, method: str = "collective"):
         import torch
 
+        if method not in ("collective", "p2p"):
+            raise ValueError("gather method must be 'collective' or 'p2p'")
+        self.method = method
         self.dist, self.world, self.rank = dist, world, rank
         self.counts = list(counts) if counts is not None else [shard_chains(total_chains, r, world)[1]
                                                                 for r in range(world)]
@@ -64,7 +67,21 @@ class DrawGather:
         if self.world == 1:
             return None
         b = it & 1
-        self.pending[b] = self.dist.all_gather_into_tensor(self.gathered[b], self.local[b], async_op=True)
+        if self.method == "collective":   # whatever algorithm the library picks (RCCL: ring / tree / direct)
+            self.pending[b] = self.dist.all_gather_into_tensor(self.gathered[b], self.local[b], async_op=True)
+            return self.gathered[b]
+        # all-pairs, direct: this rank's block goes to every peer as its own point-to-point transfer (and the peers'
+        # blocks arrive the same way), one grouped launch.  On a fully connected xGMI node every pair has a link of its
+        # own, so the W - 1 inbound blocks arrive on W - 1 links at once -- the time of ONE block over one link, where a
+        # ring all-gather forwards W - 1 blocks over each link one after the other.
+        g = self.gathered[b].view((self.world,) + tuple(self.local[b].shape))
+        g[self.rank].copy_(self.local[b])
+        ops = []
+        for r in range(self.world):
+            if r != self.rank:
+                ops.append(self.dist.P2POp(self.dist.isend, self.local[b], r))
+                ops.append(self.dist.P2POp(self.dist.irecv, g[r], r))
+        self.pending[b] = _Requests(self.dist.batch_isend_irecv(ops))
         return self.gathered[b]
 
     def result(self, it: int):
@@ -91,6 +108,17 @@ class DrawGather:
             if self.pending[b] is not None:
                 self.pending[b].wait()
                 self.pending[b] = None
+
+
+class _Requests:
+    """The requests of one grouped point-to-point exchange behind the `.wait()` of a collective's work handle."""
+
+    def __init__(self, reqs):
+        self.reqs = list(reqs)
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
 
 
 def _all_reduce(dist, values, op, device):

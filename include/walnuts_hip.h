@@ -254,12 +254,16 @@ WALNUTS_HIP_EXPORT int wn_engine_get_min_micro(wn_engine* e, int32_t* out /*[C]*
 WALNUTS_HIP_EXPORT int wn_engine_get_depths(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_grad_evals(wn_engine* e, int64_t* out /*[C]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_rng_draws(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
-/* The failure channel of a device model (the counterpart of NoExceptLogpGrad -> handler.on_logp_exception,
- * util.hpp:336-346): a device model cannot throw, a failing one produces a non-finite log density, and the macro step
- * attempt that met it fails its energy test (walnuts.hpp:339-344) as one with logp = -inf would in the reference.
- * out[c] = the number of such attempts in chain c's LAST transition (of the last launch); 0 everywhere for a
- * well-behaved model.  walnuts_hip.hpp hands the count to a handler's on_logp_exception, if it has one. */
-WALNUTS_HIP_EXPORT int wn_engine_get_nonfinite_evals(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
+/* The failure channel of a device model.  The reference traps a throwing model (NoExceptLogpGrad, util.hpp:336-346:
+ * logp = -inf, grad = 0, handler.on_logp_exception); a device model cannot throw -- what a failing one produces is a
+ * non-finite log density, and the leaf that meets it fails its energy test at every step size (walnuts.hpp:339-344),
+ * the extension fails and the transition ends where it is (:543-545), exactly as logp = -inf does in the reference.
+ * out[c] = 1 if an extension of chain c's LAST transition (of the last launch) failed that way -- which is also what a
+ * finite energy error above max_hamiltonian_error at every step size, or a failed reversibility check, looks like: a
+ * chain that reports it transition after transition is stuck at a point its model cannot leave.  Recording more (a
+ * count of non-finite attempts) costs the headline kernel 2-8 %: profiles/r04/headline_attempts.md.  walnuts_hip.hpp
+ * hands the flag to a handler's on_extension_failed, if it has one. */
+WALNUTS_HIP_EXPORT int wn_engine_get_failed_extensions(wn_engine* e, int32_t* out /*[C]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_adam(wn_engine* e, double* out /*[C*6]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_get_estimator(wn_engine* e, double* draw_mean, double* draw_ssd,
                                                double* score_mean, double* score_ssd, double* weights /*[C*2]*/,

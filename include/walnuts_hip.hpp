@@ -136,15 +136,16 @@ concept ChainHandler = SampleHandler<H> && requires(H& h, VectorView position, V
   { h.on_warmup(position, lp, step_size, diag_inv_mass) } -> std::same_as<void>;
   { h.on_warmup_complete(step_size, diag_inv_mass) } -> std::same_as<void>;
 };
-/** Optional member of a chain handler (concepts.hpp:196-201: ErrorCallback): `on_logp_exception(position, exn)`.  A
- *  device model cannot throw; what a failing one produces is a non-finite log density, and the macro-step attempts of a
- *  transition that met one are counted on the device (wn_engine_get_nonfinite_evals).  After a transition in which
- *  chain c's count is not zero the batched samplers call its handler's `on_logp_exception` -- if it has one -- with the
- *  chain's position AFTER that transition (the failing point inside the trajectory is not kept) and an exception whose
- *  text carries the count. */
+/** Optional member of a chain handler: `on_extension_failed(position)`.  The reference's ErrorCallback
+ *  (concepts.hpp:196-201: `on_logp_exception(position, exn)`) reports a THROWING model; a device model cannot throw --
+ *  what a failing one produces is a non-finite log density, the leaf that meets it fails its energy test at every step
+ *  size and the extension fails (walnuts.hpp:339-344,:543-545), as with logp = -inf in the reference.  The device flags
+ *  the transitions in which an extension failed (wn_engine_get_failed_extensions; also set by a finite energy error
+ *  above the bound at every step size) and the batched samplers pass the flag on -- with the chain's position after
+ *  that transition -- to handlers that have this member. */
 template <class H>
-concept ErrorCallback = requires(H& h, VectorView position, const std::exception& exn) {
-  { h.on_logp_exception(position, exn) } -> std::same_as<void>;
+concept FailureCallback = requires(H& h, VectorView position) {
+  { h.on_extension_failed(position) } -> std::same_as<void>;
 };
 /** One chain's sampler: concepts.hpp:95-99. */
 template <class S>
@@ -464,18 +465,14 @@ struct Batch {
     inv_mass_fresh = true;
   }
   VectorView row(const std::vector<double>& plane, std::size_t c) const { return {plane.data() + c * D, D}; }
-  /** `on_logp_exception` for the chains whose last transition met non-finite log densities (positions fetched). */
+  /** `on_extension_failed` for the chains whose last transition had a failed extension (positions fetched). */
   void report_model_failures() {
-    if constexpr (ErrorCallback<H>) {
+    if constexpr (FailureCallback<H>) {
       if (handlers == nullptr) return;
       failures.resize(C);
-      call(wn_engine_get_nonfinite_evals, e(), failures.data());
-      for (std::size_t c = 0; c < C; ++c) {
-        if (failures[c] == 0) continue;
-        const std::runtime_error exn("the device model returned a non-finite log density in " +
-                                     std::to_string(failures[c]) + " macro-step attempt(s) of this transition");
-        (*handlers)[c].on_logp_exception(row(positions, c), exn);
-      }
+      call(wn_engine_get_failed_extensions, e(), failures.data());
+      for (std::size_t c = 0; c < C; ++c)
+        if (failures[c] != 0) (*handlers)[c].on_extension_failed(row(positions, c));
     }
   }
   std::vector<std::int32_t> failures;

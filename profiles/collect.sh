@@ -1,9 +1,10 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): the round-3 bench lines of every BASELINE configuration + the rocprofv3
-# kernel trace of the headline.  Outputs land in gpurun_out/r03/; PMC passes are profiles/pmc.sh's.
+# Runs ON THE GPU BOX (through gpurun): the round's bench lines of every BASELINE configuration + the rocprofv3
+# kernel trace of the headline.  Outputs land in gpurun_out/$PROFILE_ROUND/ (default r04); PMC passes are profiles/pmc.sh's.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r03
+R=${PROFILE_ROUND:-r04}
+OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py"
@@ -12,6 +13,7 @@ $B --phase warmup --no-cpu-baseline --no-parity-gate > $OUT/bench_headline_warmu
 $B --no-cpu-baseline --model ill_normal --chains 4096 --dim 1024 --adapt-iters 300 > $OUT/bench_cfg2.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 128 --adapt-iters 300 > $OUT/bench_cfg3.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4.json 2>> $OUT/bench.err
+WALNUTS_AMD_NO_LDS_MASS=1 WALNUTS_AMD_NO_FAR_END_SUMS=1 $B --no-cpu-baseline --no-parity-gate --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4_round3_byte_budget.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --config 5 --steps 16 --warmup 8 > $OUT/bench_cfg5_one_gpu.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_funnel_1024.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model rw1 --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_rw1_1024.json 2>> $OUT/bench.err
@@ -24,7 +26,7 @@ $B --no-cpu-baseline --model funnel --chains 8192 --dim 16384 --steps 8 --warmup
 $B --no-cpu-baseline --model rw1 --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_rw1_16384_streaming.json 2>> $OUT/bench.err
 $B --gpus 2 --backend gloo --no-cpu-baseline --steps 16 --warmup 8 > $OUT/bench_gloo2_one_gpu.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --steps 16 --warmup 8 > /dev/null 2>&1
-python3 $ROOT/profiles/summarize.py r03 $(find $OUT/headline_trace -name "*results.db" | head -1) > $OUT/kernel_trace_headline.txt 2>&1
+python3 $ROOT/profiles/summarize.py $R $(find $OUT/headline_trace -name "*results.db" | head -1) > $OUT/kernel_trace_headline.txt 2>&1
 rm -rf $OUT/headline_trace
 for f in $OUT/bench_*.json; do python3 -c "
 import json,sys

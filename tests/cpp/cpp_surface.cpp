@@ -254,34 +254,32 @@ extern "C" __attribute__((visibility("default"))) int cpp_surface_run(const char
     for (std::size_t c = 1; c < C; ++c) EXPECT(st[c].lp.size() == st[0].lp.size());  // lock step: equal lengths
   }
 
-  // ---- the failure channel of a device model (concepts.hpp:196-201, util.hpp:336-346) -------------------------------
-  // chain 0 starts where the standard normal's log density overflows to -inf: every attempt of its first macro step
-  // meets a non-finite energy, the extension fails (walnuts.hpp:543-545), the chain stays where it is -- and its
-  // handler hears about it; the other chains' handlers do not
+  // ---- the failure channel of a device model (the counterpart of concepts.hpp:196-201, util.hpp:336-346) ------------
+  // chain 0 starts where the standard normal's log density overflows to -inf: its first leaf meets a non-finite energy
+  // at every step size, the extension fails (walnuts.hpp:543-545), the chain stays where it is -- and its handler hears
+  // about it after every transition; the other chains' handlers do not
   if (model_name == "std_normal" && C > 1) {
     struct Listening : ChainStore {
-      int exceptions = 0;
-      std::string last;
-      void on_logp_exception(const std::vector<double>& position, const std::exception& e) {
-        ++exceptions;
-        last = e.what();
-        (void)position;
+      int failed = 0;
+      double where = 0;
+      void on_extension_failed(const std::vector<double>& position) {
+        ++failed;
+        where = position[0];
       }
     };
-    static_assert(wh::ErrorCallback<Listening>);
-    static_assert(!wh::ErrorCallback<ChainStore>);
+    static_assert(wh::FailureCallback<Listening>);
+    static_assert(!wh::FailureCallback<ChainStore>);
     std::vector<double> pos(C * D, 0.25);
     for (std::size_t d = 0; d < D; ++d) pos[d] = 1e200;
-    const wh::WalnutsConfig cfg(wh::InitConfigBuilder(C, D).positions(pos).masses(std::vector<double>(C * D, 1.0)).step_sizes(0.5).build(),
+    const wh::WalnutsConfig cfg(wh::InitConfigBuilder(C, D).positions(pos).masses(std::vector<double>(C * D, 1.0)).step_sizes(1e-3).build(),   // (so small a step that nothing else fails)
                                 wh::WarmupConfigBuilder().min_max_iter(2, 2).build(),
                                 wh::SamplingConfigBuilder().min_max_iter(2, 2).build());
     std::vector<Listening> ears(C);
     GlobalStore g4;
     wh::walnuts(seed, ears, g4, never, model, cfg);
-    EXPECT(ears[0].exceptions == 4);   // two warmup and two sampling transitions, each failing in its first leaf
-    EXPECT(ears[0].last.find("non-finite log density in 5 macro-step attempt") != std::string::npos);   // max_step_halvings
+    EXPECT(ears[0].failed == 4 && ears[0].where == 1e200);   // two warmup and two sampling transitions
     EXPECT(ears[0].draws.size() == 2 * D && ears[0].draws[0] == 1e200);
-    for (std::size_t c = 1; c < C; ++c) EXPECT(ears[c].exceptions == 0);
+    for (std::size_t c = 1; c < C; ++c) EXPECT(ears[c].failed == 0);
   }
 
   // ---- dump for the oracle comparison -----------------------------------------------------------------------

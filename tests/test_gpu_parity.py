@@ -467,24 +467,28 @@ def test_sampler_statistics_are_sane():
 
 
 @pytest.mark.parametrize("D,geometry", [(1024, None), (100, None), (1024, (2, 8)), (20000, None)])
-def test_model_failure_counter_on_gpu(D, geometry):
-    """wn_engine_get_nonfinite_evals (the device counterpart of on_logp_exception, util.hpp:336-346) in the register
-    kernels and the streaming kernels: chains that start where the log density overflows fail every attempt of their
-    first macro step -- max_step_halvings of them -- and stay put; the others report nothing."""
+def test_failed_extension_flag_on_gpu(D, geometry):
+    """wn_engine_get_failed_extensions (the failure channel of device models: the counterpart of on_logp_exception,
+    util.hpp:336-346) in the register kernels and the streaming kernels: chains that start where the log density
+    overflows fail their first leaf at every step size and stay put, flagged after every transition; the others (small
+    step: nothing fails) report nothing."""
     C = 67
     geo = {} if geometry is None else dict(waves_per_chain=geometry[0], elems_per_lane=geometry[1])
     e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, C, wa.default_config(**geo))
     pos = np.full((C, D), 0.03)
     pos[5] = pos[66] = 1e200
     e.set_positions(pos)
-    e.set_step_sizes(0.2)
+    e.set_step_sizes(0.02)
     e.seed_chains(1, 0)
-    want = [5 if c in (5, 66) else 0 for c in range(C)]
+    want = [1 if c in (5, 66) else 0 for c in range(C)]
     e.warmup_steps(3)
     e.synchronize()
-    assert e.nonfinite_evals().tolist() == want
+    # (warmup adapts the step: a healthy chain's extension may fail its energy or reversibility test now and then)
+    assert e.failed_extensions()[[5, 66]].tolist() == [1, 1]
+    e.set_step_sizes(0.02)    # back to the InitConfig's small step, frozen: nothing else fails
+    e.set_positions(pos)
     e.freeze()
-    e.sample_step()
+    e.sample_steps(2)
     e.synchronize()
-    assert e.nonfinite_evals().tolist() == want
+    assert e.failed_extensions().tolist() == want
     assert np.array_equal(e.positions()[5], pos[5]) and np.all(e.depths()[[5, 66]] == 1)

@@ -312,22 +312,23 @@ def test_emulated_fourth_model_added_through_the_model_interface(sim, oracle, D,
 
 
 @pytest.mark.timeout(600)
-def test_emulated_model_failure_counter(sim):
-    """wn_engine_get_nonfinite_evals, the device counterpart of the reference's on_logp_exception events
-    (util.hpp:336-346): a chain that starts where the model's log density overflows fails every attempt of its first
-    macro step (max_step_halvings of them), its extension fails and it stays put; the other chains report nothing."""
+def test_emulated_failed_extension_flag(sim):
+    """wn_engine_get_failed_extensions, the failure channel of device models (the counterpart of the reference's
+    on_logp_exception events, util.hpp:336-346): a chain that starts where the model's log density overflows fails its
+    first leaf at every step size, the extension fails and the chain stays put -- flagged after every transition; the
+    other chains (small step: nothing fails) report nothing."""
     C, D = 3, 10
     e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, C, wa.default_config(sim), lib_path=sim)
     pos = np.full((C, D), 0.3)
     pos[1] = 1e200
     e.set_positions(pos)
-    e.set_step_sizes(0.5)
+    e.set_step_sizes(0.05)
     e.seed_chains(1, 0)
     e.warmup_step()
     e.synchronize()
-    assert e.nonfinite_evals().tolist() == [0, 5, 0]
+    assert e.failed_extensions().tolist() == [0, 1, 0]
     assert np.array_equal(e.positions()[1], pos[1]) and np.all(e.positions()[0] != pos[0])
     e.freeze()
     e.sample_steps(2)
     e.synchronize()
-    assert e.nonfinite_evals().tolist() == [0, 5, 0]   # (of the launch's last transition)
+    assert e.failed_extensions().tolist() == [0, 1, 0]

@@ -100,7 +100,7 @@ SYMBOLS = [
     ("wn_engine_get_depths", _i32, [_vp, _i32p, _errpp]),
     ("wn_engine_get_grad_evals", _i32, [_vp, _i64p, _errpp]),
     ("wn_engine_get_rng_draws", _i32, [_vp, _i32p, _errpp]),
-    ("wn_engine_get_nonfinite_evals", _i32, [_vp, _i32p, _errpp]),
+    ("wn_engine_get_failed_extensions", _i32, [_vp, _i32p, _errpp]),
     ("wn_engine_get_adam", _i32, [_vp, _dp, _errpp]),
     ("wn_engine_get_estimator", _i32, [_vp, _dp, _dp, _dp, _dp, _dp, _errpp]),
     ("wn_engine_total_grad_evals", _i32, [_vp, _i64p, _errpp]),

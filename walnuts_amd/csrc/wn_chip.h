@@ -62,7 +62,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   using typename Base::Meta;
   using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::wave;
   using Base::chain; using Base::aux; using Base::n_grad; using Base::n_draw; using Base::draw_base; using Base::err;
-  using Base::n_bad;
   using Base::max_error; using Base::min_micro; using Base::step; using Base::free_mask; using Base::onchip_mask;
   using Base::w_draw0; using Base::w_score0; using Base::meta; using Base::carry; using Base::bcast;
   static constexpr int L = Base::L;
@@ -434,7 +433,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         turned = p_hot < 0 || p_far < 0;
         return rev;
       }
-      if (WN_UNLIKELY(!__builtin_isfinite(logp_joint))) ++n_bad;  // (TrajBase::n_bad: the failure path only)
     }
     return false;
   }
@@ -464,7 +462,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     err = 0;
     n_grad = 0;
     n_draw = 0;
-    n_bad = 0;
     draw_base = -1;
     max_error = P.max_error;
     free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
@@ -655,7 +652,12 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
           }
         }
       }
-      if (WN_UNLIKELY(!ok)) return false;  // walnuts.hpp:543-545
+      if (WN_UNLIKELY(!ok)) {  // walnuts.hpp:543-545
+#if !defined(WN_NO_FAILURE_COUNT)  // (probe switch: tests/gpu_probes A/B of what the flag costs)
+        err |= static_cast<int>(kNoteExtensionFailed);
+#endif
+        return false;
+      }
 
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
       WN_PHASE(kPhTopMerge);

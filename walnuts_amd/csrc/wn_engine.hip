@@ -54,7 +54,7 @@ struct wn_engine {
   DevBuf<double> theta, mass, inv_mass, chol_mass, draw_mean, draw_ssd, score_mean, score_ssd;
   DevBuf<double> step_init, step_size, adam, est_weight, mm_state, logp, model_params, arena, z_buf, u_buf;
   DevBuf<double> lp_stats, mon_partial, mon_out, mon_colsum, mon_rel_mass, mon_rel_step;
-  DevBuf<int32_t> min_micro, depth, rng_draws, nonfinite;
+  DevBuf<int32_t> min_micro, depth, rng_draws, failed_ext;
   DevBuf<int64_t> grad_evals;
   DevBuf<uint32_t> counter, error_flags;
   DevBuf<unsigned long long> scratch64;
@@ -183,7 +183,7 @@ struct wn_engine {
     P.depth_out = depth.p;
     P.grad_evals = grad_evals.p;
     P.rng_draws = rng_draws.p;
-    P.nonfinite = nonfinite.p;
+    P.failed_ext = failed_ext.p;
     P.lp_stats = lp_stats.p;
     P.draws_out = draws_dev;
     P.draws_stride = draws_stride;
@@ -377,7 +377,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.min_micro.alloc(num_chains);
   e.depth.alloc(num_chains);
   e.rng_draws.alloc(num_chains);
-  e.nonfinite.alloc(num_chains);
+  e.failed_ext.alloc(num_chains);
   e.grad_evals.alloc(num_chains);
   e.counter.alloc(1);
   HIP_OK(hipMemsetAsync(e.counter.p, 0, sizeof(uint32_t), e.stream));
@@ -405,7 +405,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   HIP_OK(hipMemsetAsync(e.grad_evals.p, 0, num_chains * sizeof(int64_t), e.stream));
   HIP_OK(hipMemsetAsync(e.depth.p, 0, num_chains * sizeof(int32_t), e.stream));
   HIP_OK(hipMemsetAsync(e.rng_draws.p, 0, num_chains * sizeof(int32_t), e.stream));
-  HIP_OK(hipMemsetAsync(e.nonfinite.p, 0, num_chains * sizeof(int32_t), e.stream));
+  HIP_OK(hipMemsetAsync(e.failed_ext.p, 0, num_chains * sizeof(int32_t), e.stream));
   HIP_OK(hipMemsetAsync(e.logp.p, 0, num_chains * sizeof(double), e.stream));
   HIP_OK(hipMemsetAsync(e.lp_stats.p, 0, 3 * num_chains * sizeof(double), e.stream));
   {
@@ -741,10 +741,10 @@ int wn_engine_get_grad_evals(wn_engine* e, int64_t* out, WalnutpyError** err) {
   return guarded(err, [&] {
     if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument"); e->download(e->grad_evals, out, e->C); });
 }
-int wn_engine_get_nonfinite_evals(wn_engine* e, int32_t* out, WalnutpyError** err) {
+int wn_engine_get_failed_extensions(wn_engine* e, int32_t* out, WalnutpyError** err) {
   return guarded(err, [&] {
     if (e == nullptr || out == nullptr) throw std::invalid_argument("null argument");
-    e->download(e->nonfinite, out, e->C);
+    e->download(e->failed_ext, out, e->C);
   });
 }
 int wn_engine_get_rng_draws(wn_engine* e, int32_t* out, WalnutpyError** err) {

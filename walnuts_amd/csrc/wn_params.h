@@ -45,7 +45,7 @@ struct Params {
   int32_t* depth_out;  // [C]
   int64_t* grad_evals; // [C] running totals
   int32_t* rng_draws;  // [C] scalar draws of the last transition
-  int32_t* nonfinite;  // [C] macro-step attempts of the last transition that ended with a non-finite log density
+  int32_t* failed_ext; // [C] 1: an extension of the chain's last transition failed (kNoteExtensionFailed)
   double* lp_stats;    // [C][3] WelfordAccumulator (count, mean, M2) of the sampling log densities
   // output of this transition
   double* draws_out;   // nullable; chain c's row of the launch's k-th transition at draws_out + c*draws_stride + k*draws_tstride
@@ -85,8 +85,12 @@ struct Params {
 };
 
 enum : uint32_t {
-  kErrPoolExhausted = 1u,    // a chain needed more span-pool vectors than the engine holds
-  kErrVariatesExhausted = 2u // host-fed uniforms (wn_engine_set_variates) ran out inside a transition
+  kErrPoolExhausted = 1u,     // a chain needed more span-pool vectors than the engine holds
+  kErrVariatesExhausted = 2u, // host-fed uniforms (wn_engine_set_variates) ran out inside a transition
+  // not an error, a note kept beside the error bits (one register) until the transition's scalars are stored: an
+  // extension of this transition FAILED -- a leaf's energy error exceeded the bound at every step size, or its
+  // reversibility check failed (walnuts.hpp:344,:271-274,:543-545)
+  kNoteExtensionFailed = 256u
 };
 
 }  // namespace wn

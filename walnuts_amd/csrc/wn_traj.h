@@ -179,14 +179,13 @@ struct TrajBase {
   bool carry_armed;
   long long n_grad;
   int n_draw;
-  // The device counterpart of NoExceptLogpGrad -> handler.on_logp_exception (util.hpp:336-346, concepts.hpp:196-201): a
-  // device model cannot throw; what a failing model produces instead is a non-finite log density, which makes the
-  // energy test of its macro-step attempt fail.  Those attempts are counted per chain and transition -- on the failure
-  // path of the test only, nothing on the path of an accepted leaf -- and reported through wn_engine_get_nonfinite_evals.
-  int n_bad;
   int draw_base;  // first tree-draw index held in draw_u / draw_lu (-1: none)
   double draw_u, draw_lu;
   int err;
+  // (`err` also carries kNoteExtensionFailed: the failure channel of device models, wn_params.h -- set where an
+  // extension fails, in blocks that are cold already.  Anything finer -- a count of non-finite attempts kept in a
+  // register, in LDS or in memory, a test inside or after the halving loop -- cost the headline kernel 2-8 %,
+  // profiles/r04/headline_attempts.md.)
   double step, max_error;
   double w_draw0, w_score0;  // estimator weights at entry (read once: another wave's lane 0 rewrites them at exit)
   int min_micro;
@@ -366,7 +365,7 @@ struct TrajBase {
   // ---- span pool: wave-uniform buffer indices over a 64-bit free mask ---------------------
   __device__ __forceinline__ int alloc() {
     if (WN_UNLIKELY(free_mask == 0ull)) {
-      err = 1;
+      err |= 1;
       return 0;
     }
     const int b = uni(__builtin_ctzll(free_mask));
@@ -377,7 +376,7 @@ struct TrajBase {
   // indices stay available for the short-lived span-stack entries
   __device__ __forceinline__ int alloc_cold() {
     if (WN_UNLIKELY(free_mask == 0ull)) {
-      err = 1;
+      err |= 1;
       return 0;
     }
     // the highest free on-chip buffer (LDS / register pool); with none left, the lowest of the HBM arena
@@ -602,6 +601,8 @@ struct TrajBase {
       }
       // host-fed uniforms: a transition that consumed more than were supplied used the filler value
       if (WN_UNLIKELY(Q.rng_mode == kRngBuffer && n_draw > Q.u_stride)) err |= static_cast<int>(kErrVariatesExhausted);
+      Q.failed_ext[chain] = (err >> 8) & 1;  // (kNoteExtensionFailed)
+      err &= 0xff;
       // the per-transition report (depth -1) is overwritten by the next transition; the engine-wide word is not
       if (WN_UNLIKELY(err != 0)) atomicOr(Q.error_flags, static_cast<uint32_t>(err));
       Q.logp_out[chain] = lpsel;
@@ -612,7 +613,6 @@ struct TrajBase {
         Q.grad_evals[chain] += n_grad;
       }
       Q.rng_draws[chain] = n_draw;
-      Q.nonfinite[chain] = n_bad;
     }
   }
 
@@ -639,7 +639,6 @@ struct TrajBase {
         if (rev) self().macro_commit();
         return rev;
       }
-      if (!__builtin_isfinite(logp_joint)) ++n_bad;  // (see n_bad)
       WN_PHASE(kPhRestart);
     }
     return false;
@@ -660,7 +659,6 @@ struct TrajBase {
     err = 0;
     n_grad = 0;
     n_draw = 0;
-    n_bad = 0;
     draw_base = -1;
     max_error = P.max_error;
     free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
@@ -827,7 +825,10 @@ struct TrajBase {
           ++sp;
         }
       }
-      if (!ok) break;  // walnuts.hpp:543-545
+      if (!ok) {  // walnuts.hpp:543-545
+        err |= static_cast<int>(kNoteExtensionFailed);
+        break;
+      }
 
       WN_PHASE(kPhTopMerge);
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----

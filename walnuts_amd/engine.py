@@ -171,10 +171,11 @@ class DeviceEngine:
     def grad_evals(self):
         return self._get(self.lib.wn_engine_get_grad_evals, (self.C,), np.int64, _ffi._i64p)
 
-    def nonfinite_evals(self):
-        """Per chain: macro-step attempts of the last transition that met a non-finite log density (the device
-        counterpart of the reference's on_logp_exception events, util.hpp:336-346)."""
-        return self._get(self.lib.wn_engine_get_nonfinite_evals, (self.C,), np.int32, _ffi._i32p)
+    def failed_extensions(self):
+        """Per chain: 1 if an extension of the last transition failed (a leaf's energy error above the bound at every
+        step size -- where a model returning non-finite values ends up; the device counterpart of the reference's
+        on_logp_exception events, util.hpp:336-346 -- or a failed reversibility check)."""
+        return self._get(self.lib.wn_engine_get_failed_extensions, (self.C,), np.int32, _ffi._i32p)
 
     def rng_draws(self):
         return self._get(self.lib.wn_engine_get_rng_draws, (self.C,), np.int32, _ffi._i32p)

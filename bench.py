@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--transitions-per-launch", type=int, default=DEFAULT_TRANSITIONS_PER_LAUNCH,
                     help="transitions of every chain per kernel launch (wn_engine_sample_steps): the workgroup that "
                          "fetched a chain runs them back to back; a step stays ONE transition of all chains")
+    ap.add_argument("--chain-groups", type=int, default=0,
+                    help="wn_config::chain_groups: 0 = the engine's choice (2 when there are more chains than resident "
+                         "workgroups), 1-4 = that many independently launched chain groups")
     ap.add_argument("--gather-method", choices=["collective", "p2p"], default="collective",
                     help="collective: all_gather_into_tensor (RCCL picks the algorithm); p2p: all-pairs, every block "
                          "as its own point-to-point transfer (grouped send/recv: one xGMI link per pair)")
@@ -456,7 +459,8 @@ def main():
     # few CUs stay free so that RCCL's all-gather of the previous draws really runs underneath it
     reserved = args.reserved_cus if args.reserved_cus >= 0 else (16 if world > 1 else 0)
     cfg_kwargs = dict(device=local_rank, waves_per_chain=args.waves_per_chain, elems_per_lane=args.elems_per_lane,
-                      workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors)
+                      workgroups_per_cu=args.workgroups_per_cu, lds_vectors=args.lds_vectors,
+                      chain_groups=args.chain_groups)
     if args.fma >= 0:
         cfg_kwargs["fused_multiply_add"] = args.fma
     cfg = wa.default_config(reserved_cus=reserved, **cfg_kwargs)
@@ -527,8 +531,15 @@ def main():
     elapsed = time.perf_counter() - t0
     g_after = eng.total_grad_evals()
     ktimes = eng.kernel_times_ms() if per_launch else [region_total_ms / max(region_launches, 1)]
+    groups = eng.chain_groups
     timing_method = ("one pair of HIP events per launch" if per_launch else
                      f"one pair of HIP events around the {region_launches} launches of the timed region (gaps included)")
+    if groups > 1:
+        # a launch is `groups` kernels running side by side on their own streams, one contiguous block of chains each
+        # (wn_config::chain_groups): bytes and flops per launch count all of them, the duration is the launch's share
+        # of the region -- which is also what each of the overlapping kernels lasts in a kernel trace
+        timing_method += (f"; a launch = {groups} concurrent kernels (chain groups), each lasting about the whole launch"
+                          if not per_launch else f"; around group 0's kernel of the launch's {groups} concurrent ones")
 
     grad_evals = g_after - g_before
     legs = None
@@ -616,7 +627,7 @@ def main():
                                                        f"{args.gather_every} launch(es), one collective per block of {T} draw planes" if world > 1 else ""),
                 "geometry": {"lanes_per_chain": eng.lanes, "dim_padded": eng.dim_padded,
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
-                             "reserved_cus": reserved},
+                             "reserved_cus": reserved, "chain_groups": groups},
                 "grad_evals_per_transition_per_chain": grad_evals / max(args.steps, 1) / C,
                 "transitions_per_launch": T, "launches": launches,
                 "arithmetic": ("fused multiply-adds in the integrator (as an FMA-target build of the reference)"

@@ -174,6 +174,14 @@ typedef struct wn_config {
                                        rounded before it is added -- the element-wise bits of the reference built
                                        as its CMake files build it on x86-64 (-O3, SSE2).  Both meet the <= 1e-10
                                        bar against the reference order; the fused kernels are ~10 % faster. */
+  int32_t chain_groups;             /* 0 (default): chosen by the engine -- 2 when there are more chains than resident
+                                       workgroups, else 1; up to 4; WALNUTS_AMD_CHAIN_GROUPS in the environment
+                                       overrides.  With g > 1 the chains are launched as g independent contiguous
+                                       blocks on g streams, each filling the others' launch tails (2 groups: +13 % /
+                                       +26 % on BASELINE configs #2 / #3, +2 % on the headline; 3 and 4 measured no
+                                       better -- profiles/r04/ab_chain_groups.txt); results do not depend on it.
+                                       An engine fed host variates (reference_streams) keeps its groups in lock step;
+                                       one moved to a caller's stream (wn_engine_set_stream) runs as one group. */
 } wn_config;
 
 WALNUTS_HIP_EXPORT void wn_default_config(wn_config* cfg);
@@ -297,6 +305,7 @@ WALNUTS_HIP_EXPORT int wn_engine_lanes(const wn_engine* e);        /* L = 64*NW:
 WALNUTS_HIP_EXPORT int wn_engine_dim_padded(const wn_engine* e);   /* Dp                                */
 WALNUTS_HIP_EXPORT int wn_engine_is_streaming(const wn_engine* e); /* 1: vectors streamed from HBM      */
 WALNUTS_HIP_EXPORT int wn_engine_workgroups(const wn_engine* e);   /* persistent grid size              */
+WALNUTS_HIP_EXPORT int wn_engine_chain_groups(const wn_engine* e); /* concurrent kernels per transition launch */
 WALNUTS_HIP_EXPORT int wn_engine_lds_vectors(const wn_engine* e);  /* pool vectors resident in LDS      */
 WALNUTS_HIP_EXPORT int64_t wn_engine_iteration(const wn_engine* e);
 WALNUTS_HIP_EXPORT void* wn_engine_stream(const wn_engine* e);     /* hipStream_t the kernels run on    */

@@ -8,6 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export WALNUTS_AMD_CHAIN_GROUPS=1   # (one dispatch per launch: the per-launch counter values below are one kernel's)
 # (steps and warmup are multiples of the transitions per launch: every profiled dispatch is a full launch)
 ARGS="--no-cpu-baseline --no-parity-gate --steps 16 --warmup 8 --adapt-iters 100 $*"
 i=0

@@ -173,6 +173,7 @@ inline double wave_sum_packed(double a, double b) {  // a's total in lanes 0-31,
   const double sa = wave_sum(a), sb = wave_sum(b);
   return (wnsim::tidx.x & 63u) < 32u ? sa : sb;
 }
+inline int opaque_scalar_add(int a, int b) { return a + b; }
 inline int opaque_lane_id() { return static_cast<int>(wnsim::tidx.x & 63u); }
 inline int wave_in_workgroup() { return static_cast<int>(wnsim::tidx.x >> 6); }
 template <class T>

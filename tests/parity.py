@@ -34,7 +34,8 @@ def make_pair(model: str, D: int, C: int, lib_path=None, geometry=None, **cfg_ov
     geo = {}
     if geometry is not None:
         geo = dict(waves_per_chain=geometry[0], elems_per_lane=geometry[1])
-    extra = {k: cfg_over.pop(k) for k in ("workgroups_per_cu", "lds_vectors", "fused_multiply_add") if k in cfg_over}
+    extra = {k: cfg_over.pop(k) for k in ("workgroups_per_cu", "lds_vectors", "fused_multiply_add", "chain_groups")
+             if k in cfg_over}
     dcfg = wa.default_config(lib_path, **cfg_over, **geo, **extra)
     params = model_params(model, D)
     dev = wa.DeviceEngine(dm, D, C, dcfg, params=params, lib_path=lib_path)

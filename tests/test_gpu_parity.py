@@ -98,6 +98,20 @@ def test_fused_launches_match_oracle_bitwise(model, D, C, geometry, fused):
     parity.run_case(model, D, C, warmup=2 * fused + 1, sampling=2 * fused + 1, geometry=geometry, fused=fused)
 
 
+@pytest.mark.parametrize("model,D,C,geometry,fused", [
+    ("std_normal", 1024, 301, (1, 16), 4),     # uneven halves on the headline kernel
+    ("funnel", 128, 500, None, 8),             # config #3's kernel (the engine's own choice at this size is two groups)
+    ("rw1", 1024, 48, None, 1),                # four wavefronts per chain, single steps
+    ("diag_normal", 16384, 12, None, 3),       # streaming backend: one arena slice per group
+])
+def test_chain_groups_match_oracle_bitwise(model, D, C, geometry, fused):
+    """wn_config::chain_groups = 2: the chains as two independently launched halves on two streams -- own chain
+    counters, arena slices, no ordering between one half's launch n + 1 and the other's launch n -- against the oracle
+    (which knows nothing of groups) after every launch, through warmup, freeze and sampling."""
+    parity.run_case(model, D, C, warmup=2 * fused + 1, sampling=2 * fused + 1, geometry=geometry, fused=fused,
+                    chain_groups=2)
+
+
 def test_fused_launches_full_size_headline():
     """65 536 x 1 024: one launch of 8 transitions leaves the positions, statistics and EVERY draw plane that 8
     launches of one transition leave."""

@@ -311,6 +311,20 @@ def test_emulated_fourth_model_added_through_the_model_interface(sim, oracle, D,
     parity.run_case("rw1", D, 2, warmup=3, sampling=3, lib_path=sim, geometry=geometry)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("model,D,C,geometry", [
+    ("std_normal", 10, 5, None),           # uneven halves (2 + 3 chains)
+    ("funnel", 9, 4, (2, 2)),              # two wavefronts per chain
+    ("diag_normal", 300, 3, (1, -1)),      # streaming backend: every group has its own arena slice
+])
+def test_emulated_chain_groups(sim, oracle, model, D, C, geometry):
+    """wn_config::chain_groups = 2: the chains launched as two halves, each with its own chain counter, arena slice and
+    stream -- the same bits as one group (the oracle knows nothing of groups); single steps and fused launches, warmup,
+    freeze, sampling, and the host-side operations in between (every one of them first waits for both groups)."""
+    parity.run_case(model, D, C, warmup=3, sampling=3, lib_path=sim, geometry=geometry, chain_groups=2)
+    parity.run_case(model, D, C, warmup=4, sampling=4, lib_path=sim, geometry=geometry, chain_groups=2, fused=2)
+
+
 @pytest.mark.timeout(600)
 def test_emulated_failed_extension_flag(sim):
     """wn_engine_get_failed_extensions, the failure channel of device models (the counterpart of the reference's

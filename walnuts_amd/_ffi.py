@@ -39,6 +39,7 @@ class Config(C.Structure):
         ("lds_vectors", C.c_int32),
         ("reserved_cus", C.c_int32),
         ("fused_multiply_add", C.c_int32),
+        ("chain_groups", C.c_int32),
     ]
 
 
@@ -114,6 +115,7 @@ SYMBOLS = [
     ("wn_engine_dim_padded", _i32, [_vp]),
     ("wn_engine_is_streaming", _i32, [_vp]),
     ("wn_engine_workgroups", _i32, [_vp]),
+    ("wn_engine_chain_groups", _i32, [_vp]),
     ("wn_engine_lds_vectors", _i32, [_vp]),
     ("wn_engine_iteration", _i64, [_vp]),
     ("wn_engine_stream", _vp, [_vp]),

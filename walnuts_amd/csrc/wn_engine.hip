@@ -78,8 +78,25 @@ struct wn_engine {
   bool timing = false;     // record events around the launches (wn_engine_timing_reset switches it on)
   hipEvent_t region_begin = nullptr, region_end = nullptr;  // wn_engine_region_begin / _region_ms
   size_t region_launches = 0;
-  uint32_t work_base = 0;  // value of the device-side chain counter at the next launch
   bool own_stream = true;
+  // Chain groups (round 4): with few work items per resident workgroup (config #2: 4, config #3: 5) a launch's tail --
+  // the last chains finishing while the chip drains -- is 25-45 % of it (profiles/r03/item_balance.txt).  The chains are
+  // then split into `groups` contiguous blocks, each with its own stream, chain counter and arena slice, launched
+  // independently: nothing orders group 1's launch n + 1 behind group 0's launch n, so one group's tail is filled by the
+  // other's workgroups (two engines on two streams measured +12 % / +23 % on configs #2 / #3 and +2 % on the headline,
+  // profiles/r03/two_groups.txt; in the engine: +13 % / +26 % / +2 %, profiles/r04/ab_chain_groups.txt -- as long as
+  // nothing re-aligns the groups: a join of the streams at every step gives the lock-step numbers back).  Everything
+  // else the engine does runs on `stream` and first waits for the groups (join_groups(), reached through use_device()).
+  static constexpr int kMaxGroups = 4;
+  int groups = 1;
+  size_t group_begin[kMaxGroups + 1] = {};
+  int group_grid[kMaxGroups] = {};
+  hipStream_t gstream[kMaxGroups] = {};  // [0] is `stream`
+  hipEvent_t gdone[kMaxGroups] = {}, main_point = nullptr;
+  uint32_t work_base[kMaxGroups] = {};  // value of each group's device-side chain counter at its next launch
+  bool groups_ahead = false;  // a group stream holds launches `stream` has not waited for
+  bool main_moved = true;     // `stream` has done something since the groups last waited for it
+  bool in_step = false;
 
   ~wn_engine() {
     for (auto& ev : events) {
@@ -88,7 +105,17 @@ struct wn_engine {
     }
     if (region_begin) (void)hipEventDestroy(region_begin);
     if (region_end) (void)hipEventDestroy(region_end);
+    for (int g = 1; g < kMaxGroups; ++g) {
+      if (gstream[g]) (void)hipStreamDestroy(gstream[g]);
+      if (gdone[g]) (void)hipEventDestroy(gdone[g]);
+    }
+    if (main_point) (void)hipEventDestroy(main_point);
     if (stream && own_stream) (void)hipStreamDestroy(stream);
+  }
+  // `stream` waits for what the group streams hold
+  void join_groups() {
+    for (int g = 1; g < groups; ++g) HIP_OK(hipStreamWaitEvent(stream, gdone[g], 0));
+    groups_ahead = false;
   }
 
   std::pair<hipEvent_t, hipEvent_t>& next_events() {
@@ -102,7 +129,13 @@ struct wn_engine {
     return events[slot];
   }
 
-  void use_device() { HIP_OK(hipSetDevice(device)); }
+  void use_device() {
+    HIP_OK(hipSetDevice(device));
+    if (groups > 1 && !in_step) {  // anything but a transition launch: ordered after every group, and the groups after it
+      if (groups_ahead) join_groups();
+      main_moved = true;
+    }
+  }
 
   void upload_rows(DevBuf<double>& dst, const double* host, double pad_value) {
     // host [C][D] -> device [C][Dp]; padding columns keep their fill value
@@ -230,31 +263,56 @@ struct wn_engine {
     if (fused < 1) throw std::invalid_argument("transitions per launch must be at least 1");
     if (fused > 1 && (ref_streams || variates_pending))
       throw std::invalid_argument("host-fed variates cover one transition: transitions per launch must be 1");
+    in_step = !ref_streams;  // (a transition launch does not make `stream` wait for the groups -- unless variates are
+                             // fed from the host first, which writes buffers the groups' previous launches read)
+    struct Leave {
+      bool& flag;
+      ~Leave() { flag = false; }
+    } leave{in_step};
     use_device();
     if (ref_streams) feed_reference_streams();
+    in_step = true;
     wn::Params P = make_params(warm, draws_dev, draws_stride, fused, draws_tstride);
-    // The chain counter is never reset: every launch performs exactly C fetches (one per processed chain), so launch n
-    // starts at n * C (mod 2^32) -- one memset per transition less between two kernels.
-    P.work_base = work_base;
-    try {
-      if (timing) {  // HIP events around the launch: only between wn_engine_timing_reset and the read-back
-        auto& ev = next_events();
-        HIP_OK(hipEventRecord(ev.first, stream));
-        wn::launch_transition(model, geo, grid, smem, stream, P);
-        HIP_OK(hipGetLastError());
-        HIP_OK(hipEventRecord(ev.second, stream));
-      } else {
-        wn::launch_transition(model, geo, grid, smem, stream, P);
-        HIP_OK(hipGetLastError());
-      }
-    } catch (...) {
-      // a launch that did not happen fetched nothing: counter and base start over together (a kernel that did start
-      // and then failed leaves the device in an error state anyway; the memset then fails too and is ignored)
-      (void)hipMemsetAsync(counter.p, 0, sizeof(uint32_t), stream);
-      work_base = 0;
-      throw;
+    if (groups > 1 && main_moved) {  // the group streams catch up with what `stream` did since their last launches
+      HIP_OK(hipEventRecord(main_point, stream));
+      for (int g = 1; g < groups; ++g) HIP_OK(hipStreamWaitEvent(gstream[g], main_point, 0));
+      main_moved = false;
     }
-    work_base += static_cast<uint32_t>(C);  // (only once the launch is known to be queued)
+    for (int g = 0; g < groups; ++g) {
+      // The chain counter is never reset: every launch performs exactly as many fetches as it has chains (one per
+      // processed chain), so a group's launch n starts at n * its chain count (mod 2^32) -- one memset per transition
+      // less between two kernels.  (The first chain of the group is folded into the base: fetched = begin + ...)
+      const uint32_t count = static_cast<uint32_t>(group_begin[g + 1] - group_begin[g]);
+      P.chain_begin = static_cast<int32_t>(group_begin[g]);
+      P.num_chains = static_cast<int32_t>(group_begin[g + 1]);
+      P.work_counter = counter.p + g;
+      P.work_base = work_base[g] - static_cast<uint32_t>(group_begin[g]);
+      P.arena = arena.p + static_cast<size_t>(g) * static_cast<size_t>(grid) * static_cast<size_t>(arena_stride);
+      hipStream_t s = g == 0 ? stream : gstream[g];
+      try {
+        if (timing && g == 0) {  // HIP events around the launch: only between wn_engine_timing_reset and the read-back
+          auto& ev = next_events();
+          HIP_OK(hipEventRecord(ev.first, s));
+          wn::launch_transition(model, geo, group_grid[g], smem, s, P);
+          HIP_OK(hipGetLastError());
+          HIP_OK(hipEventRecord(ev.second, s));
+        } else {
+          wn::launch_transition(model, geo, group_grid[g], smem, s, P);
+          HIP_OK(hipGetLastError());
+        }
+      } catch (...) {
+        // a launch that did not happen fetched nothing: counter and base start over together (a kernel that did start
+        // and then failed leaves the device in an error state anyway; the memset then fails too and is ignored)
+        (void)hipMemsetAsync(counter.p + g, 0, sizeof(uint32_t), s);
+        work_base[g] = 0;
+        throw;
+      }
+      work_base[g] += count;  // (only once the launch is known to be queued)
+      if (g > 0) {
+        HIP_OK(hipEventRecord(gdone[g], s));
+        groups_ahead = true;
+      }
+    }
     ++region_launches;
     variates_pending = false;
     transition += static_cast<uint32_t>(fused);
@@ -379,8 +437,27 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.rng_draws.alloc(num_chains);
   e.failed_ext.alloc(num_chains);
   e.grad_evals.alloc(num_chains);
-  e.counter.alloc(1);
-  HIP_OK(hipMemsetAsync(e.counter.p, 0, sizeof(uint32_t), e.stream));
+  // chain groups: as configured, or two when there are more chains than resident workgroups (with at most one chain
+  // per workgroup there is no tail to fill: 1024 and 256 chains measured the same with 1-4 groups); host-fed variates
+  // and an adopted stream (wn_engine_set_stream) go back to one
+  {
+    int want = cfg.chain_groups;
+    if (const char* v = std::getenv("WALNUTS_AMD_CHAIN_GROUPS")) want = std::atoi(v);
+    if (want <= 0) want = num_chains > static_cast<size_t>(e.grid) ? 2 : 1;
+    e.groups = std::max(1, std::min({want, wn_engine::kMaxGroups, static_cast<int>(num_chains)}));
+  }
+  for (int g = 0; g <= e.groups; ++g) e.group_begin[g] = num_chains * static_cast<size_t>(g) / static_cast<size_t>(e.groups);
+  e.gstream[0] = e.stream;
+  for (int g = 0; g < e.groups; ++g) {
+    e.group_grid[g] = static_cast<int>(std::min<size_t>(e.group_begin[g + 1] - e.group_begin[g], static_cast<size_t>(e.grid)));
+    if (g > 0) {
+      HIP_OK(hipStreamCreateWithFlags(&e.gstream[g], hipStreamNonBlocking));
+      HIP_OK(hipEventCreateWithFlags(&e.gdone[g], hipEventDisableTiming));
+    }
+  }
+  if (e.groups > 1) HIP_OK(hipEventCreateWithFlags(&e.main_point, hipEventDisableTiming));
+  e.counter.alloc(wn_engine::kMaxGroups);
+  HIP_OK(hipMemsetAsync(e.counter.p, 0, wn_engine::kMaxGroups * sizeof(uint32_t), e.stream));
   e.error_flags.alloc(1);
   HIP_OK(hipMemsetAsync(e.error_flags.p, 0, sizeof(uint32_t), e.stream));
   e.lp_stats.alloc(3 * num_chains);
@@ -394,7 +471,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   const size_t arena_vecs = static_cast<size_t>(std::max(0, e.pool_total - e.pool_lds)) +
                             (e.geo.mem ? wn::kMemScratchVectors : 0);
   e.arena_stride = static_cast<int64_t>(arena_vecs) * e.Dp;
-  e.arena.alloc(std::max<size_t>(1, static_cast<size_t>(e.grid) * arena_vecs * e.Dp));
+  e.arena.alloc(std::max<size_t>(1, static_cast<size_t>(e.groups) * static_cast<size_t>(e.grid) * arena_vecs * e.Dp));
   e.model_params.alloc(e.Dp);
 
   // InitConfigBuilder defaults (config.hpp:197-207): step 0.1, positions 0, masses 1
@@ -495,6 +572,7 @@ void wn_default_config(wn_config* c) {
   c->lds_vectors = -1;
   c->fused_multiply_add = default_fma();
   c->reserved_cus = 0;
+  c->chain_groups = 0;
 }
 
 int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params, size_t num_chains,
@@ -881,6 +959,7 @@ int wn_engine_lanes(const wn_engine* e) { return 64 * e->geo.nw; }
 int wn_engine_is_streaming(const wn_engine* e) { return e->geo.mem ? 1 : 0; }
 int wn_engine_dim_padded(const wn_engine* e) { return e->Dp; }
 int wn_engine_workgroups(const wn_engine* e) { return e->grid; }
+int wn_engine_chain_groups(const wn_engine* e) { return e->groups; }
 int wn_engine_lds_vectors(const wn_engine* e) { return e->pool_lds; }
 int64_t wn_engine_iteration(const wn_engine* e) { return e->iteration; }
 void* wn_engine_stream(const wn_engine* e) { return reinterpret_cast<void*>(e->stream); }
@@ -943,6 +1022,12 @@ int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {
     if (e->own_stream && e->stream) HIP_OK(hipStreamDestroy(e->stream));
     e->stream = reinterpret_cast<hipStream_t>(stream);
     e->own_stream = false;
+    // the caller orders its own work (collectives on the draws) behind the launches on THIS stream: one chain group
+    e->groups = 1;
+    e->gstream[0] = e->stream;
+    e->group_begin[1] = e->C;
+    e->group_grid[0] = static_cast<int>(std::min<size_t>(e->C, static_cast<size_t>(e->grid)));
+    e->groups_ahead = false;
   });
 }
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {

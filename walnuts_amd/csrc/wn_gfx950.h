@@ -127,6 +127,14 @@ __device__ __forceinline__ int opaque_lane_id() {
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
   return l;
 }
+// a + b on the scalar unit, opaque to the optimiser: the sum is formed where it is written instead of being folded
+// into (and re-ordering) the address arithmetic that follows.  Used once, for the workgroup's first chain index --
+// the plain `begin + blockIdx.x` cost the headline kernel 2 % through a different register allocation
+// (profiles/r04/ab_first_chain.txt).
+__device__ __forceinline__ int opaque_scalar_add(int a, int b) {
+  asm volatile("s_add_u32 %0, %0, %1" : "+s"(a) : "s"(b) : "scc");
+  return a;
+}
 // the wavefront's index within its workgroup, read once at the kernel entry (wave-uniform: a scalar register)
 __device__ __forceinline__ int wave_in_workgroup() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
 

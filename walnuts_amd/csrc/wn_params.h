@@ -23,7 +23,8 @@ enum RngMode : int32_t { kRngPhilox = 0, kRngBuffer = 1 };
 // the 16-byte pairs (k*L + l), k = 0..EPL/2-1 (L = 64*NW lanes per chain).
 struct Params {
   // geometry
-  int32_t num_chains;
+  int32_t num_chains;  // one past the last chain of this launch (a launch covers [chain_begin, num_chains): the whole engine,
+                       // or one of its chain groups)
   int32_t dim;        // D
   int32_t dim_padded; // Dp
   int32_t warmup;     // 1: AdaptiveWalnuts transition, 0: WalnutsSampler transition
@@ -81,6 +82,8 @@ struct Params {
   uint32_t work_base;      // its value when this launch starts
   uint32_t im_in_lds;      // streaming kernels: bit 0 = the chain's inverse mass is parked in LDS for the whole
                            // transition; bit 1 = (experiment switch) no far-end sums in the leaf's pass
+  int32_t chain_begin;    // first chain of this launch
+  int32_t pad3;
   uint32_t* error_flags;  // OR of kErr* bits of every chain and transition since wn_engine_check last read (and cleared) it
 };
 

@@ -1534,7 +1534,8 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
   // The workgroup's first chain is its own index; the following ones come from the shared counter, and the fetch
   // for chain n+1 is issued while chain n is being processed, so that its round trip (a device-scope atomic, 1-2 us
   // under load) overlaps the tree instead of standing between two transitions.
-  int c = static_cast<int>(blockIdx.x);
+  // (P.chain_begin: the launch covers one chain group, chains [chain_begin, num_chains))
+  int c = opaque_scalar_add(static_cast<int>(blockIdx.x), kernel_argument(P).chain_begin);
   int slot = 0;
   // (unsigned: a chain index that went negative -- counter and base out of step -- ends the loop instead of indexing
   // rows in front of the planes)

@@ -279,6 +279,11 @@ class DeviceEngine:
         return self.lib.wn_engine_workgroups(self.h)
 
     @property
+    def chain_groups(self) -> int:
+        """Kernels one transition launch consists of (wn_config::chain_groups): contiguous chain blocks, one stream each."""
+        return self.lib.wn_engine_chain_groups(self.h)
+
+    @property
     def lds_vectors(self) -> int:
         return self.lib.wn_engine_lds_vectors(self.h)
 

@@ -91,6 +91,11 @@ def parse():
     ap.add_argument("--chain-groups", type=int, default=0,
                     help="wn_config::chain_groups: 0 = the engine's choice (2 when there are more chains than resident "
                          "workgroups), 1-4 = that many independently launched chain groups")
+    ap.add_argument("--adopt-stream", action="store_true",
+                    help="N > 1: launch the kernels on torch's current stream (wn_engine_set_stream, one chain group) "
+                         "instead of ordering the engine's own streams against it with events")
+    ap.add_argument("--order-streams", action="store_true",
+                    help="exercise the N > 1 stream ordering (wn_engine_wait_stream / _release_stream) on one GPU too")
     ap.add_argument("--gather-method", choices=["collective", "p2p"], default="collective",
                     help="collective: all_gather_into_tensor (RCCL picks the algorithm); p2p: all-pairs, every block "
                          "as its own point-to-point transfer (grouped send/recv: one xGMI link per pair)")
@@ -465,9 +470,18 @@ def main():
         cfg_kwargs["fused_multiply_add"] = args.fma
     cfg = wa.default_config(reserved_cus=reserved, **cfg_kwargs)
     eng = wa.DeviceEngine(model_id, D, C, cfg, params=params)
-    if world > 1:
-        # kernels on torch's current stream: RCCL collectives on the draws are then ordered after them by torch
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # With more than one GPU the draws are gathered by collectives torch issues behind its current stream.  The engine
+    # keeps its own streams (and its chain groups) and is ordered against that stream with events in both directions:
+    # a launch waits for the collective that last read the buffer it overwrites, the collective waits for the launch.
+    # (--adopt-stream: the kernels on torch's stream itself, one chain group -- the round-3 arrangement.)
+    # The two directions use two streams: the collectives are issued behind torch's current stream (`torch_stream`),
+    # their completion is waited for on `inbound` -- were it the same stream, a launch would also wait for the previous
+    # launch of EVERY group (which that stream was told to wait for), and the groups would run in lock step again.
+    torch_stream = torch.cuda.current_stream().cuda_stream if (world > 1 or args.order_streams) else None
+    inbound = torch.cuda.Stream() if torch_stream is not None else None
+    if torch_stream is not None and args.adopt_stream:
+        eng.set_stream(torch_stream)
+        torch_stream = inbound = None
     # InitConfigBuilder on the device: positions ~ N(0, 2^2) (init_radius, pyfunc.py:57), masses from the
     # gradient with smoothing 1e-5, step-size search from step_size_init = 1.0.  Streams are keyed by the GLOBAL
     # chain id, so the result does not depend on the sharding.
@@ -490,10 +504,18 @@ def main():
         while i < first + count:
             n = min(T, first + count - i)
             launch_id = i // T
-            block = gather.buffer(launch_id)   # [rows, D], or [T, rows, D]: one draw plane per transition
+            if inbound is not None:
+                with torch.cuda.stream(inbound):
+                    block = gather.buffer(launch_id)   # (`inbound` waits for the collective that last read the buffer)
+            else:
+                block = gather.buffer(launch_id)   # [rows, D], or [T, rows, D]: one draw plane per transition
             step_fn = eng.warmup_steps if timed_phase == "warmup" else eng.sample_steps
             if compute:
+                if inbound is not None:
+                    eng.wait_stream(inbound.cuda_stream)
                 step_fn(n, block.data_ptr(), D, gather.rows * D)
+                if torch_stream is not None:
+                    eng.release_stream(torch_stream)   # the collective below is issued behind torch's stream
             # the path's only exchange: all-gather of the launch's draws over xGMI, overlapped with the next launch
             # (no-op on one GPU)
             if exchange and launch_id % args.gather_every == 0:

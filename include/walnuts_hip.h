@@ -328,6 +328,15 @@ WALNUTS_HIP_EXPORT int wn_engine_region_ms(wn_engine* e, float* total_ms, int* l
 /* run on a caller-owned hipStream_t (e.g. the framework's current stream, so that RCCL collectives on the
  * draws are ordered after the kernels without host synchronisation) */
 WALNUTS_HIP_EXPORT int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err);
+/* The same ordering without giving up the engine's own streams (and with them its chain groups): no host
+ * synchronisation in either direction.
+ *   _wait_stream:    the engine's next transition launches wait for everything `stream` holds at the time of the call
+ *                    (e.g. the collective that last read the draw buffer the launch is about to overwrite);
+ *   _release_stream: `stream` waits for every transition launch made so far (e.g. before the collective on the draws
+ *                    is issued on it).
+ * `stream` is a hipStream_t of the engine's device. */
+WALNUTS_HIP_EXPORT int wn_engine_wait_stream(wn_engine* e, void* stream, WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_engine_release_stream(wn_engine* e, void* stream, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane);
 /* the default launch geometry depends on the model (heavier gradients prefer one wavefront per chain) */
 WALNUTS_HIP_EXPORT int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane);

@@ -112,6 +112,47 @@ def test_chain_groups_match_oracle_bitwise(model, D, C, geometry, fused):
                     chain_groups=2)
 
 
+def test_stream_ordering_without_adopting_the_stream():
+    """wn_engine_wait_stream / _release_stream: a consumer on another stream (the place of the draws' collective at
+    N > 1) reads two alternating draw buffers while the engine -- two chain groups on its own streams -- runs ahead;
+    what the consumer saw equals the draws of a plain run, launch by launch."""
+    import torch
+    D, C, T, L = 1024, 4096, 2, 12
+
+    def engine(groups):
+        e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, C, wa.default_config(chain_groups=groups))
+        e.init_positions(3, 0, 2.0)
+        e.init_masses_from_grad(1e-5)
+        e.set_step_sizes(0.3)
+        e.seed_chains(4, 0)
+        e.freeze()
+        return e
+
+    ref = engine(1)
+    want = torch.empty((L, T, C, D), dtype=torch.float64, device="cuda")
+    for k in range(L):
+        ref.sample_steps(T, want[k].data_ptr(), D, C * D)
+    ref.synchronize()
+
+    e = engine(2)
+    assert e.chain_groups == 2
+    side = torch.cuda.Stream()
+    bufs = [torch.empty((T, C, D), dtype=torch.float64, device="cuda") for _ in range(2)]
+    seen = torch.zeros((L, T, C, D), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for k in range(L):
+        e.wait_stream(side.cuda_stream)          # the consumer's last read of bufs[k & 1] (launch k - 2) is done
+        e.sample_steps(T, bufs[k & 1].data_ptr(), D, C * D)
+        e.release_stream(side.cuda_stream)       # the consumer runs behind launch k
+        with torch.cuda.stream(side):
+            seen[k].copy_(bufs[k & 1])
+            for _ in range(3):                   # (a slow consumer: the engine would overtake it without the waits)
+                seen[k].add_(bufs[k & 1]).sub_(bufs[k & 1])
+    e.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(seen, want)
+
+
 def test_fused_launches_full_size_headline():
     """65 536 x 1 024: one launch of 8 transitions leaves the positions, statistics and EVERY draw plane that 8
     launches of one transition leave."""

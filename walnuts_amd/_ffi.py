@@ -126,6 +126,8 @@ SYMBOLS = [
     ("wn_engine_region_ms", _i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int), _errpp]),
     ("wn_engine_kernel_times", _i32, [_vp, C.POINTER(C.c_float), _i32, C.POINTER(C.c_int), _errpp]),
     ("wn_engine_set_stream", _i32, [_vp, _vp, _errpp]),
+    ("wn_engine_wait_stream", _i32, [_vp, _vp, _errpp]),
+    ("wn_engine_release_stream", _i32, [_vp, _vp, _errpp]),
     ("wn_lanes_for_dim", _i32, [_i32, _i32, _i32]),
     ("wn_lanes_for_model_dim", _i32, [_i32, _i32, _i32, _i32]),
     # posterior summaries (summary.hpp:370-768)

@@ -93,6 +93,7 @@ struct wn_engine {
   int group_grid[kMaxGroups] = {};
   hipStream_t gstream[kMaxGroups] = {};  // [0] is `stream`
   hipEvent_t gdone[kMaxGroups] = {}, main_point = nullptr;
+  hipEvent_t ext_point = nullptr, rel_point = nullptr;  // wn_engine_wait_stream / _release_stream
   uint32_t work_base[kMaxGroups] = {};  // value of each group's device-side chain counter at its next launch
   bool groups_ahead = false;  // a group stream holds launches `stream` has not waited for
   bool main_moved = true;     // `stream` has done something since the groups last waited for it
@@ -110,6 +111,8 @@ struct wn_engine {
       if (gdone[g]) (void)hipEventDestroy(gdone[g]);
     }
     if (main_point) (void)hipEventDestroy(main_point);
+    if (ext_point) (void)hipEventDestroy(ext_point);
+    if (rel_point) (void)hipEventDestroy(rel_point);
     if (stream && own_stream) (void)hipStreamDestroy(stream);
   }
   // `stream` waits for what the group streams hold
@@ -1028,6 +1031,26 @@ int wn_engine_set_stream(wn_engine* e, void* stream, WalnutpyError** err) {
     e->group_begin[1] = e->C;
     e->group_grid[0] = static_cast<int>(std::min<size_t>(e->C, static_cast<size_t>(e->grid)));
     e->groups_ahead = false;
+  });
+}
+int wn_engine_wait_stream(wn_engine* e, void* stream, WalnutpyError** err) {
+  return guarded(err, [&] {
+    HIP_OK(hipSetDevice(e->device));  // (not use_device(): the groups are not joined, they only get one more wait each)
+    if (e->ext_point == nullptr) HIP_OK(hipEventCreateWithFlags(&e->ext_point, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(e->ext_point, reinterpret_cast<hipStream_t>(stream)));
+    for (int g = 0; g < e->groups; ++g) HIP_OK(hipStreamWaitEvent(e->gstream[g], e->ext_point, 0));
+  });
+}
+int wn_engine_release_stream(wn_engine* e, void* stream, WalnutpyError** err) {
+  return guarded(err, [&] {
+    HIP_OK(hipSetDevice(e->device));
+    if (e->rel_point == nullptr) HIP_OK(hipEventCreateWithFlags(&e->rel_point, hipEventDisableTiming));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_OK(hipEventRecord(e->rel_point, e->stream));
+    HIP_OK(hipStreamWaitEvent(s, e->rel_point, 0));
+    // (gdone[g] was recorded behind group g's last launch; a group that has not launched yet has nothing to wait for)
+    if (e->groups_ahead)
+      for (int g = 1; g < e->groups; ++g) HIP_OK(hipStreamWaitEvent(s, e->gdone[g], 0));
   });
 }
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {

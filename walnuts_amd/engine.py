@@ -262,6 +262,14 @@ class DeviceEngine:
     def set_stream(self, stream_handle: int):
         self._call(self.lib.wn_engine_set_stream, C.c_void_p(stream_handle))
 
+    def wait_stream(self, stream_handle: int):
+        """The next transition launches wait for what the caller's stream holds now (wn_engine_wait_stream)."""
+        self._call(self.lib.wn_engine_wait_stream, C.c_void_p(stream_handle))
+
+    def release_stream(self, stream_handle: int):
+        """The caller's stream waits for every transition launch made so far (wn_engine_release_stream)."""
+        self._call(self.lib.wn_engine_release_stream, C.c_void_p(stream_handle))
+
     @property
     def lanes(self) -> int:
         return self.lib.wn_engine_lanes(self.h)

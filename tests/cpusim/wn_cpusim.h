@@ -2,14 +2,19 @@
 // of the HIP runtime API that walnuts_amd/csrc uses.  tests/cpusim/build.py compiles the product's
 // .hip sources with g++ -DWN_CPU_SIM against this header into tests/cpusim/libwalnuts_sim.so so that
 // the `-m "not gpu"` suite can drive the real host logic and the kernels' control flow (span pool,
-// random-number order, adaptation) against the oracle.  It is slow (one OS thread per lane, a barrier
-// per cross-lane operation), is never linked into libwalnuts_hip.so and proves nothing about the GPU
-// build: device parity is established by the `-m gpu` tests only.
+// random-number order, adaptation) against the oracle.  Every lane is a cooperative fiber of the
+// launching thread (its own stack, switched at every cross-lane operation and barrier: ~20 ns a
+// switch; round 3's one OS thread per lane paid a futex round trip there and made the CPU tier take
+// 17 minutes).  It is never linked into libwalnuts_hip.so and proves nothing about the GPU build:
+// device parity is established by the `-m gpu` tests only.
 #pragma once
 
 #include <algorithm>
 #include <atomic>
-#include <barrier>
+#include <cstdio>
+#include <deque>
+#include <functional>
+#include <sys/mman.h>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -18,7 +23,6 @@
 #include <memory>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -39,18 +43,116 @@ struct dim3 {
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
 
+// ---- fibers: callee-saved registers on the fiber's own stack, the stack pointer is the whole context -------------
+#if defined(__x86_64__)
+extern "C" void wnsim_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.weak wnsim_switch
+.hidden wnsim_switch
+.type wnsim_switch,@function
+wnsim_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size wnsim_switch,.-wnsim_switch
+)");
+#else
+#error "tests/cpusim: the fiber switch is written for x86-64 (the container the CPU tier runs in)"
+#endif
+
 namespace wnsim {
+struct Barrier {  // arrivals park here until the last one comes
+  unsigned expected = 0, arrived = 0;
+  std::vector<unsigned> parked;
+};
 struct Block {
   unsigned nthreads = 0;
-  std::unique_ptr<std::barrier<>> bar;
-  std::vector<std::unique_ptr<std::barrier<>>> wave_bar;  // cross-lane operations are wavefront-scoped
+  Barrier bar;
+  std::vector<Barrier> wave_bar;  // cross-lane operations are wavefront-scoped
   std::vector<uint64_t> xchg;
   double* smem = nullptr;
+  // the scheduler: lanes that can run, in the order they became runnable
+  std::deque<unsigned> ready;
+  std::vector<void*> sp;  // a suspended lane's stack pointer
+  void* main_sp = nullptr;
+  unsigned running = 0, finished = 0;
+  std::function<void()> body;
 };
 inline thread_local Block* blk = nullptr;
 inline thread_local dim3 tidx, bidx, gdim, bdim;
-inline void sync() { blk->bar->arrive_and_wait(); }
-inline void wave_sync() { blk->wave_bar[tidx.x >> 6]->arrive_and_wait(); }
+
+constexpr size_t kFiberStackBytes = size_t{1} << 20;
+// one region of lane stacks per launching thread, grown on demand and kept (pages are touched lazily)
+inline char* fiber_stacks(unsigned lanes) {
+  thread_local char* base = nullptr;
+  thread_local unsigned have = 0;
+  if (lanes > have) {
+    if (base) munmap(base, static_cast<size_t>(have) * kFiberStackBytes);
+    void* p = mmap(nullptr, static_cast<size_t>(lanes) * kFiberStackBytes, PROT_READ | PROT_WRITE,
+                   MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) {
+      std::fprintf(stderr, "cpusim: cannot map %u lane stacks\n", lanes);
+      std::abort();
+    }
+    base = static_cast<char*>(p);
+    have = lanes;
+  }
+  return base;
+}
+// hand the processor to the next runnable lane (or back to launch() when every lane has finished)
+inline void run_next(void** save_sp) {
+  Block& B = *blk;
+  if (B.ready.empty()) {
+    if (B.finished != B.nthreads) {
+      std::fprintf(stderr, "cpusim: deadlock -- %u of %u lanes wait at barriers nobody else will reach\n",
+                   B.nthreads - B.finished, B.nthreads);
+      std::abort();
+    }
+    wnsim_switch(save_sp, B.main_sp);
+    return;
+  }
+  const unsigned next = B.ready.front();
+  B.ready.pop_front();
+  B.running = next;
+  tidx = dim3(next);
+  wnsim_switch(save_sp, B.sp[next]);
+  // (back in this lane: whoever resumed it has set `running` and tidx to it)
+}
+inline void arrive(Barrier& b) {
+  Block& B = *blk;
+  if (++b.arrived == b.expected) {  // the last one: everybody else becomes runnable, this lane simply goes on
+    b.arrived = 0;
+    for (unsigned t : b.parked) B.ready.push_back(t);
+    b.parked.clear();
+    return;
+  }
+  const unsigned me = B.running;
+  b.parked.push_back(me);
+  run_next(&B.sp[me]);
+}
+inline void sync() { arrive(blk->bar); }
+inline void wave_sync() { arrive(blk->wave_bar[tidx.x >> 6]); }
+inline void fiber_entry() {
+  Block& B = *blk;
+  B.body();
+  ++B.finished;
+  void* dead = nullptr;
+  run_next(&dead);  // never comes back
+  std::abort();
+}
 // a cross-lane move inside one wavefront (only that wavefront's lanes need to arrive: one wavefront of a
 // workgroup may run scalar work the others skip)
 template <class T>
@@ -84,26 +186,33 @@ void launch(K kernel, dim3 grid, dim3 block, size_t smem_bytes, A... args) {
   for (unsigned b = 0; b < grid.x; ++b) {
     Block B;
     B.nthreads = block.x;
-    B.bar = std::make_unique<std::barrier<>>(static_cast<std::ptrdiff_t>(block.x));
+    B.bar.expected = block.x;
     B.xchg.assign(block.x, 0);
-    for (unsigned w = 0; w * 64 < block.x; ++w)
-      B.wave_bar.push_back(std::make_unique<std::barrier<>>(static_cast<std::ptrdiff_t>(std::min(64u, block.x - w * 64))));
+    B.wave_bar.resize((block.x + 63) / 64);
+    for (unsigned w = 0; w * 64 < block.x; ++w) B.wave_bar[w].expected = std::min(64u, block.x - w * 64);
     const size_t bytes = ((smem_bytes + 63) / 64 + 1) * 64;
     B.smem = static_cast<double*>(std::aligned_alloc(64, bytes));
     std::memset(B.smem, 0xCD, bytes);
-    std::vector<std::thread> th;
-    th.reserve(block.x);
+    B.body = [&] { kernel(args...); };
+    char* stacks = fiber_stacks(block.x);
+    B.sp.resize(block.x);
     for (unsigned t = 0; t < block.x; ++t) {
-      th.emplace_back([&, t] {
-        blk = &B;
-        tidx = dim3(t);
-        bidx = dim3(b);
-        gdim = grid;
-        bdim = block;
-        kernel(args...);
-      });
+      // a fresh lane: six callee-saved registers, then fiber_entry as the address the first switch returns to
+      // (the slot holding it is 16-byte aligned, so the entry sees the stack a call would have left)
+      void** top = reinterpret_cast<void**>(stacks + static_cast<size_t>(t + 1) * kFiberStackBytes);
+      top[-1] = nullptr;
+      top[-2] = reinterpret_cast<void*>(&fiber_entry);
+      for (int r = 3; r <= 8; ++r) top[-r] = nullptr;
+      B.sp[t] = top - 8;
+      B.ready.push_back(t);
     }
-    for (auto& x : th) x.join();
+    Block* outer = blk;
+    blk = &B;
+    bidx = dim3(b);
+    gdim = grid;
+    bdim = block;
+    run_next(&B.main_sp);  // returns when the last lane has finished
+    blk = outer;
     std::free(B.smem);
   }
 }

@@ -21,14 +21,14 @@ GEOMETRIES = [(1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8), (4, 2), (
               (16, 4), (16, 8)]
 
 
-def random_case(rng):
+def random_case(rng, geometries=GEOMETRIES, mem_waves=(2, 4, 8, 16), chain_counts=(1, 2, 3, 7, 16, 33, 64)):
     model = rng.choice(["std_normal", "diag_normal", "funnel", "rw1"])
     streaming = rng.uniform() < 0.15   # every model has streaming kernels (funnel / rw1: the two-pass form)
     if streaming:
-        geometry = (int(rng.choice([2, 4, 8, 16])), -1)
+        geometry = (int(rng.choice(list(mem_waves))), -1)
         D = int(rng.integers(3, 3000))
     else:
-        geometry = GEOMETRIES[int(rng.integers(len(GEOMETRIES)))]
+        geometry = geometries[int(rng.integers(len(geometries)))]
         cap = 64 * geometry[0] * geometry[1]
         D = int(rng.integers(max(2, cap // 4), cap + 1))
     kw = dict(warmup=int(rng.integers(0, 5)), sampling=int(rng.integers(1, 5)), geometry=geometry,
@@ -54,18 +54,23 @@ def random_case(rng):
         kw.update(average_masses=True)
     kw.update(fused_multiply_add=int(rng.integers(0, 2)))   # both arithmetic modes
     kw.update(fused=int(rng.choice([1, 1, 2, 3, 5])))       # transitions per launch (wn_engine_*_steps)
-    C = int(rng.choice([1, 2, 3, 7, 16, 33, 64]))
+    C = int(rng.choice(list(chain_counts)))
+    if C > 1 and rng.uniform() < 0.3:
+        kw.update(chain_groups=2)                           # two independently launched blocks of chains
     return model, D, C, kw
 
 
-def campaign(seed: int, seconds: float, cases: int = 10**9, verbose: bool = False):
-    """-> (cases run, failing descriptions, tally)"""
+def campaign(seed: int, seconds: float, cases: int = 10**9, verbose: bool = False, lib_path=None, **case_kw):
+    """-> (cases run, failing descriptions, tally).  lib_path / case_kw: the CPU tier runs the same campaign against
+    the workgroup emulation with its reduced geometry table (tests/test_sim_parity.py)."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
     done, failed, tally = 0, [], {}
     while done < cases and time.time() - t0 < seconds:
-        model, D, C, kw = random_case(rng)
-        desc = f"{model} D={D} C={C} " + " ".join(f"{k}={v}" for k, v in sorted(kw.items()))
+        model, D, C, kw = random_case(rng, **case_kw)
+        if lib_path is not None:
+            kw["lib_path"] = lib_path
+        desc = f"{model} D={D} C={C} " + " ".join(f"{k}={v}" for k, v in sorted(kw.items()) if k != "lib_path")
         try:
             dev, orc = parity.run_case(model, D, C, **kw)
             evals = int(dev.grad_evals().sum())

@@ -48,6 +48,51 @@ def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry, fma):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("fma", [1, 0])
+@pytest.mark.parametrize("model,D,geometry,fused", [
+    ("std_normal", 1024, (1, 16), 1),     # the headline kernel: one wavefront per chain, the span's other end parked
+    ("std_normal", 1024, (1, 16), 4),     # ... four transitions per launch
+    ("diag_normal", 1024, (1, 16), 1),    # config #2's kernel (per-coordinate parameters in registers)
+    ("funnel", 1024, (1, 16), 3),         # general gradient at the headline dimension
+    ("std_normal", 1024, (2, 8), 2),      # two wavefronts per chain at one per SIMD
+    ("rw1", 900, (2, 8), 1),
+    ("std_normal", 1000, (4, 4), 1),      # four wavefronts, ragged padding
+    ("funnel", 1000, (4, 4), 2),          # cross-wavefront sums inside the model
+    ("rw1", 1024, (4, 4), 1),             # rw1's own geometry at 1 024 dimensions
+    ("std_normal", 4096, (8, 8), 1),      # eight wavefronts
+    ("diag_normal", 16384, (4, -1), 3),   # config #4's dimension: streaming, four wavefronts, LDS-parked inverse mass
+    ("funnel", 16384, (2, -1), 1),        # streaming, two passes per micro step
+    ("rw1", 12000, (4, -1), 2),           # streaming with halo reads
+    ("std_normal", 20000, (2, -1), 1),    # ragged last tile
+])
+def test_emulated_full_size_geometries(sim, oracle, model, D, geometry, fused, fma):
+    """The geometries the benchmarks run at -- the headline's (1, 16) at 1 024 dimensions, its multi-wavefront
+    neighbours, the streaming kernels at 12 000-20 000 dimensions -- bit for bit against the oracle in both arithmetic
+    modes, on the CPU tier (cheap since the emulation runs lanes as fibers; the GPU tier repeats them on the device)."""
+    parity.run_case(model, D, 3, warmup=2 * fused + 2, sampling=2 * fused + 1, lib_path=sim, geometry=geometry,
+                    fused_multiply_add=fma, fused=fused)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed", [2025, 7])
+def test_emulated_random_campaign(sim, oracle, seed):
+    """The GPU tier's randomised parity campaign (tests/gpu_probes/fuzz_parity.py: random model, dimension, geometry,
+    pool tiers, step size, tree depth, halvings, micro steps, error bound, arithmetic mode, transitions per launch,
+    chain groups) against the emulation, over the geometries the emulation is built with: a fixed number of cases per
+    seed, every one bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "wn_fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_probes", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    done, failed, tally = fuzz.campaign(seed, seconds=300.0, cases=40, lib_path=sim,
+                                        geometries=[(1, 2), (1, 4), (2, 2), (1, 16), (2, 8), (4, 4), (8, 8)],
+                                        mem_waves=(1, 2, 4), chain_counts=(1, 2, 3, 5))
+    assert done == 40 and not failed, failed
+    assert len(tally) >= 8, tally   # (the cases really spread over models and geometries)
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("model,D,fma,kw", [
     ("funnel", 140, 1, dict(warmup=2, sampling=2, max_trajectory_doublings=4)),   # sums over the coordinates: two passes per micro step
     ("funnel", 140, 0, dict(warmup=1, sampling=2, step=1.6, max_trajectory_doublings=3)),   # halvings + reversibility

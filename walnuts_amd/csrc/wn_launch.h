@@ -22,7 +22,7 @@ struct Geometry {
 
 // X(NW) -- wavefronts per chain of the streaming kernels
 #if defined(WN_SIM_GEOMETRIES)
-#define WN_FOR_EACH_MEM_GEOMETRY(X) X(1)
+#define WN_FOR_EACH_MEM_GEOMETRY(X) X(1) X(2) X(4)
 #elif defined(WN_FAST_BUILD)
 #define WN_FOR_EACH_MEM_GEOMETRY(X) X(4)
 #else
@@ -46,8 +46,8 @@ inline int default_mem_waves() {
 constexpr int kMaxRegisterDim = 8192;
 
 // X(NW, EPL) -- the register kernels (TrajChip, wn_chip.h)
-#if defined(WN_SIM_GEOMETRIES)  // tests/cpusim: small workgroups only
-#define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(1, 4) X(2, 2)
+#if defined(WN_SIM_GEOMETRIES)  // tests/cpusim: a cross-section (the headline's (1, 16) and its neighbours included)
+#define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(1, 4) X(2, 2) X(1, 16) X(2, 8) X(4, 4) X(8, 8)
 #elif defined(WN_FAST_BUILD)
 #define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(4, 4) X(2, 8) X(1, 16)
 #else

@@ -19,6 +19,9 @@ $B --no-cpu-baseline --model funnel --chains 16384 --dim 1024 --adapt-iters 150 
 $B --no-cpu-baseline --model rw1 --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_rw1_1024.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --fma 0 > $OUT/bench_headline_every_product_rounded.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --transitions-per-launch 1 > $OUT/bench_headline_one_transition_per_launch.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --chain-groups 1 > $OUT/bench_headline_one_chain_group.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --chain-groups 1 --model ill_normal --chains 4096 --dim 1024 --adapt-iters 300 > $OUT/bench_cfg2_one_chain_group.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --chain-groups 1 --model funnel --chains 16384 --dim 128 --adapt-iters 300 > $OUT/bench_cfg3_one_chain_group.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --chains 8192 --steps 40 > $OUT/bench_shard_8192.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --chains 16384 --steps 40 > $OUT/bench_shard_16384.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --chains 32768 --steps 40 > $OUT/bench_shard_32768.json 2>> $OUT/bench.err
@@ -28,6 +31,9 @@ $B --gpus 2 --backend gloo --no-cpu-baseline --steps 16 --warmup 8 > $OUT/bench_
 rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --steps 16 --warmup 8 > /dev/null 2>&1
 python3 $ROOT/profiles/summarize.py $R $(find $OUT/headline_trace -name "*results.db" | head -1) > $OUT/kernel_trace_headline.txt 2>&1
 rm -rf $OUT/headline_trace
+# the whole drop-in call, phase by phase (WALNUTS_AMD_TIMING), and a longer run of the randomised parity campaign
+(cd $ROOT && timeout 900 python3 tests/gpu_probes/sample_device_e2e.py > $OUT/sample_device_e2e.txt 2>&1)
+(cd $ROOT && timeout 600 python3 tests/gpu_probes/fuzz_parity.py --seconds 240 --seed 404 > $OUT/fuzz_parity.txt 2>&1; tail -3 $OUT/fuzz_parity.txt)
 for f in $OUT/bench_*.json; do python3 -c "
 import json,sys
 d=json.load(open('$f')); r=d['roofline']

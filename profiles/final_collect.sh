@@ -9,4 +9,6 @@ R=$PROFILE_ROUND
 python profiles/record_pmc.py headline headline_warmup funnel_1024 rw1_1024 cfg4 cfg2 cfg3
 mkdir -p profiles/bench_$R profiles/$R && cp gpurun_out/$R/bench_*.json profiles/bench_$R/
 cp gpurun_out/$R/kernel_trace_headline.txt profiles/$R/kernel_trace_headline.txt   # (summarised on the GPU box by collect.sh)
+cp gpurun_out/$R/sample_device_e2e.txt profiles/$R/sample_device_e2e.txt
+cp gpurun_out/$R/fuzz_parity.txt profiles/$R/fuzz_parity.txt
 head -30 profiles/$R/kernel_trace_headline.txt

@@ -161,6 +161,9 @@ def measured_traffic(args, D, chains_local, transitions_per_average_launch):
     walnuts_amd/csrc and THIS number of transitions per launch counts; anything else is reported as stale and not
     used.  The profiled dispatch ran a full launch; when K is not a multiple of the transitions per launch the average
     launch of the timed region is shorter and the figure is scaled by transitions."""
+    switched = [v for v in ("WALNUTS_AMD_NO_LDS_MASS", "WALNUTS_AMD_NO_FAR_END_SUMS", "WALNUTS_AMD_LIB") if os.environ.get(v)]
+    if switched:   # (the recorded passes ran the library as built, with its default switches)
+        return None, "not recorded for this run's switches (" + ", ".join(switched) + ")"
     try:
         entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except OSError:
@@ -608,9 +611,17 @@ def main():
                         "traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                         "kernel": "wn::transition_kernel_mem", "avg_launch_ms": avg_kernel_ms, "avg_launch_ms_from": timing_method,
                         "algorithmic_bytes_per_launch": algorithmic_bytes,
-                        "note": "algorithmic bytes = 56*D per grad-eval; the streaming kernels move theta, rho and the "
-                                "inverse mass per micro step and recompute the element-wise gradient (40*D); part of the "
-                                "counter traffic is served by the 256 MiB Infinity Cache"}
+                        # the same launch priced on what a one-pass streaming kernel has to move by design: theta and
+                        # rho in and out and the inverse mass in, the element-wise gradient recomputed = 40*D
+                        "design_bytes": {"per_grad_eval_per_dim": 40, "GBps": algorithmic_gbps * 40.0 / 56.0,
+                                         "frac": algorithmic_gbps * 40.0 / 56.0 / HBM_PEAK_GBPS},
+                        "note": "achieved / frac price the launch at SURVEY.md section 8(d)'s 56*D bytes per grad-eval (theta, "
+                                "rho, gradient and inverse mass read; theta, rho, gradient written).  The one-pass streaming "
+                                "kernel never stores a gradient (element-wise: recomputed) and, when it fits, keeps the "
+                                "inverse mass in LDS for the whole transition, so it moves 32-40*D plus the U-turn tests' "
+                                "span ends: frac can exceed 1 on the 56*D definition.  The bandwidth actually drawn is "
+                                "traffic_frac (rocprofv3 PMC; part of it served by the 256 MiB Infinity Cache); models "
+                                "whose gradient needs two passes per micro step (funnel, rw1) move 72*D"}
         else:
             flops = FLOPS_PER_GRAD_EVAL_PER_DIM * D * evals_per_launch
             tf = flops / kernel_s / 1e12

@@ -28,7 +28,7 @@ $B --no-cpu-baseline --no-parity-gate --chains 32768 --steps 40 > $OUT/bench_sha
 $B --no-cpu-baseline --model funnel --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_funnel_16384_streaming.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model rw1 --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_rw1_16384_streaming.json 2>> $OUT/bench.err
 $B --gpus 2 --backend gloo --no-cpu-baseline --steps 16 --warmup 8 > $OUT/bench_gloo2_one_gpu.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --steps 16 --warmup 8 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate > $OUT/bench_headline_under_trace.json 2>/dev/null
 python3 $ROOT/profiles/summarize.py $R $(find $OUT/headline_trace -name "*results.db" | head -1) > $OUT/kernel_trace_headline.txt 2>&1
 rm -rf $OUT/headline_trace
 # the whole drop-in call, phase by phase (WALNUTS_AMD_TIMING), and a longer run of the randomised parity campaign

@@ -15,6 +15,18 @@ def kernel_stats(db):
     lines.append("transition_kernel dispatches (us, grid threads, block, LDS bytes, VGPRs, SGPRs):")
     for r in rows:
         lines.append(f"  {r[1]:.1f} us  grid={r[2]} block={r[3]} lds={r[4]} vgpr={r[5]} sgpr={r[6]}")
+    if rows:
+        # the timed phase's kernel = the last dispatch's; with chain groups (wn_config::chain_groups) a launch is two of
+        # them on two streams.  Right after a join (freeze, a read-back) the two start aligned -- the first runs alone
+        # on the whole chip, the second waits for its slots -- and drift apart over the next launches; from then on each
+        # kernel lasts one launch period while sharing the chip, which is bench.py's avg_launch_ms.
+        last = [r[1] for r in rows if r[0] == rows[-1][0]]
+        lines.append("")
+        lines.append(f"timed phase's kernel ({rows[-1][0][:60]}...): {len(last)} dispatches, mean {sum(last) / len(last):.1f} us")
+        if len(last) > 8:
+            steady = last[4:]
+            lines.append(f"  steady state (without the first four dispatches after the join): {len(steady)} dispatches, "
+                         f"mean {sum(steady) / len(steady):.1f} us, min {min(steady):.1f}, max {max(steady):.1f}")
     return lines, rows
 
 

@@ -308,7 +308,11 @@ WALNUTS_HIP_EXPORT int wn_engine_workgroups(const wn_engine* e);   /* persistent
 WALNUTS_HIP_EXPORT int wn_engine_chain_groups(const wn_engine* e); /* concurrent kernels per transition launch */
 WALNUTS_HIP_EXPORT int wn_engine_lds_vectors(const wn_engine* e);  /* pool vectors resident in LDS      */
 WALNUTS_HIP_EXPORT int64_t wn_engine_iteration(const wn_engine* e);
-WALNUTS_HIP_EXPORT void* wn_engine_stream(const wn_engine* e);     /* hipStream_t the kernels run on    */
+WALNUTS_HIP_EXPORT void* wn_engine_stream(const wn_engine* e);     /* the engine's main hipStream_t: everything but the
+                                                                      transition launches of chain groups 1.. runs on
+                                                                      it.  Work queued on it behind a transition is
+                                                                      ordered after ALL groups only through
+                                                                      wn_engine_release_stream / wn_engine_synchronize */
 /* device pointer to the [C][Dp] position plane (for RCCL all-gather of draws) */
 WALNUTS_HIP_EXPORT double* wn_engine_positions_device(const wn_engine* e);
 /* HIP-event time of the last transition kernel launch, milliseconds */
@@ -336,6 +340,9 @@ WALNUTS_HIP_EXPORT int wn_engine_set_stream(wn_engine* e, void* stream, Walnutpy
  *                    is issued on it).
  * `stream` is a hipStream_t of the engine's device. */
 WALNUTS_HIP_EXPORT int wn_engine_wait_stream(wn_engine* e, void* stream, WalnutpyError** err);
+/* ... the same for ONE recorded hipEvent_t instead of everything a stream holds (a double-buffered consumer waits for
+ * the copy of the block about to be overwritten, not for the copy it has just queued) */
+WALNUTS_HIP_EXPORT int wn_engine_wait_event(wn_engine* e, void* event, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_engine_release_stream(wn_engine* e, void* stream, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_lanes_for_dim(int num_params, int waves_per_chain, int elems_per_lane);
 /* the default launch geometry depends on the model (heavier gradients prefer one wavefront per chain) */

@@ -59,6 +59,25 @@ def test_draw_sink_streams_the_headline_chain_count_through_a_small_staging_buff
         assert np.array_equal(np.asarray(big[c]), np.asarray(small[c])), c
 
 
+def test_draw_copies_are_ordered_behind_every_chain_group(monkeypatch):
+    """The staging blocks' copies (and the resident mode's thinned rows) leave on a second stream: they must wait for
+    the launches of EVERY chain group, and a block must not be refilled by any group while it is still being copied.
+    8 192 chains (two groups on 1 024 workgroups) through staging blocks of one iteration each -- a flush per iteration
+    -- against the same call with one chain group; then the resident mode's thinned rows against the streamed rows."""
+    C, D, T = 8192, 1024, 12
+    kw = dict(num_params=D, num_chains=C, seed=5, min_warmup_iter=4, max_warmup_iter=4, min_sampling_iter=T,
+              max_sampling_iter=T, save_warmup=True)
+    monkeypatch.setenv("WALNUTS_AMD_DRAW_STAGING_BYTES", str(2 * C * D * 8))
+    two = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    thinned, chains = wa.walnuts_device(wa.MODEL_STD_NORMAL, keep_on_device=True, thin=1, **kw)
+    monkeypatch.setenv("WALNUTS_AMD_CHAIN_GROUPS", "1")
+    one = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    for c in list(range(0, C, 257)) + [C // 2 - 1, C // 2, C - 1]:
+        assert np.array_equal(np.asarray(two[c]), np.asarray(one[c])), c
+        assert np.array_equal(two[c].warmup.warmup_draws, one[c].warmup.warmup_draws), c
+        assert np.array_equal(np.asarray(thinned[c]), np.asarray(one[c])), c
+
+
 def test_reference_summary_symbols_on_the_device(oracle):
     rng = np.random.default_rng(3)
     chains = sp.ar_chains(rng, 6, 130, [230, 170, 290, 201, 199, 333], rng.uniform(0, 0.95, size=130))

@@ -128,6 +128,7 @@ SYMBOLS = [
     ("wn_engine_set_stream", _i32, [_vp, _vp, _errpp]),
     ("wn_engine_wait_stream", _i32, [_vp, _vp, _errpp]),
     ("wn_engine_release_stream", _i32, [_vp, _vp, _errpp]),
+    ("wn_engine_wait_event", _i32, [_vp, _vp, _errpp]),
     ("wn_lanes_for_dim", _i32, [_i32, _i32, _i32]),
     ("wn_lanes_for_model_dim", _i32, [_i32, _i32, _i32, _i32]),
     # posterior summaries (summary.hpp:370-768)

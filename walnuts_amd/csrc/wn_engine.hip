@@ -1041,6 +1041,12 @@ int wn_engine_wait_stream(wn_engine* e, void* stream, WalnutpyError** err) {
     for (int g = 0; g < e->groups; ++g) HIP_OK(hipStreamWaitEvent(e->gstream[g], e->ext_point, 0));
   });
 }
+int wn_engine_wait_event(wn_engine* e, void* event, WalnutpyError** err) {
+  return guarded(err, [&] {
+    HIP_OK(hipSetDevice(e->device));
+    for (int g = 0; g < e->groups; ++g) HIP_OK(hipStreamWaitEvent(e->gstream[g], reinterpret_cast<hipEvent_t>(event), 0));
+  });
+}
 int wn_engine_release_stream(wn_engine* e, void* stream, WalnutpyError** err) {
   return guarded(err, [&] {
     HIP_OK(hipSetDevice(e->device));

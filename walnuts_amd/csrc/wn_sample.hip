@@ -176,8 +176,11 @@ struct PinnedRange {
 class DrawSink {
  public:
   // `rows`: rows per chain of the caller's buffer; `capacity`: how many of them this sink will be asked to write
-  DrawSink(size_t chains, size_t rows, size_t capacity, size_t dim, double* out, hipStream_t compute)
-      : C_(chains), rows_(rows), D_(dim), out_(out), compute_(compute) {
+  // `engine`: whose transition launches fill the blocks.  The copies are ordered against ALL of its launches through
+  // the engine (wn_engine_release_stream / _wait_event), not against one stream of it: with chain groups a launch is
+  // several kernels on several streams.
+  DrawSink(size_t chains, size_t rows, size_t capacity, size_t dim, double* out, wn_engine* engine)
+      : C_(chains), rows_(rows), D_(dim), out_(out), engine_(engine) {
     if (C_ * capacity * D_ == 0) return;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t{1} << 30;
@@ -195,7 +198,6 @@ class DrawSink {
       span_ = (span_ + 1) / 2;
     }
     for (int b = 0; b < 2; ++b) {
-      filled_[b].create();
       drained_[b].create();
     }
     copy_.create();
@@ -204,7 +206,7 @@ class DrawSink {
   // where the next iteration's draws go (device pointer of chain 0's row)
   double* next_row() {
     if (fill_ == 0 && busy_[cur_]) {  // the block still feeds a copy: the kernels must not overwrite it yet
-      if (hipStreamWaitEvent(compute_, drained_[cur_].e, 0) != hipSuccess) throw std::runtime_error("draw sink: wait failed");
+      WN_CALL(wn_engine_wait_event(engine_, drained_[cur_].e, &call_err_));
       busy_[cur_] = false;
     }
     return block_[cur_].p + fill_ * D_;
@@ -227,9 +229,8 @@ class DrawSink {
  private:
   void flush() {
     const size_t first = written_ - fill_;
-    if (hipEventRecord(filled_[cur_].e, compute_) != hipSuccess ||
-        hipStreamWaitEvent(copy_.s, filled_[cur_].e, 0) != hipSuccess ||
-        hipMemcpy2DAsync(out_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_].p, span_ * D_ * sizeof(double),
+    WN_CALL(wn_engine_release_stream(engine_, copy_.s, &call_err_));  // the copy runs behind every launch made so far
+    if (hipMemcpy2DAsync(out_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_].p, span_ * D_ * sizeof(double),
                          fill_ * D_ * sizeof(double), C_, hipMemcpyDeviceToHost, copy_.s) != hipSuccess ||
         hipEventRecord(drained_[cur_].e, copy_.s) != hipSuccess)
       throw std::runtime_error("copying draws to the host failed");
@@ -239,10 +240,10 @@ class DrawSink {
   }
   size_t C_, rows_, D_;
   double* out_;
-  hipStream_t compute_;
+  wn_engine* engine_;
   Stream copy_;
   DevBlock block_[2];
-  Event filled_[2], drained_[2];
+  Event drained_[2];
   bool busy_[2] = {false, false};
   size_t span_ = 1, fill_ = 0, written_ = 0;
   int cur_ = 0;
@@ -253,9 +254,9 @@ class DrawSink {
 class ResidentDraws {
  public:
   ResidentDraws(size_t chains, size_t max_sampling, size_t dim, int thin, double* out, size_t out_rows,
-                size_t out_first_row, hipStream_t compute)
+                size_t out_first_row, wn_engine* engine)
       : C_(chains), S_(max_sampling), D_(dim), thin_(thin), out_(out), out_rows_(out_rows), out_first_(out_first_row),
-        compute_(compute) {
+        engine_(engine) {
     size_t free_b = 0, total_b = 0;
     const size_t bytes = C_ * S_ * D_ * sizeof(double);
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b - free_b / 16) {
@@ -266,7 +267,6 @@ class ResidentDraws {
       throw std::runtime_error(ss.str());
     }
     if (bytes > 0 && !block_.alloc(C_ * S_ * D_)) throw std::runtime_error("cannot allocate the device-resident draw block");
-    ready_.create();
     copy_.create();
   }
   int64_t stride() const { return static_cast<int64_t>(S_ * D_); }
@@ -277,8 +277,8 @@ class ResidentDraws {
   void row_done() {
     if (thin_ > 0 && written_ % static_cast<size_t>(thin_) == 0) {
       const size_t k = written_ / static_cast<size_t>(thin_);
-      if (hipEventRecord(ready_.e, compute_) != hipSuccess || hipStreamWaitEvent(copy_.s, ready_.e, 0) != hipSuccess ||
-          hipMemcpy2DAsync(out_ + (out_first_ + k) * D_, out_rows_ * D_ * sizeof(double), block_.p + written_ * D_,
+      WN_CALL(wn_engine_release_stream(engine_, copy_.s, &call_err_));  // (every chain group's launch, not one stream's)
+      if (hipMemcpy2DAsync(out_ + (out_first_ + k) * D_, out_rows_ * D_ * sizeof(double), block_.p + written_ * D_,
                            S_ * D_ * sizeof(double), D_ * sizeof(double), C_, hipMemcpyDeviceToHost,
                            copy_.s) != hipSuccess)
         throw std::runtime_error("copying thinned draws to the host failed");
@@ -296,9 +296,8 @@ class ResidentDraws {
   int thin_;
   double* out_;
   size_t out_rows_, out_first_;
-  hipStream_t compute_;
+  wn_engine* engine_;
   DevBlock block_;
-  Event ready_;
   Stream copy_;
   size_t written_ = 0;
 };
@@ -583,10 +582,10 @@ static int sample_device_impl(
       try {
         if (hipSetDevice(cfg.device) != hipSuccess) throw std::runtime_error("cannot select the device");
         pinned = std::make_unique<PinnedRange>(out, num_chains * draws_offset * sizeof(double));
-        sink_holder = std::make_unique<DrawSink>(num_chains, rows, resident != nullptr ? warm_rows : rows, D, out, compute);
+        sink_holder = std::make_unique<DrawSink>(num_chains, rows, resident != nullptr ? warm_rows : rows, D, out, e);
         if (resident != nullptr)
           kept = std::make_unique<ResidentDraws>(num_chains, static_cast<size_t>(max_sampling_iter), D, resident->thin,
-                                                 out, rows, warm_rows, compute);
+                                                 out, rows, warm_rows, e);
       } catch (...) {
         prep_error = std::current_exception();
       }

@@ -17,9 +17,12 @@
  *      ::sampler() (:263-271) and walnutpie::WalnutsSampler::operator()
  *      (walnuts.hpp:682-692) -- each call advancing ALL chains by one transition.
  *
- * A host LOGP_CFUNC cannot be called from a GPU-resident trajectory, so
- * walnutpie_sample_cfunc / walnutpie_sample_bridgestan are intentionally NOT
- * provided here; callers with host models keep using the reference library.
+ * A host LOGP_CFUNC cannot be called from a GPU-resident trajectory and this library has
+ * no CPU path.  walnutpie_sample_cfunc / walnutpie_sample_bridgestan are exported with the
+ * reference's signatures so that the library can stand in for libwalnutpy at LOAD time (the
+ * reference's python/src/walnutpie/_ffi.py binds every symbol at import), but calling one
+ * fails with a config error naming walnutpie_sample_device; callers with host models keep
+ * the reference library for those calls.
  *
  * Every function returns 0 on success and -1 on failure; on failure *err (when
  * err != NULL) receives a WalnutpyError to be freed with walnutpie_destroy_error,
@@ -38,6 +41,7 @@ extern "C" {
 
 #define WALNUTS_HIP_EXPORT __attribute__((visibility("default")))
 
+
 /* ---- errors: python/src/walnutpie/errors.hpp:10-24, walnutpy.cpp:371-389 ---- */
 typedef enum { generic = 0, config = 1, interrupt = 2 } WalnutpyErrorType;
 typedef struct WalnutpyError WalnutpyError;
@@ -47,6 +51,27 @@ WALNUTS_HIP_EXPORT void walnutpie_destroy_error(WalnutpyError* err);
 
 /* progress callback: python/src/walnutpie/handlers.hpp:15 */
 typedef void (*PRINT_CALLBACK)(const char* msg, size_t len, bool bad);
+
+/* ---- the reference's host-model entry points: present, never sampling (see above) -------------
+ * walnutpy.cpp:131-149 (LOGP_CFUNC model), :227-245 (BridgeStan model), :224-225 (the separator of
+ * the per-chain init strings).  Both samplers return -1 with error type `config`. */
+typedef int (*WN_LOGP_CFUNC)(size_t size, const double* theta, double* grad, double* lp, void* data);
+#define WN_REFERENCE_SAMPLING_PARAMS                                                                              \
+  size_t num_chains, unsigned int seed, unsigned int id, double init_radius, const double *init_inv_metric,      \
+      int min_warmup_iter, int max_warmup_iter, int min_sampling_iter, int max_sampling_iter,                    \
+      int max_trajectory_doublings, int max_step_halvings, int min_micro_steps, double max_hamiltonian_error,    \
+      double step_size_converge_tol, double mass_converge_tol, double rhat_converge_tol, double mass_init_count, \
+      double mass_additive_smoothing, double max_macro_steps_target, double step_size_init,                      \
+      double step_accept_rate_target, double step_learning_rate, double step_gradient_decay,                     \
+      double step_sq_gradient_decay, double step_stabilization, double step_learn_rate_decay, bool save_warmup,  \
+      double *out, size_t out_size, int *final_lengths, double *stepsize_out, double *inv_metric_out,            \
+      int refresh, PRINT_CALLBACK print, WalnutpyError **err
+WALNUTS_HIP_EXPORT int walnutpie_sample_cfunc(WN_LOGP_CFUNC logp_c, void* data, int num_params, const double* inits,
+                                              WN_REFERENCE_SAMPLING_PARAMS);
+WALNUTS_HIP_EXPORT int walnutpie_sample_bridgestan(const char* bs_dll, const char* json_data,
+                                                   PRINT_CALLBACK callback, unsigned int model_seed,
+                                                   const char* inits, WN_REFERENCE_SAMPLING_PARAMS);
+WALNUTS_HIP_EXPORT char walnutpie_separator_char(void);
 
 /* ---- built-in device models (the LogpGrad contract, concepts.hpp:258-262) ---- */
 typedef enum {

@@ -29,6 +29,44 @@ def test_hip_library_exports_every_declared_symbol():
         assert hasattr(lib, name)
 
 
+def test_library_stands_in_for_libwalnutpy_at_load_time_and_refuses_host_models():
+    """Every symbol the reference's python/src/walnutpie/_ffi.py binds at import exists; the two host-model samplers
+    refuse with the reference's error protocol (rc != 0, type `config` -> ValueError there) instead of sampling on a
+    CPU path that does not exist."""
+    if not os.path.exists(ffi.DEFAULT_LIB):
+        pytest.fail("walnuts_amd/lib/libwalnuts_hip.so is not built: run __graft_entry__.build()")
+    import ctypes as C
+    import numpy as np
+    lib = ffi.load_library()
+    for name in ("walnutpie_get_error_message", "walnutpie_get_error_type", "walnutpie_destroy_error",
+                 "walnutpie_sample_cfunc", "walnutpie_sample_bridgestan", "walnutpie_ess", "walnutpie_r_hat",
+                 "walnutpie_mcse", "walnutpie_separator_char"):
+        assert hasattr(lib, name), name
+    assert lib.walnutpie_separator_char() == b"\x1c"
+    called = []
+
+    @ffi.LOGP_CFUNC
+    def logp(size, theta, grad, lp, data):
+        called.append(size)
+        return 0
+
+    out = np.zeros(4 * 3)
+    lengths = np.zeros(2, dtype=np.intc)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    trailing = [1, 1, 0, 2.0, None, 1, 1, 1, 1, 8, 8, 1, 0.5, 0.1, 0.1, 1.1, 1.0, 1e-5, 8.0, 1.0, 0.8, 0.2, 0.3, 0.99, 0.1,
+                0.5, False, dp(out), out.size, lengths.ctypes.data_as(C.POINTER(C.c_int)), None, None, 0,
+                ffi.PRINT_CALLBACK(0)]
+    for call in (lambda e: lib.walnutpie_sample_cfunc(logp, None, 3, None, *trailing, C.byref(e)),
+                 lambda e: lib.walnutpie_sample_bridgestan(b"model.so", b"{}", ffi.PRINT_CALLBACK(0), 1, b"", *trailing,
+                                                           C.byref(e))):
+        err = C.c_void_p()
+        assert call(err) != 0 and err.value
+        assert lib.walnutpie_get_error_type(err) == 1   # config (errors.hpp:10-24) -> ValueError in the reference's wrapper
+        assert b"walnutpie_sample_device" in lib.walnutpie_get_error_message(err)
+        lib.walnutpie_destroy_error(err)
+    assert not called and not out.any()
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(ffi.WalnutsHipError, match="no CPU fallback"):
         ffi.load_library(str(tmp_path / "nope.so"))

@@ -46,10 +46,22 @@ class Config(C.Structure):
 # every symbol include/walnuts_hip.h declares: (name, restype, argtypes)
 _vp, _sz, _i32, _i64, _u32, _u64, _dbl = C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
 _i32p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+# the reference's trailing sampling arguments (python/src/walnutpie/_ffi.py: _common_sampling_argtypes)
+_REFERENCE_SAMPLING_ARGS = [_sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl, _dbl,
+                            _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz,
+                            C.POINTER(C.c_int), _dp, _dp, _i32, PRINT_CALLBACK, _errpp]
+LOGP_CFUNC = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                         C.c_void_p)
 SYMBOLS = [
     ("walnutpie_get_error_message", C.c_char_p, [_vp]),
     ("walnutpie_get_error_type", _i32, [_vp]),
     ("walnutpie_destroy_error", None, [_vp]),
+    # host-model entry points of the reference: exported so that the library loads where libwalnutpy is expected; a call
+    # fails with a config error (no CPU path exists here)
+    ("walnutpie_sample_cfunc", _i32, [LOGP_CFUNC, _vp, _i32, _dp] + _REFERENCE_SAMPLING_ARGS),
+    ("walnutpie_sample_bridgestan", _i32, [C.c_char_p, C.c_char_p, PRINT_CALLBACK, C.c_uint, C.c_char_p]
+     + _REFERENCE_SAMPLING_ARGS),
+    ("walnutpie_separator_char", C.c_char, []),
     ("walnutpie_sample_device", _i32,
      [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
       _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),

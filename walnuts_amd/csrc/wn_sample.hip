@@ -5,9 +5,10 @@
 // What is kept: argument list after the model, validation and error types, output layout
 // out[C][max_sampling + max_warmup*save_warmup][num_params] written chain-major, final_lengths
 // [C warmup rows | C sampling rows], stepsize_out[C], inv_metric_out[C][num_params], progress lines.
-// Initial positions and the step-size search consume the same libstdc++ streams as the reference
-// (seed_seq{seed,1} and seed_seq{seed,2}; walnutpy.cpp:187-189,75-76): they are generated on the host,
-// so those inputs are bit-identical to the reference's.
+// Initial positions and the step-size search draw from the engine's counter-based streams on the device; in
+// walnutpie_sample_device_reference_streams they consume the same libstdc++ streams as the reference
+// (seed_seq{seed,1} and seed_seq{seed,2}; walnutpy.cpp:187-189,75-76), generated on the host, so that there
+// those inputs are bit-identical to the reference's.
 // What differs (documented in INTEGRATION.md): chains advance in lock step, so the controllers' stopping
 // rules (adapt.hpp:172-229, sampler.hpp:117-158) are evaluated on whole iterations and every chain gets the same
 // length (the reference's thread-per-chain workers stop wherever they happen to be), and the
@@ -847,6 +848,45 @@ extern "C" void wn_internal_reference_normals(unsigned int seed, unsigned int st
   std::mt19937_64 rng(ss);
   wnref::polar_stream_fill(rng, pool, scale, num_chains, count_per_chain, fresh_per_chain != 0, out);
 }
+
+// ---- the reference's host-model entry points (walnutpy.cpp:134-149, 227-245): exported so that the library loads
+// where libwalnutpy is expected, and refusing to sample -- a host callback cannot run inside a GPU-resident
+// trajectory, and there is no CPU path in this library to fall back to
+namespace {
+int refuse_host_model(const char* symbol, WalnutpyError** err) {
+  const std::string msg = std::string(symbol) +
+                          ": this library samples device models only (a host log-density callback cannot be called "
+                          "from a GPU-resident trajectory and there is no CPU path here); use walnutpie_sample_device "
+                          "with a model compiled through walnuts_amd/csrc/wn_model_api.h, or the reference library for "
+                          "host models";
+  if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error(msg.c_str(), config));
+  return -1;
+}
+}  // namespace
+extern "C" int walnutpie_sample_cfunc(WN_LOGP_CFUNC, void*, int, const double*, WN_REFERENCE_SAMPLING_PARAMS) {
+  (void)num_chains, (void)seed, (void)id, (void)init_radius, (void)init_inv_metric, (void)min_warmup_iter;
+  (void)max_warmup_iter, (void)min_sampling_iter, (void)max_sampling_iter, (void)max_trajectory_doublings;
+  (void)max_step_halvings, (void)min_micro_steps, (void)max_hamiltonian_error, (void)step_size_converge_tol;
+  (void)mass_converge_tol, (void)rhat_converge_tol, (void)mass_init_count, (void)mass_additive_smoothing;
+  (void)max_macro_steps_target, (void)step_size_init, (void)step_accept_rate_target, (void)step_learning_rate;
+  (void)step_gradient_decay, (void)step_sq_gradient_decay, (void)step_stabilization, (void)step_learn_rate_decay;
+  (void)save_warmup, (void)out, (void)out_size, (void)final_lengths, (void)stepsize_out, (void)inv_metric_out;
+  (void)refresh, (void)print;
+  return refuse_host_model("walnutpie_sample_cfunc", err);
+}
+extern "C" int walnutpie_sample_bridgestan(const char*, const char*, PRINT_CALLBACK, unsigned int, const char*,
+                                           WN_REFERENCE_SAMPLING_PARAMS) {
+  (void)num_chains, (void)seed, (void)id, (void)init_radius, (void)init_inv_metric, (void)min_warmup_iter;
+  (void)max_warmup_iter, (void)min_sampling_iter, (void)max_sampling_iter, (void)max_trajectory_doublings;
+  (void)max_step_halvings, (void)min_micro_steps, (void)max_hamiltonian_error, (void)step_size_converge_tol;
+  (void)mass_converge_tol, (void)rhat_converge_tol, (void)mass_init_count, (void)mass_additive_smoothing;
+  (void)max_macro_steps_target, (void)step_size_init, (void)step_accept_rate_target, (void)step_learning_rate;
+  (void)step_gradient_decay, (void)step_sq_gradient_decay, (void)step_stabilization, (void)step_learn_rate_decay;
+  (void)save_warmup, (void)out, (void)out_size, (void)final_lengths, (void)stepsize_out, (void)inv_metric_out;
+  (void)refresh, (void)print;
+  return refuse_host_model("walnutpie_sample_bridgestan", err);
+}
+extern "C" char walnutpie_separator_char(void) { return '\x1C'; }  // walnutpy.cpp:224-225 (ASCII file separator)
 
 extern "C" int walnutpie_sample_device(WN_SAMPLE_PARAMS) {
   return sample_device_impl(false, nullptr, nullptr, WN_SAMPLE_ARGS);

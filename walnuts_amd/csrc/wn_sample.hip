@@ -35,6 +35,10 @@
 #include <string>
 #include <vector>
 
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include "../../include/walnuts_hip.h"
 #include "wn_refstream.h"
 
@@ -169,6 +173,60 @@ struct PinnedRange {
   }
 };
 
+// A caller's fresh buffer (numpy.empty: 16 GiB at the headline size) has no pages yet: the device-to-host copies then
+// take every first-touch fault on the runtime's one staging thread -- 11.5 GB/s into fresh memory against 21.6 GB/s
+// into touched memory on the GPU box (tests/gpu_probes/d2h_probe.hip).  A few helper threads populate the range with
+// madvise(MADV_POPULATE_WRITE) -- which faults pages in WITHOUT changing their content, so it can run beside the
+// copies and beside whatever the caller keeps in rows this call never writes -- while the engine is created and the
+// warmup runs.  Best effort: an older kernel (EINVAL) or an odd mapping simply leaves the faults to the copies.
+// Measured in fresh processes, 65 536 x 1 024, 20 + 32 iterations, 16 GiB of draws (profiles/r04/prefault_ab.txt):
+// the call takes 0.80-0.89 s with the helpers (8 threads, 256 MiB per madvise) against 1.09 s without (2.05 s for a
+// second call of the same process); smaller slices lose the gain (2 MiB: 1.06 s).
+class Prefault {
+ public:
+  Prefault(void* ptr, size_t bytes) {
+#if defined(MADV_POPULATE_WRITE) || defined(__linux__)
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+    const size_t page = static_cast<size_t>(sysconf(_SC_PAGESIZE));
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(ptr) + page - 1) / page * page;
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(ptr) + bytes) / page * page;
+    if (ptr == nullptr || hi <= lo || hi - lo < (size_t{64} << 20)) return;
+    if (const char* env = std::getenv("WALNUTS_AMD_NO_PREFAULT"))
+      if (env[0] == '1') return;
+    cpu_set_t set;
+    int cores = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 1;
+    int n = std::max(1, std::min(8, cores / 2));
+    if (const char* env = std::getenv("WALNUTS_AMD_PREFAULT_THREADS")) n = std::max(1, std::atoi(env));
+    const size_t pages = (hi - lo) / page;
+    for (int t = 0; t < n; ++t) {
+      const uintptr_t a = lo + pages * static_cast<size_t>(t) / static_cast<size_t>(n) * page;
+      const uintptr_t b = lo + pages * static_cast<size_t>(t + 1) / static_cast<size_t>(n) * page;
+      workers_.emplace_back([a, b, this] {
+        // in slices, so that a call that ends early (an error, Ctrl-C) does not wait for gigabytes of faults
+        uintptr_t slice = uintptr_t{256} << 20;
+        if (const char* env = std::getenv("WALNUTS_AMD_PREFAULT_SLICE_KB")) slice = static_cast<uintptr_t>(std::atoll(env)) << 10;
+        for (uintptr_t p = a; p < b && !stop_.load(std::memory_order_relaxed); p += slice)
+          if (madvise(reinterpret_cast<void*>(p), static_cast<size_t>(std::min(slice, b - p)), MADV_POPULATE_WRITE) != 0) return;
+      });
+    }
+#else
+    (void)ptr, (void)bytes;
+#endif
+  }
+  Prefault(const Prefault&) = delete;
+  Prefault& operator=(const Prefault&) = delete;
+  ~Prefault() {  // the helpers never outlive the call: the caller may free the buffer right after it
+    stop_.store(true, std::memory_order_relaxed);
+    for (auto& w : workers_) w.join();
+  }
+
+ private:
+  std::vector<std::thread> workers_;
+  std::atomic<bool> stop_{false};
+};
+
 // The draw sink (handlers.hpp:63-116 writes every draw straight into the caller's buffer, whatever its size).
 // The device writes the draws of up to `span` consecutive iterations of all chains into one of two staging blocks
 // [C][span][D]; a full block goes to the caller's out[C][rows][D] as ONE strided copy on a second stream while the
@@ -198,16 +256,23 @@ class DrawSink {
       if (span_ == 1) throw std::runtime_error("cannot allocate the device draw staging buffer");
       span_ = (span_ + 1) / 2;
     }
-    for (int b = 0; b < 2; ++b) {
-      drained_[b].create();
+    // A block can leave as `lanes_` strided copies of contiguous chain ranges on as many streams
+    // (WALNUTS_AMD_COPY_STREAMS).  Measured with the buffer pre-faulted (Prefault above), 16 GiB: 0.73-0.78 s on one
+    // stream, 0.75-0.81 on two, 0.70-0.82 on four, 0.75-0.80 on eight -- the runtime's staging of a pageable
+    // destination is not what more streams speed up -- so one stream is the default.
+    lanes_ = 1;
+    if (const char* env = std::getenv("WALNUTS_AMD_COPY_STREAMS")) lanes_ = std::atoi(env);
+    lanes_ = std::max(1, std::min({lanes_, kMaxLanes, static_cast<int>(C_)}));
+    for (int l = 0; l < lanes_; ++l) {
+      copy_[l].create();
+      for (int b = 0; b < 2; ++b) drained_[b][l].create();
     }
-    copy_.create();
   }
   size_t stride() const { return span_ * D_; }  // doubles between two chains' rows in a staging block
   // where the next iteration's draws go (device pointer of chain 0's row)
   double* next_row() {
     if (fill_ == 0 && busy_[cur_]) {  // the block still feeds a copy: the kernels must not overwrite it yet
-      WN_CALL(wn_engine_wait_event(engine_, drained_[cur_].e, &call_err_));
+      for (int l = 0; l < lanes_; ++l) WN_CALL(wn_engine_wait_event(engine_, drained_[cur_][l].e, &call_err_));
       busy_[cur_] = false;
     }
     return block_[cur_].p + fill_ * D_;
@@ -224,17 +289,24 @@ class DrawSink {
   // everything written so far is in the caller's buffer when this returns
   void finish() {
     if (fill_ > 0) flush();
-    if (copy_.s && hipStreamSynchronize(copy_.s) != hipSuccess) throw std::runtime_error("copying draws to the host failed");
+    for (int l = 0; l < lanes_; ++l)
+      if (copy_[l].s && hipStreamSynchronize(copy_[l].s) != hipSuccess)
+        throw std::runtime_error("copying draws to the host failed");
   }
 
  private:
   void flush() {
     const size_t first = written_ - fill_;
-    WN_CALL(wn_engine_release_stream(engine_, copy_.s, &call_err_));  // the copy runs behind every launch made so far
-    if (hipMemcpy2DAsync(out_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_].p, span_ * D_ * sizeof(double),
-                         fill_ * D_ * sizeof(double), C_, hipMemcpyDeviceToHost, copy_.s) != hipSuccess ||
-        hipEventRecord(drained_[cur_].e, copy_.s) != hipSuccess)
-      throw std::runtime_error("copying draws to the host failed");
+    for (int l = 0; l < lanes_; ++l) {
+      const size_t c0 = C_ * static_cast<size_t>(l) / static_cast<size_t>(lanes_);
+      const size_t c1 = C_ * static_cast<size_t>(l + 1) / static_cast<size_t>(lanes_);
+      WN_CALL(wn_engine_release_stream(engine_, copy_[l].s, &call_err_));  // the copy runs behind every launch made so far
+      if (hipMemcpy2DAsync(out_ + c0 * rows_ * D_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_].p + c0 * span_ * D_,
+                           span_ * D_ * sizeof(double), fill_ * D_ * sizeof(double), c1 - c0, hipMemcpyDeviceToHost,
+                           copy_[l].s) != hipSuccess ||
+          hipEventRecord(drained_[cur_][l].e, copy_[l].s) != hipSuccess)
+        throw std::runtime_error("copying draws to the host failed");
+    }
     busy_[cur_] = true;
     cur_ ^= 1;
     fill_ = 0;
@@ -242,9 +314,11 @@ class DrawSink {
   size_t C_, rows_, D_;
   double* out_;
   wn_engine* engine_;
-  Stream copy_;
+  static constexpr int kMaxLanes = 8;
+  int lanes_ = 1;
+  Stream copy_[kMaxLanes];
   DevBlock block_[2];
-  Event drained_[2];
+  Event drained_[2][kMaxLanes];
   bool busy_[2] = {false, false};
   size_t span_ = 1, fill_ = 0, written_ = 0;
   int cur_ = 0;
@@ -566,6 +640,8 @@ static int sample_device_impl(
     if (shard != nullptr) cfg.device = shard->device;
 
     PhaseTimer timer;
+    // (declared first of the call's resources: destroyed last, after the copies into the buffer have been waited for)
+    Prefault populate(out, num_chains * draws_offset * sizeof(double));
     EngineGuard guard;
     WN_CALL(wn_engine_create(&guard.e, model, num_params, model_params, num_chains, &cfg, &call_err_));
     wn_engine* e = guard.e;

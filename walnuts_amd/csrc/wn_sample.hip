@@ -184,7 +184,9 @@ struct PinnedRange {
 // second call of the same process); smaller slices lose the gain (2 MiB: 1.06 s).
 class Prefault {
  public:
-  Prefault(void* ptr, size_t bytes) {
+  // `share`: the fraction of the process's helper budget this call may use (a shard of a multi-device call: its
+  // share of the chains)
+  Prefault(void* ptr, size_t bytes, double share = 1.0) {
 #if defined(MADV_POPULATE_WRITE) || defined(__linux__)
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
@@ -197,7 +199,7 @@ class Prefault {
       if (env[0] == '1') return;
     cpu_set_t set;
     int cores = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 1;
-    int n = std::max(1, std::min(8, cores / 2));
+    int n = std::max(1, static_cast<int>(std::min(8, cores / 2) * share + 0.5));
     if (const char* env = std::getenv("WALNUTS_AMD_PREFAULT_THREADS")) n = std::max(1, std::atoi(env));
     const size_t pages = (hi - lo) / page;
     for (int t = 0; t < n; ++t) {
@@ -641,7 +643,8 @@ static int sample_device_impl(
 
     PhaseTimer timer;
     // (declared first of the call's resources: destroyed last, after the copies into the buffer have been waited for)
-    Prefault populate(out, num_chains * draws_offset * sizeof(double));
+    Prefault populate(out, num_chains * draws_offset * sizeof(double),
+                      static_cast<double>(num_chains) / static_cast<double>(std::max<size_t>(1, total_chains)));
     EngineGuard guard;
     WN_CALL(wn_engine_create(&guard.e, model, num_params, model_params, num_chains, &cfg, &call_err_));
     wn_engine* e = guard.e;

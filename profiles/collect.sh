@@ -32,7 +32,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/be
 python3 $ROOT/profiles/summarize.py $R $(find $OUT/headline_trace -name "*results.db" | head -1) > $OUT/kernel_trace_headline.txt 2>&1
 rm -rf $OUT/headline_trace
 # the whole drop-in call, phase by phase (WALNUTS_AMD_TIMING), and a longer run of the randomised parity campaign
-(cd $ROOT && timeout 900 python3 tests/gpu_probes/sample_device_e2e.py > $OUT/sample_device_e2e.txt 2>&1)
+(cd $ROOT && WALNUTS_AMD_TIMING=1 timeout 900 python3 tests/gpu_probes/sample_device_e2e.py > $OUT/sample_device_e2e.txt 2>&1)
 (cd $ROOT && timeout 600 python3 tests/gpu_probes/fuzz_parity.py --seconds 240 --seed 404 > $OUT/fuzz_parity.txt 2>&1; tail -3 $OUT/fuzz_parity.txt)
 for f in $OUT/bench_*.json; do python3 -c "
 import json,sys

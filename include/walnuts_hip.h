@@ -164,6 +164,22 @@ WALNUTS_HIP_EXPORT int walnutpie_sample_device_multi(
     int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
     const int* devices, int num_devices, WalnutpyError** err);
 
+/* ... with the sampling draws kept on the devices (walnutpie_sample_device_resident's contract for `out`, `thin` and
+ * `chains_out`): every shard keeps its draws on its own device while it samples; at the end the shards' blocks --
+ * contiguous slabs of the chain-major [C][S][D] layout -- are gathered on devices[0] with one peer-to-peer copy per
+ * shard (hipMemcpyPeerAsync: each over its own xGMI link, all at once) and handed back as ONE wn_chains there. */
+WALNUTS_HIP_EXPORT int walnutpie_sample_device_multi_resident(
+    int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
+    unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
+    int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
+    int max_step_halvings, int min_micro_steps, double max_hamiltonian_error, double step_size_converge_tol,
+    double mass_converge_tol, double rhat_converge_tol, double mass_init_count, double mass_additive_smoothing,
+    double max_macro_steps_target, double step_size_init, double step_accept_rate_target,
+    double step_learning_rate, double step_gradient_decay, double step_sq_gradient_decay,
+    double step_stabilization, double step_learn_rate_decay, bool save_warmup, double* out, size_t out_size,
+    int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
+    const int* devices, int num_devices, int thin, wn_chains** chains_out, WalnutpyError** err);
+
 /* ---- batched engine ------------------------------------------------------------- */
 typedef struct wn_engine wn_engine;
 
@@ -409,6 +425,9 @@ WALNUTS_HIP_EXPORT size_t wn_chains_num_chains(const wn_chains* chains);
 WALNUTS_HIP_EXPORT size_t wn_chains_dims(const wn_chains* chains);
 WALNUTS_HIP_EXPORT size_t wn_chains_num_draws(const wn_chains* chains);
 WALNUTS_HIP_EXPORT size_t wn_chains_min_chain_size(const wn_chains* chains);
+/* where the draws are: chain 0's first draw on device wn_chains_device() (chain c's n-th draw: see wn_chains_view) */
+WALNUTS_HIP_EXPORT const double* wn_chains_device_draws(const wn_chains* chains);
+WALNUTS_HIP_EXPORT int wn_chains_device(const wn_chains* chains);
 
 WALNUTS_HIP_EXPORT int wn_summary_mean(wn_chains* chains, double* out /*[D]*/, WalnutpyError** err);
 WALNUTS_HIP_EXPORT int wn_summary_sample_variance(wn_chains* chains, double* out /*[D]*/, WalnutpyError** err);

@@ -360,6 +360,10 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind
   std::memcpy(d, s, n);
   return hipSuccess;
 }
+inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) {
+  std::memcpy(d, s, n);
+  return hipSuccess;
+}
 inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height,
                                    hipMemcpyKind, hipStream_t) {
   for (size_t r = 0; r < height; ++r)

@@ -110,6 +110,25 @@ def test_resident_draws_thinned_mode_on_the_device(oracle):
     assert np.array_equal(chains0.mean(), sp.wnso.mean(sub))
 
 
+def test_multi_device_resident_on_one_gpu_gathers_the_shards_draws():
+    """walnutpie_sample_device_multi_resident with devices = {0, 0, 0} on the one GPU there is: three shards keep their
+    draws in their own blocks, the blocks are gathered by hipMemcpyPeerAsync into one wn_chains -- thinned rows and
+    on-device summaries equal the one-engine resident call's bit for bit."""
+    C, D, S = 3000, 256, 16
+    kw = dict(num_params=D, num_chains=C, seed=9, min_warmup_iter=6, max_warmup_iter=6, min_sampling_iter=S,
+              max_sampling_iter=S, keep_on_device=True, thin=4)
+    one, chains_one = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    many, chains = wa.walnuts_device(wa.MODEL_STD_NORMAL, devices=[0, 0, 0], **kw)
+    assert chains.num_chains() == C and chains.num_draws() == C * S
+    for c in (0, 999, 1000, 1999, 2000, C - 1):
+        assert np.array_equal(np.asarray(many[c]), np.asarray(one[c])), c
+        assert many[c].warmup.stepsize == one[c].warmup.stepsize
+    assert np.array_equal(chains.mean(), chains_one.mean())
+    assert np.array_equal(chains.r_hat(), chains_one.r_hat())
+    assert np.array_equal(chains.quantiles([0.1, 0.5]), chains_one.quantiles([0.1, 0.5]))
+    chains.close(), chains_one.close()
+
+
 def test_multi_device_call_on_one_gpu_equals_the_single_engine_call():
     """walnutpie_sample_device_multi with devices = {0, 0} (and {0, 0, 0}: uneven shards): two / three engines on their
     own host threads and streams of the one GPU there is, each writing its slice of the caller's buffers -- the same

@@ -162,3 +162,29 @@ def test_multi_device_controllers_look_at_all_chains(sim):
     tight = _run(sim, devices=[0, 0], **{**kw, "rhat_converge_tol": 1.0 + 1e-12, "step_size_converge_tol": 1e-12,
                                          "mass_converge_tol": 1e-12, "max_warmup_iter": 10, "max_sampling_iter": 9})
     assert [len(a) for a in tight] == [9] * 6 and [len(a.warmup.warmup_draws) for a in tight] == [10] * 6
+
+
+@pytest.mark.timeout(900)
+def test_multi_device_resident_gathers_the_shards_draws(sim, oracle):
+    """walnutpie_sample_device_multi_resident with devices = {0, 0} / {0, 0, 0}: every shard keeps its sampling draws
+    on its device, the blocks are gathered into ONE wn_chains (peer copies) -- the thinned rows, the warmup rows and the
+    on-device summaries over the gathered block equal the one-engine resident call's, early stop included."""
+    kw = dict(num_chains=5, save_inv_metric=True, keep_on_device=True, thin=2, min_sampling_iter=4, max_sampling_iter=9,
+              rhat_converge_tol=1e6)
+    one, chains_one = _run(sim, **kw)
+    assert [len(a) for a in one] == [2] * 5 and chains_one.num_draws() == 5 * 4
+    for devices in ([0, 0], [0, 0, 0]):
+        many, chains = _run(sim, devices=devices, **kw)
+        assert chains.num_chains() == 5 and chains.num_draws() == 5 * 4
+        for a, b in zip(one, many):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+            assert np.array_equal(a.warmup.warmup_draws, b.warmup.warmup_draws)
+            assert a.warmup.stepsize == b.warmup.stepsize
+        assert np.array_equal(chains.mean(), chains_one.mean())
+        assert np.array_equal(chains.r_hat(), chains_one.r_hat())
+        assert np.array_equal(chains.effective_sample_size(), chains_one.effective_sample_size())
+        chains.close()
+    streamed = _run(sim, num_chains=5, min_sampling_iter=4, max_sampling_iter=9, rhat_converge_tol=1e6)
+    assert np.array_equal(chains_one.mean(), sp.wnso.mean([np.asarray(s) for s in streamed]))
+    with pytest.raises(ValueError, match="max_sampling_iter"):
+        _run(sim, devices=[0, 0], num_chains=5, keep_on_device=True, thin=1, min_sampling_iter=0, max_sampling_iter=0)

@@ -78,6 +78,10 @@ SYMBOLS = [
      [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
       _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
       _dp, _dp, _i32, PRINT_CALLBACK, C.POINTER(C.c_int), _i32, _errpp]),
+    ("walnutpie_sample_device_multi_resident", _i32,
+     [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
+      _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
+      _dp, _dp, _i32, PRINT_CALLBACK, C.POINTER(C.c_int), _i32, _i32, C.POINTER(_vp), _errpp]),
     ("wn_internal_reference_normals", None, [C.c_uint, C.c_uint, _sz, _sz, _i32, _dbl, _dp]),
     ("walnutpie_ess", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("walnutpie_r_hat", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
@@ -152,6 +156,8 @@ SYMBOLS = [
     ("wn_chains_dims", _sz, [_vp]),
     ("wn_chains_num_draws", _sz, [_vp]),
     ("wn_chains_min_chain_size", _sz, [_vp]),
+    ("wn_chains_device_draws", _vp, [_vp]),
+    ("wn_chains_device", _i32, [_vp]),
     ("wn_summary_mean", _i32, [_vp, _dp, _errpp]),
     ("wn_summary_sample_variance", _i32, [_vp, _dp, _errpp]),
     ("wn_summary_sample_standard_deviation", _i32, [_vp, _dp, _errpp]),

@@ -995,10 +995,28 @@ extern "C" int walnutpie_sample_device_resident(WN_SAMPLE_PARAMS_NOERR, int thin
 // (an ordinal may repeat: two shards on one device overlap each other's launch tails), contiguous shards of the global
 // chain ids, every shard writing its own slice of the caller's buffers.  Results do not depend on the sharding: the
 // random streams are keyed by global chain id, the controllers look at all chains (Coordinator).
-extern "C" int walnutpie_sample_device_multi(WN_SAMPLE_PARAMS_NOERR, const int* devices, int num_devices,
-                                             WalnutpyError** err) {
+// `resident` (walnutpie_sample_device_multi_resident): every shard keeps its sampling draws in a block on ITS device;
+// when all shards are done the blocks -- contiguous slabs of the chain-major [C][S][D] layout -- are gathered into one
+// block on devices[0], one peer-to-peer copy per shard (hipMemcpyPeerAsync: over the shard's own xGMI link, all
+// inbound copies at once), and handed over as one wn_chains for the wn_summary_* functions.
+static int sample_multi_impl(const ResidentRequest* resident, WN_SAMPLE_PARAMS_NOERR, const int* devices,
+                             int num_devices, WalnutpyError** err) {
+  std::vector<wn_chains*> shard_chains(static_cast<size_t>(std::max(num_devices, 0)), nullptr);
+  struct ChainsGuard {
+    std::vector<wn_chains*>& v;
+    ~ChainsGuard() {
+      for (auto* c : v)
+        if (c != nullptr) wn_chains_destroy(c);
+    }
+  } chains_guard{shard_chains};
   try {
     if (devices == nullptr || num_devices < 1) throw std::invalid_argument("devices must name at least one device");
+    if (resident != nullptr) {
+      if (resident->chains_out == nullptr) throw std::invalid_argument("chains_out must not be null");
+      if (resident->thin < 0) throw std::invalid_argument("thin must be >= 0");
+      if (max_sampling_iter < 1) throw std::invalid_argument("resident draws need max_sampling_iter >= 1");
+      *resident->chains_out = nullptr;
+    }
     if (num_chains < static_cast<size_t>(num_devices)) throw std::invalid_argument("fewer chains than devices");
     if (num_params < 1) throw std::invalid_argument("num_params must be in {1, 2, ... }");
     if (max_sampling_iter < 0 || max_warmup_iter < 0) throw std::invalid_argument("iteration counts must be >= 0");
@@ -1007,7 +1025,10 @@ extern "C" int walnutpie_sample_device_multi(WN_SAMPLE_PARAMS_NOERR, const int* 
     for (int s = 0; s < num_devices; ++s)
       if (devices[s] < 0 || devices[s] >= visible) throw std::invalid_argument("device ordinal out of range");
     const size_t D = static_cast<size_t>(num_params);
-    const size_t rows = static_cast<size_t>(max_sampling_iter) + (save_warmup ? static_cast<size_t>(max_warmup_iter) : 0);
+    // (the caller's rows per chain: every sampling draw, or -- resident -- only every thin-th of them)
+    const size_t thin = resident != nullptr ? static_cast<size_t>(resident->thin) : 1;
+    const size_t samp_rows = thin == 0 ? 0 : (static_cast<size_t>(max_sampling_iter) + thin - 1) / thin;
+    const size_t rows = samp_rows + (save_warmup ? static_cast<size_t>(max_warmup_iter) : 0);
     if (rows > 0 && out == nullptr) throw std::invalid_argument("out must not be null");
     if (out_size < num_chains * rows * D) {  // walnutpy.cpp:153-160
       std::stringstream ss;
@@ -1039,8 +1060,9 @@ extern "C" int walnutpie_sample_device_multi(WN_SAMPLE_PARAMS_NOERR, const int* 
         double* out_s = out == nullptr ? nullptr : out + ctx.chain_begin * rows * D;
         double* step_s = stepsize_out == nullptr ? nullptr : stepsize_out + ctx.chain_begin;
         double* metric_out_s = inv_metric_out == nullptr ? nullptr : inv_metric_out + ctx.chain_begin * D;
+        const ResidentRequest shard_req{resident != nullptr ? resident->thin : 0, &shard_chains[static_cast<size_t>(s)]};
         rcs[s] = sample_device_impl(
-            false, nullptr, &ctx, model, model_params, num_params, inits_s, count, seed, id, init_radius, metric_s,
+            false, resident != nullptr ? &shard_req : nullptr, &ctx, model, model_params, num_params, inits_s, count, seed, id, init_radius, metric_s,
             min_warmup_iter, max_warmup_iter, min_sampling_iter, max_sampling_iter, max_trajectory_doublings,
             max_step_halvings, min_micro_steps, max_hamiltonian_error, step_size_converge_tol, mass_converge_tol,
             rhat_converge_tol, mass_init_count, mass_additive_smoothing, max_macro_steps_target, step_size_init,
@@ -1067,6 +1089,34 @@ extern "C" int walnutpie_sample_device_multi(WN_SAMPLE_PARAMS_NOERR, const int* 
     if (rc == 0)
       for (int s = 0; s < num_devices; ++s)
         if (rcs[s] != 0) throw std::runtime_error("a shard ended without reporting its error");
+    if (rc == 0 && resident != nullptr) {
+      // gather: shard s's [count_s][S][D] block is rows [begin_s, begin_s + count_s) of the whole [C][S][D] block
+      const size_t S = static_cast<size_t>(max_sampling_iter);
+      const int dev0 = devices[0];
+      if (hipSetDevice(dev0) != hipSuccess) throw std::runtime_error("cannot select the device");
+      DevBlock whole;
+      if (!whole.alloc(num_chains * S * D)) throw std::runtime_error("cannot allocate the gathered draw block");
+      Stream gather;
+      gather.create();
+      size_t first = 0;
+      for (int s = 0; s < num_devices; ++s) {
+        const size_t count = wn_chains_num_chains(shard_chains[static_cast<size_t>(s)]);
+        if (hipMemcpyPeerAsync(whole.p + first * S * D, dev0, wn_chains_device_draws(shard_chains[static_cast<size_t>(s)]),
+                               devices[s], count * S * D * sizeof(double), gather.s) != hipSuccess)
+          throw std::runtime_error("gathering the shards' draws failed");
+        first += count;
+      }
+      if (hipStreamSynchronize(gather.s) != hipSuccess) throw std::runtime_error("gathering the shards' draws failed");
+      std::vector<int64_t> lengths(num_chains);
+      for (size_t c = 0; c < num_chains; ++c) lengths[c] = final_lengths[num_chains + c];
+      double* block = whole.release();
+      WalnutpyError* adopt_err = nullptr;
+      if (wn_chains_adopt(resident->chains_out, block, num_chains, S, D, static_cast<int64_t>(S * D), lengths.data(), dev0,
+                          &adopt_err) != 0) {
+        (void)hipFree(block);
+        rethrow(adopt_err);
+      }
+    }
     return rc;
   } catch (const std::invalid_argument& ex) {
     if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error(ex.what(), config));
@@ -1076,6 +1126,22 @@ extern "C" int walnutpie_sample_device_multi(WN_SAMPLE_PARAMS_NOERR, const int* 
     if (err) *err = static_cast<WalnutpyError*>(wn_internal_make_error("Unknown error", generic));
   }
   return -1;
+}
+#define WN_SAMPLE_ARGS_NOERR                                                                                       \
+  model, model_params, num_params, inits, num_chains, seed, id, init_radius, init_inv_metric, min_warmup_iter,     \
+      max_warmup_iter, min_sampling_iter, max_sampling_iter, max_trajectory_doublings, max_step_halvings,          \
+      min_micro_steps, max_hamiltonian_error, step_size_converge_tol, mass_converge_tol, rhat_converge_tol,        \
+      mass_init_count, mass_additive_smoothing, max_macro_steps_target, step_size_init, step_accept_rate_target,  \
+      step_learning_rate, step_gradient_decay, step_sq_gradient_decay, step_stabilization, step_learn_rate_decay, \
+      save_warmup, out, out_size, final_lengths, stepsize_out, inv_metric_out, refresh, print
+extern "C" int walnutpie_sample_device_multi(WN_SAMPLE_PARAMS_NOERR, const int* devices, int num_devices,
+                                             WalnutpyError** err) {
+  return sample_multi_impl(nullptr, WN_SAMPLE_ARGS_NOERR, devices, num_devices, err);
+}
+extern "C" int walnutpie_sample_device_multi_resident(WN_SAMPLE_PARAMS_NOERR, const int* devices, int num_devices, int thin,
+                                                      wn_chains** chains_out, WalnutpyError** err) {
+  const ResidentRequest req{thin, chains_out};
+  return sample_multi_impl(&req, WN_SAMPLE_ARGS_NOERR, devices, num_devices, err);
 }
 
 // ---- walnutpie_ess / walnutpie_r_hat / walnutpie_mcse (walnutpy.cpp:333-369) ----------------------------------

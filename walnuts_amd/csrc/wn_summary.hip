@@ -771,6 +771,8 @@ size_t wn_chains_num_chains(const wn_chains* ch) { return ch->C; }
 size_t wn_chains_dims(const wn_chains* ch) { return ch->D; }
 size_t wn_chains_num_draws(const wn_chains* ch) { return static_cast<size_t>(ch->N); }
 size_t wn_chains_min_chain_size(const wn_chains* ch) { return static_cast<size_t>(ch->min_len); }
+const double* wn_chains_device_draws(const wn_chains* ch) { return ch->x; }
+int wn_chains_device(const wn_chains* ch) { return ch->device; }
 
 int wn_summary_mean(wn_chains* ch, double* out, WalnutpyError** err) {
   return guarded(err, [&] {

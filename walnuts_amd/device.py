@@ -139,10 +139,12 @@ def walnuts_device(
     ``devices=[0, 1, ...]`` (walnutpie_sample_device_multi): the chains are sharded over these HIP devices of the node,
     one host thread + engine + stream each, every shard writing its own slice of the output; same result as the
     one-device call (random streams keyed by global chain id, controllers reduced over all shards).  An ordinal may
-    repeat: ``devices=[0, 0]`` runs two half-size engines on one device, each filling the other's launch tail."""
+    repeat: ``devices=[0, 0]`` runs two half-size engines on one device, each filling the other's launch tail.  With
+    ``keep_on_device=True`` (walnutpie_sample_device_multi_resident) every shard keeps its draws on its own device and
+    the blocks are gathered on ``devices[0]`` by peer-to-peer copies at the end: one ``MarkovChains`` handle there."""
     lib = _ffi.load_library(lib_path)
-    if devices is not None and (keep_on_device or reference_streams):
-        raise ValueError("devices is not available with keep_on_device or reference_streams")
+    if devices is not None and reference_streams:
+        raise ValueError("devices is not available with reference_streams")
     if keep_on_device and reference_streams:
         raise ValueError("keep_on_device is not available with reference_streams")
     if thin < 0:
@@ -198,6 +200,9 @@ def walnuts_device(
         dev = (C.c_int * len(devices))(*[int(d) for d in devices])
         entry = lib.walnutpie_sample_device_multi
         tail = (refresh, cb, dev, len(devices), C.byref(err))
+        if keep_on_device:   # every shard's draws stay on its device, gathered on devices[0] at the end
+            entry = lib.walnutpie_sample_device_multi_resident
+            tail = (refresh, cb, dev, len(devices), thin, C.byref(chains_handle), C.byref(err))
     import os
     import sys
     import time

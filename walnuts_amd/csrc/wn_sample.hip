@@ -180,8 +180,8 @@ struct PinnedRange {
 // copies and beside whatever the caller keeps in rows this call never writes -- while the engine is created and the
 // warmup runs.  Best effort: an older kernel (EINVAL) or an odd mapping simply leaves the faults to the copies.
 // Measured in fresh processes, 65 536 x 1 024, 20 + 32 iterations, 16 GiB of draws (profiles/r04/prefault_ab.txt):
-// the call takes 0.80-0.89 s with the helpers (8 threads, 256 MiB per madvise) against 1.09 s without (2.05 s for a
-// second call of the same process); smaller slices lose the gain (2 MiB: 1.06 s).
+// the call takes 0.70-0.76 s with the helpers (8 threads, 256 MiB per madvise; started after the device allocations)
+// against 1.07-2.05 s without; smaller slices lose the gain (2 MiB: 1.06 s).
 class Prefault {
  public:
   // `share`: the fraction of the process's helper budget this call may use (a shard of a multi-device call: its
@@ -642,9 +642,9 @@ static int sample_device_impl(
     if (shard != nullptr) cfg.device = shard->device;
 
     PhaseTimer timer;
-    // (declared first of the call's resources: destroyed last, after the copies into the buffer have been waited for)
-    Prefault populate(out, num_chains * draws_offset * sizeof(double),
-                      static_cast<double>(num_chains) / static_cast<double>(std::max<size_t>(1, total_chains)));
+    // (declared first of the call's resources: destroyed last, after the copies into the buffer have been waited for;
+    // started once the device allocations are done -- see below)
+    std::unique_ptr<Prefault> populate;
     EngineGuard guard;
     WN_CALL(wn_engine_create(&guard.e, model, num_params, model_params, num_chains, &cfg, &call_err_));
     wn_engine* e = guard.e;
@@ -763,6 +763,11 @@ static int sample_device_impl(
     DrawSink& sink = *sink_holder;
     RunAhead pace(compute);
     timer.mark("preparation thread joined (output registered, draw blocks allocated)");
+    // The helpers start HERE, not at the call's entry: page population and hipMalloc both go through the process's
+    // address-space lock, and with the helpers running the engine's and the staging blocks' allocations took 0.9 s
+    // instead of 0.03 s (profiles/r04/prefault_ab.txt).  From here on the call only launches kernels and copies.
+    populate = std::make_unique<Prefault>(out, num_chains * draws_offset * sizeof(double),
+                                          static_cast<double>(num_chains) / static_cast<double>(std::max<size_t>(1, total_chains)));
     // (progress lines: shard 0 speaks for all chains)
     Printer printer{shard != nullptr && shard->shard != 0 ? nullptr : print, static_cast<size_t>(refresh)};
     // Consecutive iterations between two looks of a controller go out as ONE launch (wn_engine_*_steps: the workgroup

@@ -56,8 +56,11 @@ int main(int argc, char** argv) {
     OK(hipHostMalloc(&pin[i], chunk_doubles * sizeof(double), hipHostMallocDefault));
     OK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
   }
-  for (int nt : {4, 8, threads}) {
+  for (int pass = 0; pass < 6; ++pass) {
+    const int nt = pass % 3 == 0 ? 4 : pass % 3 == 1 ? 8 : threads;
+    const bool touched = pass >= 3;  // (b') the same into memory that has its pages already
     double* out = static_cast<double*>(std::malloc(C * rows * D * sizeof(double)));
+    if (touched) std::memset(out, 0, C * rows * D * sizeof(double));
     const double t0 = now();
     size_t job = 0;
     std::vector<std::thread> scatter[ring];
@@ -80,8 +83,8 @@ int main(int argc, char** argv) {
     for (auto& v : scatter)
       for (auto& t : v) t.join();
     const double dt = now() - t0;
-    std::printf("pinned ring of %d x %zu MiB + %d scatter threads into fresh pageable memory: %.2f s, %.1f GB/s\n", ring,
-                chunk_doubles * 8 >> 20, nt, dt, C * rows * D * 8 / dt / 1e9);
+    std::printf("pinned ring of %d x %zu MiB + %d scatter threads into %s pageable memory: %.2f s, %.1f GB/s\n", ring,
+                chunk_doubles * 8 >> 20, nt, touched ? "pre-touched" : "fresh", dt, C * rows * D * 8 / dt / 1e9);
     std::free(out);
   }
   return 0;

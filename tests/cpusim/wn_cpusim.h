@@ -374,6 +374,15 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
   std::memset(d, v, n);
   return hipSuccess;
 }
+constexpr unsigned hipHostMallocDefault = 0;
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) {
+  *p = std::aligned_alloc(64, ((n + 63) / 64) * 64);
+  return *p ? hipSuccess : 1;
+}
+inline hipError_t hipHostFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
 constexpr unsigned hipHostRegisterDefault = 0;
 inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 inline hipError_t hipHostUnregister(void*) { return hipSuccess; }

@@ -188,3 +188,35 @@ def test_multi_device_resident_gathers_the_shards_draws(sim, oracle):
     assert np.array_equal(chains_one.mean(), sp.wnso.mean([np.asarray(s) for s in streamed]))
     with pytest.raises(ValueError, match="max_sampling_iter"):
         _run(sim, devices=[0, 0], num_chains=5, keep_on_device=True, thin=1, min_sampling_iter=0, max_sampling_iter=0)
+
+
+@pytest.mark.timeout(900)
+def test_pinned_ring_path_of_the_draw_sink(sim, monkeypatch):
+    """WALNUTS_AMD_BOUNCE=1 forces the large-output path of the draw sink at test sizes: the staging blocks leave through
+    a ring of pinned chunks, a dispatcher thread and scatter workers instead of one strided copy.  Same rows in the
+    caller's buffer -- whole blocks, partial last blocks, one-iteration blocks, early stops, several shards -- and a
+    call that ends by Ctrl-C shuts the threads down and leaves the library usable."""
+    whole = _run(sim, num_chains=5)
+    early_kw = dict(num_chains=5, min_warmup_iter=5, max_warmup_iter=15, step_size_converge_tol=1e6, mass_converge_tol=1e6,
+                    min_sampling_iter=4, max_sampling_iter=30, rhat_converge_tol=1e6)
+    early = _run(sim, **early_kw)
+    monkeypatch.setenv("WALNUTS_AMD_BOUNCE", "1")
+    for budget in (None, 5 * 5 * 8 * 3 * 2, 1):
+        if budget is not None:
+            monkeypatch.setenv("WALNUTS_AMD_DRAW_STAGING_BYTES", str(budget))
+        for kw, want in ((dict(num_chains=5), whole), (early_kw, early), (dict(num_chains=5, devices=[0, 0]), whole)):
+            got = _run(sim, **kw)
+            for a, b in zip(want, got):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), (budget, kw)
+                assert np.array_equal(a.warmup.warmup_draws, b.warmup.warmup_draws), (budget, kw)
+    seen = []
+
+    def on_print(text):
+        seen.append(text)
+        if len(seen) == 2:
+            os.kill(os.getpid(), signal.SIGINT)
+
+    with pytest.raises(KeyboardInterrupt):
+        _run(sim, max_warmup_iter=50, min_warmup_iter=50, refresh=1, print_callback=on_print)
+    again = _run(sim, num_chains=5)
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(whole, again))

@@ -30,6 +30,7 @@
 #include <stdexcept>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -229,18 +230,223 @@ class Prefault {
   std::atomic<bool> stop_{false};
 };
 
+// Device-to-host at the PCIe rate into a PAGEABLE destination.  A copy straight into pageable memory is staged by the
+// runtime on one thread: 21-34 GB/s into populated pages on the GPU boxes.  Here the device writes contiguous chain
+// ranges of a staging block into a small ring of pinned chunks (plain DMA: 53 GB/s) and a few host threads scatter each
+// chunk's rows into the caller's out[C][rows][D] while the next chunk is on its way (tests/gpu_probes/d2h_probe.hip:
+// 16 GiB in 0.32 s against 0.50 s into populated pages).  One dispatcher thread queues the chunk copies -- it is the one
+// that waits for a free chunk, so the sampling loop never does --, the workers wait for a chunk's event and copy its
+// rows, taking the first-touch faults of a fresh buffer in parallel.  The whole call, 65 536 x 1 024, 20 + 32
+// iterations, 16 GiB of draws into a fresh numpy buffer, fresh processes (profiles/r04/prefault_ab.txt): 0.50-0.57 s,
+// against 0.70-0.76 s for one strided copy into a buffer populated by helper threads and 1.07-2.05 s for round 3's
+// plain copy; two workers 0.73-0.86 s, eight no better than four.
+class BounceRing {
+ public:
+  struct Job {
+    const double* block;  // [C][span][D] on the device
+    size_t span, fill, first;  // rows per chain in the block, valid rows, first destination row
+    hipEvent_t drained;        // recorded behind the job's last chunk copy
+    uint64_t ticket;
+  };
+  BounceRing(int device, size_t chains, size_t rows, size_t dim, double* out, size_t span, hipStream_t copy)
+      : device_(device), C_(chains), rows_(rows), D_(dim), out_(out), copy_(copy) {
+    const size_t per_chain = span * D_ * sizeof(double);
+    cc_ = std::max<size_t>(1, std::min(C_, kChunkBytes / std::max<size_t>(1, per_chain)));
+    if (cc_ * per_chain > 4 * kChunkBytes) return;  // one chain's rows alone are too large for a chunk: direct copies
+    for (int k = 0; k < kRing; ++k) {
+      void* p = nullptr;
+      if (hipHostMalloc(&p, cc_ * per_chain, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        release();
+        return;
+      }
+      pin_[k] = static_cast<double*>(p);
+      if (hipEventCreateWithFlags(&ev_[k], hipEventDisableTiming) != hipSuccess) {
+        release();
+        return;
+      }
+    }
+    usable_ = true;
+    dispatcher_ = std::thread([this] { dispatch(); });
+    int nworkers = kWorkers;
+    if (const char* env = std::getenv("WALNUTS_AMD_BOUNCE_WORKERS")) nworkers = std::max(1, std::atoi(env));
+    for (int w = 0; w < nworkers; ++w) workers_.emplace_back([this] { work(); });
+  }
+  BounceRing(const BounceRing&) = delete;
+  BounceRing& operator=(const BounceRing&) = delete;
+  ~BounceRing() {
+    shut_down(true);
+    (void)hipStreamSynchronize(copy_);  // (no chunk is a DMA target any more when it is freed)
+    release();
+  }
+  bool usable() const { return usable_; }
+  // sampling thread: the copy stream has been ordered behind the launches that filled the block
+  uint64_t submit(Job j) {
+    std::unique_lock<std::mutex> lk(mu_);
+    rethrow_locked();
+    j.ticket = ++submitted_;
+    jobs_.push_back(j);
+    cv_.notify_all();
+    return j.ticket;
+  }
+  // sampling thread: the job's `drained` event has been recorded (it can be waited for on a stream now)
+  void wait_recorded(uint64_t ticket) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return recorded_ >= ticket || error_; });
+    rethrow_locked();
+  }
+  // every submitted row is in the caller's buffer when this returns
+  void finish() {
+    shut_down(false);
+    std::unique_lock<std::mutex> lk(mu_);
+    rethrow_locked();
+  }
+
+ private:
+  struct Task {
+    int slot;
+    size_t c0, c1, first, fill;
+  };
+  static constexpr size_t kChunkBytes = size_t{64} << 20;
+  static constexpr int kRing = 8, kWorkers = 4;
+  void rethrow_locked() {
+    if (error_) std::rethrow_exception(error_);
+  }
+  void fail(std::exception_ptr e) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!error_) error_ = e;
+    abort_ = true;
+    cv_.notify_all();
+  }
+  void dispatch() {
+    try {
+      if (hipSetDevice(device_) != hipSuccess) throw std::runtime_error("cannot select the device");
+      for (;;) {
+        Job j;
+        {
+          std::unique_lock<std::mutex> lk(mu_);
+          cv_.wait(lk, [&] { return !jobs_.empty() || closing_ || abort_; });
+          if (abort_ || jobs_.empty()) return;
+          j = jobs_.front();
+          jobs_.pop_front();
+        }
+        for (size_t c0 = 0; c0 < C_; c0 += cc_) {
+          const size_t c1 = std::min(C_, c0 + cc_);
+          int slot = -1;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] {
+              for (int k = 0; k < kRing; ++k)
+                if (!slot_busy_[k]) return true;
+              return abort_;
+            });
+            if (abort_) return;
+            for (int k = 0; k < kRing; ++k)
+              if (!slot_busy_[k]) slot = k;
+            slot_busy_[slot] = true;
+          }
+          // the chunk arrives compact: [c1 - c0][fill][D]
+          if (hipMemcpy2DAsync(pin_[slot], j.fill * D_ * sizeof(double), j.block + c0 * j.span * D_,
+                               j.span * D_ * sizeof(double), j.fill * D_ * sizeof(double), c1 - c0, hipMemcpyDeviceToHost,
+                               copy_) != hipSuccess ||
+              hipEventRecord(ev_[slot], copy_) != hipSuccess)
+            throw std::runtime_error("copying draws to the host failed");
+          std::lock_guard<std::mutex> lk(mu_);
+          tasks_.push_back(Task{slot, c0, c1, j.first, j.fill});
+          cv_.notify_all();
+        }
+        if (hipEventRecord(j.drained, copy_) != hipSuccess) throw std::runtime_error("copying draws to the host failed");
+        std::lock_guard<std::mutex> lk(mu_);
+        recorded_ = j.ticket;
+        cv_.notify_all();
+      }
+    } catch (...) {
+      fail(std::current_exception());
+    }
+  }
+  void work() {
+    try {
+      if (hipSetDevice(device_) != hipSuccess) throw std::runtime_error("cannot select the device");
+      for (;;) {
+        Task t;
+        {
+          std::unique_lock<std::mutex> lk(mu_);
+          cv_.wait(lk, [&] { return !tasks_.empty() || workers_closing_ || abort_; });
+          if (abort_ || tasks_.empty()) return;
+          t = tasks_.front();
+          tasks_.pop_front();
+        }
+        if (hipEventSynchronize(ev_[t.slot]) != hipSuccess) throw std::runtime_error("copying draws to the host failed");
+        const double* src = pin_[t.slot];
+        for (size_t c = t.c0; c < t.c1; ++c)
+          std::memcpy(out_ + c * rows_ * D_ + t.first * D_, src + (c - t.c0) * t.fill * D_, t.fill * D_ * sizeof(double));
+        std::lock_guard<std::mutex> lk(mu_);
+        slot_busy_[t.slot] = false;
+        cv_.notify_all();
+      }
+    } catch (...) {
+      fail(std::current_exception());
+    }
+  }
+  // orderly (every queued job and task is carried out) or, from the destructor of a call that is being unwound, at once
+  void shut_down(bool abort_now) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (abort_now && (!jobs_.empty() || !tasks_.empty() || submitted_ != recorded_)) abort_ = true;
+      closing_ = true;
+      cv_.notify_all();
+    }
+    if (dispatcher_.joinable()) dispatcher_.join();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      workers_closing_ = true;
+      cv_.notify_all();
+    }
+    for (auto& w : workers_)
+      if (w.joinable()) w.join();
+    workers_.clear();
+  }
+  void release() {
+    for (int k = 0; k < kRing; ++k) {
+      if (pin_[k]) (void)hipHostFree(pin_[k]);
+      if (ev_[k]) (void)hipEventDestroy(ev_[k]);
+      pin_[k] = nullptr;
+      ev_[k] = nullptr;
+    }
+  }
+  int device_;
+  size_t C_, rows_, D_;
+  double* out_;
+  hipStream_t copy_;
+  size_t cc_ = 1;
+  bool usable_ = false;
+  double* pin_[kRing] = {};
+  hipEvent_t ev_[kRing] = {};
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Job> jobs_;
+  std::deque<Task> tasks_;
+  bool slot_busy_[kRing] = {};
+  uint64_t submitted_ = 0, recorded_ = 0;
+  bool closing_ = false, workers_closing_ = false, abort_ = false;
+  std::exception_ptr error_;
+  std::thread dispatcher_;
+  std::vector<std::thread> workers_;
+};
+
 // The draw sink (handlers.hpp:63-116 writes every draw straight into the caller's buffer, whatever its size).
 // The device writes the draws of up to `span` consecutive iterations of all chains into one of two staging blocks
-// [C][span][D]; a full block goes to the caller's out[C][rows][D] as ONE strided copy on a second stream while the
-// next iterations fill the other block, so the device never holds more than two blocks of draws and
-// [C][T][D] may exceed HBM (65 536 chains x 1 000 draws x 1 024 = 537 GB).
+// [C][span][D]; a full block goes to the caller's out[C][rows][D] on a second stream while the next iterations fill the
+// other block, so the device never holds more than two blocks of draws and [C][T][D] may exceed HBM (65 536 chains x
+// 1 000 draws x 1 024 = 537 GB).  Large outputs leave through the pinned ring above, small ones (and anything the ring
+// cannot take) as ONE strided copy.
 class DrawSink {
  public:
   // `rows`: rows per chain of the caller's buffer; `capacity`: how many of them this sink will be asked to write
   // `engine`: whose transition launches fill the blocks.  The copies are ordered against ALL of its launches through
   // the engine (wn_engine_release_stream / _wait_event), not against one stream of it: with chain groups a launch is
   // several kernels on several streams.
-  DrawSink(size_t chains, size_t rows, size_t capacity, size_t dim, double* out, wn_engine* engine)
+  DrawSink(size_t chains, size_t rows, size_t capacity, size_t dim, double* out, wn_engine* engine, int device)
       : C_(chains), rows_(rows), D_(dim), out_(out), engine_(engine) {
     if (C_ * capacity * D_ == 0) return;
     size_t free_b = 0, total_b = 0;
@@ -258,23 +464,23 @@ class DrawSink {
       if (span_ == 1) throw std::runtime_error("cannot allocate the device draw staging buffer");
       span_ = (span_ + 1) / 2;
     }
-    // A block can leave as `lanes_` strided copies of contiguous chain ranges on as many streams
-    // (WALNUTS_AMD_COPY_STREAMS).  Measured with the buffer pre-faulted (Prefault above), 16 GiB: 0.73-0.78 s on one
-    // stream, 0.75-0.81 on two, 0.70-0.82 on four, 0.75-0.80 on eight -- the runtime's staging of a pageable
-    // destination is not what more streams speed up -- so one stream is the default.
-    lanes_ = 1;
-    if (const char* env = std::getenv("WALNUTS_AMD_COPY_STREAMS")) lanes_ = std::atoi(env);
-    lanes_ = std::max(1, std::min({lanes_, kMaxLanes, static_cast<int>(C_)}));
-    for (int l = 0; l < lanes_; ++l) {
-      copy_[l].create();
-      for (int b = 0; b < 2; ++b) drained_[b][l].create();
+    copy_.create();
+    for (int b = 0; b < 2; ++b) drained_[b].create();
+    // WALNUTS_AMD_BOUNCE: 1 = the pinned ring whatever the size (tests), 0 = never; default: from 256 MiB of output
+    bool ring = C_ * capacity * D_ * sizeof(double) >= (size_t{256} << 20);
+    if (const char* env = std::getenv("WALNUTS_AMD_BOUNCE")) ring = env[0] == '1';
+    if (ring) {
+      ring_ = std::make_unique<BounceRing>(device, C_, rows_, D_, out_, span_, copy_.s);
+      if (!ring_->usable()) ring_.reset();
     }
   }
   size_t stride() const { return span_ * D_; }  // doubles between two chains' rows in a staging block
+  bool uses_ring() const { return ring_ != nullptr; }
   // where the next iteration's draws go (device pointer of chain 0's row)
   double* next_row() {
     if (fill_ == 0 && busy_[cur_]) {  // the block still feeds a copy: the kernels must not overwrite it yet
-      for (int l = 0; l < lanes_; ++l) WN_CALL(wn_engine_wait_event(engine_, drained_[cur_][l].e, &call_err_));
+      if (ring_) ring_->wait_recorded(ticket_[cur_]);
+      WN_CALL(wn_engine_wait_event(engine_, drained_[cur_].e, &call_err_));
       busy_[cur_] = false;
     }
     return block_[cur_].p + fill_ * D_;
@@ -291,23 +497,20 @@ class DrawSink {
   // everything written so far is in the caller's buffer when this returns
   void finish() {
     if (fill_ > 0) flush();
-    for (int l = 0; l < lanes_; ++l)
-      if (copy_[l].s && hipStreamSynchronize(copy_[l].s) != hipSuccess)
-        throw std::runtime_error("copying draws to the host failed");
+    if (ring_) ring_->finish();
+    if (copy_.s && hipStreamSynchronize(copy_.s) != hipSuccess) throw std::runtime_error("copying draws to the host failed");
   }
 
  private:
   void flush() {
     const size_t first = written_ - fill_;
-    for (int l = 0; l < lanes_; ++l) {
-      const size_t c0 = C_ * static_cast<size_t>(l) / static_cast<size_t>(lanes_);
-      const size_t c1 = C_ * static_cast<size_t>(l + 1) / static_cast<size_t>(lanes_);
-      WN_CALL(wn_engine_release_stream(engine_, copy_[l].s, &call_err_));  // the copy runs behind every launch made so far
-      if (hipMemcpy2DAsync(out_ + c0 * rows_ * D_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_].p + c0 * span_ * D_,
-                           span_ * D_ * sizeof(double), fill_ * D_ * sizeof(double), c1 - c0, hipMemcpyDeviceToHost,
-                           copy_[l].s) != hipSuccess ||
-          hipEventRecord(drained_[cur_][l].e, copy_[l].s) != hipSuccess)
-        throw std::runtime_error("copying draws to the host failed");
+    WN_CALL(wn_engine_release_stream(engine_, copy_.s, &call_err_));  // the copy runs behind every launch made so far
+    if (ring_) {
+      ticket_[cur_] = ring_->submit(BounceRing::Job{block_[cur_].p, span_, fill_, first, drained_[cur_].e, 0});
+    } else if (hipMemcpy2DAsync(out_ + first * D_, rows_ * D_ * sizeof(double), block_[cur_].p, span_ * D_ * sizeof(double),
+                                fill_ * D_ * sizeof(double), C_, hipMemcpyDeviceToHost, copy_.s) != hipSuccess ||
+               hipEventRecord(drained_[cur_].e, copy_.s) != hipSuccess) {
+      throw std::runtime_error("copying draws to the host failed");
     }
     busy_[cur_] = true;
     cur_ ^= 1;
@@ -316,14 +519,14 @@ class DrawSink {
   size_t C_, rows_, D_;
   double* out_;
   wn_engine* engine_;
-  static constexpr int kMaxLanes = 8;
-  int lanes_ = 1;
-  Stream copy_[kMaxLanes];
+  Stream copy_;
   DevBlock block_[2];
-  Event drained_[2][kMaxLanes];
+  Event drained_[2];
+  uint64_t ticket_[2] = {0, 0};
   bool busy_[2] = {false, false};
   size_t span_ = 1, fill_ = 0, written_ = 0;
   int cur_ = 0;
+  std::unique_ptr<BounceRing> ring_;  // (declared last: its threads stop before the blocks and the stream go away)
 };
 
 // Resident mode (walnutpie_sample_device_resident): the sampling draws stay in one [C][S][D] block in HBM; every
@@ -662,7 +865,7 @@ static int sample_device_impl(
       try {
         if (hipSetDevice(cfg.device) != hipSuccess) throw std::runtime_error("cannot select the device");
         pinned = std::make_unique<PinnedRange>(out, num_chains * draws_offset * sizeof(double));
-        sink_holder = std::make_unique<DrawSink>(num_chains, rows, resident != nullptr ? warm_rows : rows, D, out, e);
+        sink_holder = std::make_unique<DrawSink>(num_chains, rows, resident != nullptr ? warm_rows : rows, D, out, e, cfg.device);
         if (resident != nullptr)
           kept = std::make_unique<ResidentDraws>(num_chains, static_cast<size_t>(max_sampling_iter), D, resident->thin,
                                                  out, rows, warm_rows, e);
@@ -766,8 +969,12 @@ static int sample_device_impl(
     // The helpers start HERE, not at the call's entry: page population and hipMalloc both go through the process's
     // address-space lock, and with the helpers running the engine's and the staging blocks' allocations took 0.9 s
     // instead of 0.03 s (profiles/r04/prefault_ab.txt).  From here on the call only launches kernels and copies.
-    populate = std::make_unique<Prefault>(out, num_chains * draws_offset * sizeof(double),
-                                          static_cast<double>(num_chains) / static_cast<double>(std::max<size_t>(1, total_chains)));
+    // (Only for the sink's direct copies: the pinned ring's scatter threads take their first-touch faults in parallel
+    // by themselves, and the helpers beside them only contend -- 0.80-0.83 s with both against 0.51 s with the ring
+    // alone, same file.)
+    if (!sink.uses_ring())
+      populate = std::make_unique<Prefault>(out, num_chains * draws_offset * sizeof(double),
+                                            static_cast<double>(num_chains) / static_cast<double>(std::max<size_t>(1, total_chains)));
     // (progress lines: shard 0 speaks for all chains)
     Printer printer{shard != nullptr && shard->shard != 0 ? nullptr : print, static_cast<size_t>(refresh)};
     // Consecutive iterations between two looks of a controller go out as ONE launch (wn_engine_*_steps: the workgroup

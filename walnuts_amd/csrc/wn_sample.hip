@@ -451,7 +451,11 @@ class DrawSink {
     if (C_ * capacity * D_ == 0) return;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t{1} << 30;
-    size_t budget = free_b / 4;  // both blocks together: a quarter of what the engine left
+    // Both blocks together: a quarter of what the engine left, and no more than 8 GiB -- a block that holds the whole
+    // run is copied only when the run is over (nothing overlaps), and 52 GiB of fresh device memory for two such
+    // blocks took the first call of a process ~1 s to map (profiles/r04/prefault_ab.txt).  At the headline size a block
+    // is then 8 iterations: one launch of 8 transitions.
+    size_t budget = std::min(free_b / 4, size_t{8} << 30);
     if (const char* env = std::getenv("WALNUTS_AMD_DRAW_STAGING_BYTES")) budget = std::strtoull(env, nullptr, 10);
     const size_t per_iter = C_ * D_ * sizeof(double);
     span_ = std::max<size_t>(1, std::min(capacity, budget / 2 / per_iter));

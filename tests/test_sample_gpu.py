@@ -37,6 +37,35 @@ def test_sigint_ends_the_device_call_with_keyboard_interrupt():
     assert np.all(np.isfinite(np.asarray(out[0])))
 
 
+def test_sigint_while_the_pinned_ring_is_copying():
+    """Ctrl-C in the middle of a run whose draws leave through the sink's pinned ring (4 GiB of output: dispatcher and
+    scatter threads busy): the call ends with KeyboardInterrupt at the next launch boundary, its threads are gone, and
+    the same call runs to the end afterwards with the rows of an undisturbed run."""
+    C, D, S = 8192, 1024, 64
+    kw = dict(num_params=D, num_chains=C, seed=13, min_warmup_iter=4, max_warmup_iter=4, min_sampling_iter=S,
+              max_sampling_iter=S)
+    seen = []
+
+    def on_print(text):
+        seen.append(text)
+        if len(seen) == 20:
+            os.kill(os.getpid(), signal.SIGINT)
+
+    import threading
+    before = threading.active_count()
+    with pytest.raises(KeyboardInterrupt):
+        wa.walnuts_device(wa.MODEL_STD_NORMAL, refresh=1, print_callback=on_print, **kw)
+    assert threading.active_count() == before
+    a = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    os.environ["WALNUTS_AMD_BOUNCE"] = "0"
+    try:
+        b = wa.walnuts_device(wa.MODEL_STD_NORMAL, **kw)
+    finally:
+        del os.environ["WALNUTS_AMD_BOUNCE"]
+    for c in (0, 1, 4095, 4096, C - 1):
+        assert np.array_equal(np.asarray(a[c]), np.asarray(b[c])), c
+
+
 def test_draw_sink_streams_the_headline_chain_count_through_a_small_staging_buffer(monkeypatch):
     """65 536 chains x 1 024 params x 16 draws = 8.6 GB of draws through two staging blocks of two iterations each
     (2.1 GB together): what the whole [C][T][D] block of a default 1 000-draw run could not do in 288 GB of HBM.

@@ -371,6 +371,38 @@ def test_emulated_chain_groups(sim, oracle, model, D, C, geometry):
 
 
 @pytest.mark.timeout(600)
+def test_emulated_stream_ordering_calls(sim):
+    """wn_engine_wait_stream / _release_stream / _wait_event (ordering a caller's stream or event against the engine's
+    streams without adopting them) and wn_engine_set_stream (adopting: one chain group from then on) change nothing in
+    the draws; a null engine-side handle is an error object, not a crash."""
+    def engine(groups):
+        e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, 10, 5, wa.default_config(sim, chain_groups=groups), lib_path=sim)
+        e.init_positions(3, 0, 2.0)
+        e.init_masses_from_grad(1e-5)
+        e.set_step_sizes(0.4)
+        e.seed_chains(4, 0)
+        return e
+
+    a, b, c = engine(1), engine(2), engine(2)
+    assert (a.chain_groups, b.chain_groups) == (1, 2)
+    for it in range(3):
+        a.warmup_step()
+        b.wait_stream(0)
+        b.warmup_step()
+        b.release_stream(0)
+        if it == 1:
+            c.set_stream(0)
+            assert c.chain_groups == 1
+        c.warmup_step()
+    for x in (b, c):
+        assert np.array_equal(a.positions(), x.positions()) and np.array_equal(a.step_sizes(), x.step_sizes())
+    err = C.c_void_p()
+    assert b.lib.wn_engine_wait_event(b.h, None, C.byref(err)) == 0   # (the emulation's events are no-ops)
+    for e in (a, b, c):
+        e.close()
+
+
+@pytest.mark.timeout(600)
 def test_emulated_failed_extension_flag(sim):
     """wn_engine_get_failed_extensions, the failure channel of device models (the counterpart of the reference's
     on_logp_exception events, util.hpp:336-346): a chain that starts where the model's log density overflows fails its

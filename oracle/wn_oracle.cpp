@@ -259,9 +259,7 @@ double log_sum_exp(const MathOps& m, double x1, double x2) {
   double mx = std::fmax(x1, x2);
   if (std::isnan(x1) || std::isnan(x2)) return std::numeric_limits<double>::quiet_NaN();
   if (std::isinf(mx) || std::isnan(x1 + x2)) return std::fmax(x1, x2);
-  if (m.mode == WNO_MATH_LIBM) return mx + std::log(std::exp(x1 - mx) + std::exp(x2 - mx));
-  // device arithmetic: one of the two exponentials is exp(0) = 1, the other's argument is min - max <= 0
-  return mx + wno_log1pexp(x1 < x2 ? x1 - mx : x2 - mx);
+  return mx + m.log(m.exp(x1 - mx) + m.exp(x2 - mx));
 }
 
 // ---------------------------------------------------------------------------
@@ -441,6 +439,10 @@ struct Span {  // walnuts.hpp:34-131
   Vec th_sel, g_sel;
   double lp_sel = 0;
   double logsum = 0;
+  // device arithmetic (WNO_MATH_PORTABLE): the span's weight in the linear domain, exp(energy - Ctx::w_ref), valid
+  // for the reference energy of `epoch` (Ctx::weight_now brings it up to date)
+  double w = 0;
+  size_t epoch = 0;
 };
 
 struct TraceRec {
@@ -473,6 +475,28 @@ struct Ctx {
   void audit(int kind, double margin, double scale) {
     ++decisions[kind];
     if (tie_tol > 0 && std::fabs(margin) <= tie_tol * std::max(1.0, scale)) ++ties[kind];
+  }
+  // ---- the device's span weights (walnuts_amd/csrc/wn_traj.h, "span weights"; WNO_MATH_PORTABLE only) ----
+  // The device carries combine()'s weights in the linear domain relative to a reference energy w_ref (the initial
+  // point's, whose weight is exactly 1): a leaf weighs exp(logp_joint - w_ref), a merged span the sum of its halves,
+  // and the acceptance tests compare u * total < w_new (Barker) / u * w_old < w_new (Metropolis).  A leaf whose
+  // energy is more than 256 above w_ref moves the reference there: the device scales every live weight by
+  // exp(old - new) on the spot; here the factors are kept in a list and a span's weight is brought up to date when
+  // it is next read -- the same multiplications in the same order.
+  double w_ref = 0;
+  std::vector<double> rebase_factors;
+  double leaf_weight(double lj) {
+    const double x = lj - w_ref;
+    if (x > 256.0) {
+      rebase_factors.push_back(wno_exp_weight(-x));
+      w_ref = lj;
+      return 1.0;
+    }
+    return wno_exp_weight(x);
+  }
+  double weight_now(Span& s) {
+    while (s.epoch < rebase_factors.size()) s.w = s.w * rebase_factors[s.epoch++];
+    return s.w;
   }
 };
 
@@ -576,12 +600,26 @@ bool uturn(Ctx& c, bool forward, const Span& s1, const Span& s2) {
 
 // walnuts.hpp:368-387
 Span combine(Ctx& c, bool metropolis, bool forward, Span&& s_old, Span&& s_new) {
-  double total = log_sum_exp(c.mo, s_old.logsum, s_new.logsum);
-  double denom = metropolis ? s_old.logsum : total;
-  double update_logprob = s_new.logsum - denom;
-  const double log_u = c.mo.log(c.rng->uniform01());
-  bool update = log_u < update_logprob;
-  c.audit(2, log_u - update_logprob, std::max(std::fabs(s_new.logsum), std::fabs(denom)));
+  double total;
+  bool update;
+  double total_w = 0;
+  if (c.mo.mode == WNO_MATH_PORTABLE) {
+    // device arithmetic: the weights themselves (see Ctx::leaf_weight); log_sum_exp is never evaluated
+    const double w_old = c.weight_now(s_old), w_new = c.weight_now(s_new);
+    total_w = w_old + w_new;
+    const double denom = metropolis ? w_old : total_w;
+    const double u = c.rng->uniform01();
+    update = u * denom < w_new;
+    c.audit(2, std::log(u * denom) - std::log(w_new), 1.0);
+    total = 0;  // (unused in this mode)
+  } else {
+    total = log_sum_exp(c.mo, s_old.logsum, s_new.logsum);
+    double denom = metropolis ? s_old.logsum : total;
+    double update_logprob = s_new.logsum - denom;
+    const double log_u = c.mo.log(c.rng->uniform01());
+    update = log_u < update_logprob;
+    c.audit(2, log_u - update_logprob, std::max(std::fabs(s_new.logsum), std::fabs(denom)));
+  }
   Span& sel = update ? s_new : s_old;
   Span out;
   out.th_sel = std::move(sel.th_sel);
@@ -598,6 +636,8 @@ Span combine(Ctx& c, bool metropolis, bool forward, Span&& s_old, Span&& s_new) 
   out.g_fw = std::move(fw.g_fw);
   out.lj_fw = fw.lj_fw;
   out.logsum = total;
+  out.w = total_w;
+  out.epoch = c.rebase_factors.size();
   return out;
 }
 
@@ -619,7 +659,12 @@ std::optional<Span> build_leaf(Ctx& c, bool forward, const Span& span) {
   const Vec& g0 = forward ? span.g_fw : span.g_bk;
   double logp = forward ? span.lj_fw : span.lj_bk;
   if (!macro_step(c, forward, th0, rho0, g0, logp, th, rho, g, lp_pos, lj)) return std::nullopt;
-  return single_state(th, rho, g, lp_pos, lj);
+  Span leaf = single_state(th, rho, g, lp_pos, lj);
+  if (c.mo.mode == WNO_MATH_PORTABLE) {
+    leaf.w = c.leaf_weight(lj);
+    leaf.epoch = c.rebase_factors.size();
+  }
+  return leaf;
 }
 
 // walnuts.hpp:464-495
@@ -645,6 +690,10 @@ void transition(Ctx& c, const double* chol, size_t max_depth, Vec& theta, size_t
   ++c.grad_evals;
   double lj = lp_pos + logp_momentum(c.red, D, rho.data(), c.im, c.fma);
   Span acc = single_state(theta, rho, g, lp_pos, lj);
+  c.w_ref = lj;  // device arithmetic: the initial point weighs exactly 1
+  c.rebase_factors.clear();
+  acc.w = 1.0;
+  acc.epoch = 0;
   for (depth = 1; depth <= max_depth; ++depth) {
     bool forward = c.rng->bernoulli();
     auto next = build_span(c, forward, depth - 1, acc);
@@ -713,6 +762,7 @@ struct Chain {
   std::mt19937 eng32;
   std::vector<TraceRec> trace;
   int64_t ties[3] = {0, 0, 0}, decisions[3] = {0, 0, 0};
+  int64_t weight_rebases = 0;  // device arithmetic: how often a transition moved its weights' reference energy
   // WelfordAccumulator of the sampling log densities (online_moments.hpp:22-86, sampler.hpp:87-88)
   double lp_n = 0, lp_mean = 0, lp_m2 = 0;
   void observe_lp(double x) {
@@ -794,6 +844,7 @@ struct wno_engine {
       ch.ties[k] += c.ties[k];
       ch.decisions[k] += c.decisions[k];
     }
+    ch.weight_rebases += static_cast<int64_t>(c.rebase_factors.size());
   }
 
   void warmup_chain(Chain& ch) {  // adaptive_walnuts.hpp:234-251
@@ -1163,6 +1214,13 @@ void wno_get_near_ties(wno_engine* e, int64_t* out, int reset) {
   }
 }
 
+/* device arithmetic: moves of the span weights' reference energy (Ctx::leaf_weight) over all chains so far */
+int64_t wno_get_weight_rebases(const wno_engine* e) {
+  int64_t n = 0;
+  for (auto& ch : e->chains) n += ch.weight_rebases;
+  return n;
+}
+
 void wno_get_positions(const wno_engine* e, double* out) {
   for (size_t c = 0; c < e->C; ++c) std::copy(e->chains[c].theta.begin(), e->chains[c].theta.end(), out + c * e->D);
 }
@@ -1426,6 +1484,6 @@ void wno_stream_normals(uint64_t seed, uint32_t chain, uint32_t transition, uint
 }
 double wno_math_exp(double x) { return wno_exp(x); }
 double wno_math_log(double x) { return wno_log(x); }
-double wno_math_log1pexp(double x) { return wno_log1pexp(x); }
+double wno_math_exp_weight(double x) { return wno_exp_weight(x); }
 
 }  // extern "C"

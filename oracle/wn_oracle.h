@@ -109,6 +109,8 @@ void wno_set_transition_index(wno_engine* e, uint32_t t);
  * out[3..5] = decisions taken */
 void wno_set_tie_tolerance(wno_engine* e, double tol);
 void wno_get_near_ties(wno_engine* e, int64_t* out, int reset);
+/* WNO_MATH_PORTABLE: how often a transition moved the reference energy of its span weights (all chains, so far) */
+int64_t wno_get_weight_rebases(const wno_engine* e);
 
 /* ---- state -------------------------------------------------------------- */
 void wno_get_positions(const wno_engine* e, double* out /*[C*D]*/);
@@ -169,7 +171,7 @@ void wno_stream_normals(uint64_t seed, uint32_t chain, uint32_t transition, uint
                         double* out);
 double wno_math_exp(double x);
 double wno_math_log(double x);
-double wno_math_log1pexp(double x);  /* log(1 + e^x), x <= 0: the device's log_sum_exp core */
+double wno_math_exp_weight(double x);  /* exp(max(x, -700)): the device's span-weight exponential */
 
 #ifdef __cplusplus
 }

@@ -117,12 +117,14 @@ def lib():
     L.wno_math_exp.argtypes = [dbl]
     L.wno_math_log.restype = dbl
     L.wno_math_log.argtypes = [dbl]
-    L.wno_math_log1pexp.restype = dbl
-    L.wno_math_log1pexp.argtypes = [dbl]
+    L.wno_math_exp_weight.restype = dbl
+    L.wno_math_exp_weight.argtypes = [dbl]
     L.wno_set_sampler_state.argtypes = [vp, _dp, _dp, C.POINTER(C.c_int64)]
     L.wno_set_transition_index.argtypes = [vp, u32]
     L.wno_set_tie_tolerance.argtypes = [vp, dbl]
     L.wno_get_near_ties.argtypes = [vp, C.POINTER(C.c_int64), i32]
+    L.wno_get_weight_rebases.restype = C.c_int64
+    L.wno_get_weight_rebases.argtypes = [vp]
     _lib = L
     return L
 
@@ -225,6 +227,10 @@ class Engine:
         out = (C.c_int64 * 6)()
         self.L.wno_get_near_ties(self.h, out, 1 if reset else 0)
         return {k: (int(out[i]), int(out[3 + i])) for i, k in enumerate(("energy_error", "uturn_sign", "acceptance"))}
+
+    def weight_rebases(self) -> int:
+        """Device arithmetic: how often a transition moved the reference energy of its span weights (all chains)."""
+        return int(self.L.wno_get_weight_rebases(self.h))
 
     # --- state
     def _vec(self, fn, shape, dtype=np.float64, ptr=_dp):

@@ -88,13 +88,13 @@ def assert_same_state(dev, orc, where: str, warm: bool):
 
 
 def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path=None, geometry=None, seed=1234,
-             init="random", step=None, check_every=1, average_masses=False, fused=1, **cfg_over):
+             init="random", step=None, check_every=1, average_masses=False, fused=1, init_scale=2.0, **cfg_over):
     """InitConfigBuilder -> warmup -> freeze -> sampling on both sides, bit-compared along the way.  fused > 1: the
     device runs that many transitions per launch (wn_engine_warmup_steps / _sample_steps), the oracle single steps."""
     dev, orc = make_pair(model, D, C, lib_path, geometry, **cfg_over)
     rng = np.random.default_rng(seed)
     if init == "random":
-        pos = rng.normal(0.0, 2.0, size=(C, D))  # init_radius 2.0, pyfunc.py:57
+        pos = rng.normal(0.0, init_scale, size=(C, D))  # init_radius 2.0, pyfunc.py:57
         for x in (dev, orc):
             x.set_positions(pos)
     elif init == "device":
@@ -212,3 +212,14 @@ def check_reference_stream_run(model: str, D: int, C: int, *, seed: int, warmup:
             assert abs(out[c].warmup.stepsize - steps[c]) <= rtol * steps[c]
             assert np.allclose(out[c].warmup.inv_metric, inv_metric[c], rtol=rtol, atol=0)
     return worst, growth
+
+
+def run_weight_rebase_case(model: str, D: int, C: int, *, lib_path=None, geometry=None, **kw):
+    """A run whose trees climb hundreds of units of log density (far-out starting points, no energy-error bound, i.e.
+    plain NUTS): the device's span weights (walnuts_amd/csrc/wn_traj.h, "span weights") move their reference energy
+    several times per chain -- every weight alive at that moment is rescaled -- and the result still equals the
+    oracle's bit for bit.  The oracle counts the moves, so the case cannot pass vacuously."""
+    dev, orc = run_case(model, D, C, lib_path=lib_path, geometry=geometry, init_scale=100.0,
+                        max_hamiltonian_error=1e9, **kw)
+    assert orc.weight_rebases() >= 3, orc.weight_rebases()
+    return dev, orc

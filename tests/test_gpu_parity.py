@@ -216,10 +216,26 @@ def test_edge_configurations_match_oracle(kw):
     parity.run_case(kw.pop("model"), kw.pop("D"), kw.pop("C"), warmup=5, sampling=5, **kw)
 
 
+@pytest.mark.parametrize("model,D,C,geometry,kw", [
+    ("std_normal", 1024, 24, None, dict(step=0.3)),                         # the headline kernel
+    ("std_normal", 1024, 24, None, dict(step=0.3, fused_multiply_add=0)),
+    ("std_normal", 200, 16, (2, 2), dict(step=1.0)),                        # two wavefronts: each keeps its own stack
+    ("diag_normal", 1000, 16, (4, 4), dict(step=0.3)),
+    ("diag_normal", 9000, 6, None, dict(step=0.3)),                         # streaming backend
+    ("std_normal", 100, 32, None, dict(step=0.3, lds_vectors=1)),           # deep stacks, most of them in the arena
+])
+def test_span_weights_move_their_reference_energy(model, D, C, geometry, kw):
+    """combine() in the linear domain (wn_traj.h, "span weights") on trees whose energies leave the range a fixed
+    reference can carry (far-out starts, no energy-error bound): the reference moves, every live weight is rescaled,
+    and the chains equal the oracle's bit for bit; the oracle counts the moves (parity.run_weight_rebase_case)."""
+    parity.run_weight_rebase_case(model, D, C, geometry=geometry, warmup=2, sampling=4, max_trajectory_doublings=6, **kw)
+
+
 def test_non_finite_energies_follow_ieee_like_the_reference():
     """Positions so large that the energies overflow: logp = -inf / NaN comparisons must take the reference's
-    branches (walnuts.hpp:339: a NaN difference is never <= max_error; util.hpp:176-181 for log_sum_exp), the
-    transition ends where the reference's would and the chain keeps its state."""
+    branches (walnuts.hpp:339: a NaN difference is never <= max_error, so no such state is ever merged and the rules
+    of util.hpp:176-181 are never reached), the transition ends where the reference's would and the chain keeps its
+    state."""
     D, C = 32, 6
     dev, orc = parity.make_pair("std_normal", D, C)
     pos = np.random.default_rng(0).normal(size=(C, D))

@@ -15,7 +15,7 @@ SHIM = r'''
 extern "C" {
 double p_exp(double x) { return wnd::dexp(x); }
 double p_log(double x) { return wnd::dlog(x); }
-double p_log1pexp(double x) { return wnd::dlog1pexp<false>(x); }
+double p_exp_weight(double x) { return wnd::dexp_weight(x); }
 double p_pow(double x, double y) { return wnd::dpow_pos(x, y); }
 void p_sincospi(double a, double* s, double* c) { wnd::dsincospi(a, *s, *c); }
 void p_philox(const unsigned* c, const unsigned* k, unsigned* o) {
@@ -37,7 +37,7 @@ def shim(tmp_path_factory):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I",
                            os.path.join(ROOT, "walnuts_amd", "csrc"), str(src), "-o", str(so)])
     L = C.CDLL(str(so))
-    for f in ("p_exp", "p_log", "p_log1pexp"):
+    for f in ("p_exp", "p_log", "p_exp_weight"):
         getattr(L, f).restype = C.c_double
         getattr(L, f).argtypes = [C.c_double]
     L.p_pow.restype = C.c_double
@@ -79,26 +79,25 @@ def test_exp_log_bitwise_equal_to_oracle_copy_and_close_to_libm(shim, oracle):
     assert shim.p_pow(49.0, 0.5) == 7.0 and shim.p_pow(3.0, 0.0) == 1.0
 
 
-def test_log1pexp_bitwise_equal_to_oracle_copy_and_close_to_the_true_value(shim, oracle):
-    """log_sum_exp's core, log(1 + e^d) for d <= 0: table + two short series (wn_devmath.h)."""
-    import mpmath as mp
-    mp.mp.prec = 400   # 1 + e^-48 needs 70 bits before the logarithm sees anything
+def test_span_weight_exp_bitwise_equal_to_oracle_copy_and_close_to_libm(shim, oracle):
+    """exp for the span weights (wn_devmath.h: dexp_weight): arguments up to the rebase threshold, a floor at -700."""
     rng = np.random.default_rng(5)
-    ds = np.concatenate([-rng.uniform(0, 48, 20000), -np.abs(rng.normal(0, 2, 20000)), -rng.uniform(0, 1e-3, 2000),
-                         -np.arange(0, 769) / 16.0, -np.arange(0, 768) / 16.0 - 1 / 32, [-0.0, 0.0, -47.999, -48.0]])
+    xs = np.concatenate([rng.uniform(-700, 256, 20000), rng.normal(0, 3, 20000), rng.uniform(-1e-3, 1e-3, 2000),
+                         [0.0, -0.0, 256.0, -700.0, -699.999, 16.0, -16.0]])
     L = oracle.lib()
-    worst = 0.0
-    for d in ds:
-        a, b = shim.p_log1pexp(d), L.wno_math_log1pexp(d)
+    L.wno_math_exp_weight.restype = C.c_double
+    L.wno_math_exp_weight.argtypes = [C.c_double]
+    for x in xs:
+        a, b = shim.p_exp_weight(x), L.wno_math_exp_weight(x)
         assert a == b
-        ref = mp.log(1 + mp.exp(mp.mpf(float(d))))
-        err = abs(mp.mpf(a) - ref) / mp.mpf(float(np.spacing(float(ref))))
-        worst = max(worst, float(err))
-    assert worst <= 1.5, worst   # ulps
-    # below the table: the last entry stands in (e^-48 = 1.4e-21, absolute)
-    assert shim.p_log1pexp(-60.0) == shim.p_log1pexp(-48.0) == L.wno_math_log1pexp(-1e300) < 1.5e-21
-    assert shim.p_log1pexp(-np.inf) == shim.p_log1pexp(-48.0) and np.isnan(shim.p_log1pexp(np.nan))
-    assert shim.p_log1pexp(0.0) == np.log(2.0)
+        ref = np.exp(x)
+        assert abs(a - ref) <= 2.0 * np.spacing(ref)
+        assert a == shim.p_exp(x)   # the general exp's main path: the same bits wherever both are defined
+    floor = shim.p_exp_weight(-700.0)
+    assert 0 < floor < 1e-303 and floor == L.wno_math_exp_weight(-700.0)
+    for x in (-701.0, -1e6, -np.inf, np.nan):   # anything below the floor -- and NaN -- stands at the floor
+        assert shim.p_exp_weight(x) == floor == L.wno_math_exp_weight(x)
+    assert shim.p_exp_weight(0.0) == 1.0
 
 
 def test_streams_bitwise_equal_to_oracle_copy(shim, oracle):

@@ -74,6 +74,19 @@ def test_emulated_full_size_geometries(sim, oracle, model, D, geometry, fused, f
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("model,D,geometry,kw", [
+    ("std_normal", 64, None, dict(warmup=2, sampling=4, step=0.3, max_trajectory_doublings=6)),
+    ("std_normal", 200, (2, 2), dict(warmup=2, sampling=4, step=1.0, max_trajectory_doublings=6)),
+    ("diag_normal", 300, (1, -1), dict(warmup=2, sampling=4, step=0.3, max_trajectory_doublings=6)),   # streaming
+    ("std_normal", 200, (1, 4), dict(warmup=2, sampling=4, step=0.3, max_trajectory_doublings=6, fused_multiply_add=0)),
+])
+def test_emulated_span_weights_move_their_reference_energy(sim, oracle, model, D, geometry, kw):
+    """combine() in the linear domain (wn_traj.h, "span weights") when a tree's energies leave the range a fixed
+    reference can carry: the reference moves, every live weight is rescaled, bit for bit like the oracle."""
+    parity.run_weight_rebase_case(model, D, 3, lib_path=sim, geometry=geometry, **kw)
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("seed", [2025, 7])
 def test_emulated_random_campaign(sim, oracle, seed):
     """The GPU tier's randomised parity campaign (tests/gpu_probes/fuzz_parity.py: random model, dimension, geometry,

@@ -63,7 +63,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   using Base::P; using Base::lds_pool; using Base::arena; using Base::tid; using Base::lane; using Base::wave;
   using Base::chain; using Base::aux; using Base::n_grad; using Base::n_draw; using Base::draw_base; using Base::err;
   using Base::max_error; using Base::min_micro; using Base::step; using Base::free_mask; using Base::onchip_mask;
-  using Base::w_draw0; using Base::w_score0; using Base::meta; using Base::carry; using Base::bcast;
+  using Base::w_draw0; using Base::w_score0; using Base::meta; using Base::bcast; using Base::w_ref;
   static constexpr int L = Base::L;
   static constexpr int NP = EPL / 2;
   static constexpr int kDp = L * EPL;  // padded dimension: a compile-time constant of the geometry
@@ -516,7 +516,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       if (!kNoGrad) pool_store(o_g, g[0]);
       a_sel = o_th;
     }
-    double lj_hot = lj, lj_other = lj, a_logsum = lj, a_lpsel = lp_pos;
+    // (a_w: the accumulated span's weight -- wn_traj.h, "span weights"; the initial point weighs exactly 1)
+    double lj_hot = lj, lj_other = lj, a_w = 1.0, a_lpsel = lp_pos;
+    w_ref = lj;
     bool hot_fw = true;
 
     // One doubling (walnuts.hpp:541-558); returns whether the tree keeps growing.  The first doubling is a single
@@ -580,7 +582,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       bool ok = true;
       bool top_turned = false;
       int c_in_th = kHot, c_in_rh = kHot, c_sel = kHot;
-      double c_logsum = 0.0, c_lpsel = 0.0;
+      double c_w = 0.0, c_lpsel = 0.0;
       if (kFirst) {
         // a single leaf: its U-turn test against the span's other end (= the initial point, still in set 0 when
         // the leaf is done) rides in the leaf's reduction
@@ -594,7 +596,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
             if (!kNoGrad) g[0][j] = g[1][j];
           }
           h_cur = leaf_lj;
-          c_logsum = leaf_lj;
+          double none = 0.0;
+          c_w = this->leaf_weight(leaf_lj, 0, a_w, none);
           c_lpsel = leaf_lp;
         }
       } else {
@@ -609,36 +612,41 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
             ok = false;
             break;
           }
+          // the two leaves' weights (wn_traj.h, "span weights"), in the order the leaves were built: two independent
+          // chains of scalar maths side by side.  (Had the odd leaf failed, the extension -- and with it the
+          // transition's tree -- would have ended: the even leaf's weight is not missed.)
+          double none = 0.0;
+          double e_w = this->leaf_weight(e_lj, sp, a_w, none);
+          const double leaf_w = this->leaf_weight(leaf_lj, sp, a_w, e_w);
           if (is_warmup() && wave == 0) this->adam_make_room();
           h_cur = leaf_lj;
           // level-0 merge, combine<Barker> (walnuts.hpp:370-386): old = the even leaf (set 1), new = the odd leaf (set 0)
           WN_PHASE(kPhCombine);
           {
-            const double total = uni(log_sum_exp_uniform(e_lj, leaf_lj));
             if (WN_UNLIKELY(pair_turned)) {  // walnuts.hpp:490-492
               ok = false;
               break;
             }
-            const bool update = this->log_uniform01() < leaf_lj - total;
+            const double total = uni(e_w + leaf_w);
+            const bool update = this->uniform01() * total < leaf_w;
             c_in_th = kStart;
             c_in_rh = kStart;
             c_sel = update ? kHot : kStart;
             c_lpsel = update ? leaf_lp : e_lp;
-            c_logsum = total;
+            c_w = total;
           }
           for (int l = 1; ((i + 1) >> l) & 1; ++l) {
             --sp;
             const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
-            const double s_logsum = uni(meta->logsum[sp]), s_lpsel = uni(meta->lpsel[sp]);
+            const double s_w = uni(meta->weight[sp]), s_lpsel = uni(meta->lpsel[sp]);
             WN_PHASE(kPhUturn);
-            this->lse_on_leader(s_logsum, c_logsum);
             if (WN_UNLIKELY(uturn_pool(s_in_th, s_in_rh, fwd))) {  // walnuts.hpp:490-492
               ok = false;
               break;
             }
             WN_PHASE(kPhCombine);
-            const double total = uni(carry);
-            const bool update = this->log_uniform01() < c_logsum - total;
+            const double total = uni(s_w + c_w);
+            const bool update = this->uniform01() * total < c_w;
             const int n_sel = update ? c_sel : s_sel;
             const double n_lpsel = update ? c_lpsel : s_lpsel;
             this->release_unless(s_sel, s_in_th, s_in_rh, n_sel);
@@ -649,7 +657,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
             c_in_rh = s_in_rh;
             c_sel = n_sel;
             c_lpsel = n_lpsel;
-            c_logsum = total;
+            c_w = total;
           }
           if (WN_UNLIKELY(!ok)) break;
           WN_PHASE(kPhPush);
@@ -663,7 +671,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
               meta->in_th[sp] = c_in_th;
               meta->in_rh[sp] = c_in_rh;
               meta->sel[sp] = c_sel;
-              meta->logsum[sp] = c_logsum;
+              meta->weight[sp] = c_w;
               meta->lpsel[sp] = c_lpsel;
             }
             ++sp;
@@ -680,12 +688,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
       WN_PHASE(kPhTopMerge);
       bool turned;
-      double total;
       if (kFirst) {
         turned = top_turned;
-        total = uni(log_sum_exp_uniform(a_logsum, c_logsum));
       } else {
-        this->lse_on_leader(a_logsum, c_logsum);
         if (kOtherRegs) {
           double p_hot, p_far;
           double a[EPL], b[EPL];
@@ -700,9 +705,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         } else {
           turned = uturn_pool(o_th, o_rh, fwd);
         }
-        total = uni(carry);
       }
-      const bool update = this->log_uniform01() < c_logsum - a_logsum;  // Metropolis
+      const bool update = this->uniform01() * a_w < c_w;  // Metropolis
       // the new span's inner end is never read again
       this->release_unless(c_in_th, c_sel, -3, -3);
       this->release_unless(c_in_rh, -3, -3, -3);
@@ -715,7 +719,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         this->release(c_sel);
       }
       lj_hot = h_cur;
-      a_logsum = total;
+      a_w = uni(a_w + c_w);
       return !turned;  // walnuts.hpp:549,556-558
     };
     if (depth <= P.max_depth && doubling(std::true_type{})) {

@@ -162,80 +162,27 @@ WND_HD double dlog_normal(double x, const Tab& tab) {
   return fmad(dk, kLn2Hi, lc) + fmad(dk, kLn2Lo, l1);
 }
 
-// log(1 + e^d) for d <= 0: the core of log_sum_exp (util.hpp:174-183), which the tree evaluates at every merge on a
-// wave-uniform value -- one wavefront per SIMD pays ~2x for every DEPENDENT instruction, and exp followed by log is a
-// chain of ~70.  Here one table look-up replaces both range reductions:
-//     1 + e^(c + r) = (1 + e^c) (1 + s (e^r - 1)),   s = e^c / (1 + e^c)
-//     log(1 + e^d)  = F(c) + log1p(s * expm1(r)),    c = k/16 nearest d, |r| <= 1/32, |s expm1(r)| < 0.016
-// with (F, s) tabulated for c = 0, -1/16, ..., -48 and two short Taylor polynomials (truncation < 1e-17 relative):
-// ~15 dependent operations around one 16-byte look-up.  Below d = -48 (e^d < 1.5e-21) the table's last entry stands
-// in.  Within 1.5 ulp of log1p(exp(d)) (tests/test_portable_math.py).  `Uniform`: the argument is the same in every
-// lane of the wavefront, the look-up is then a scalar load.
-template <bool Uniform>
-WND_HD double dlog1pexp(double d) {
-  const double dc = (d != d) ? 0.0 : (d < -48.0 ? -48.0 : d);
-  const double kf = __builtin_floor(fmad(dc, 16.0, 0.5));
-  int i = -static_cast<int>(kf);  // 0..768
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (Uniform) i = __builtin_amdgcn_readfirstlane(i);
-#endif
-  const double F = as_f64(wn_tab_l1pe_bits[2 * i]);
-  const double S = as_f64(wn_tab_l1pe_bits[2 * i + 1]);
-  const double r = fmad(-kf, 0.0625, dc);  // exact
-  // expm1(r) = r + r^2/2 + ... + r^8/8!
+// exp(x) for the weight of a trajectory span relative to the transition's reference energy (wn_traj.h, "span weights"):
+// the caller keeps x <= kWeightRebase (it moves the reference when a state's energy runs ahead of it), and arguments
+// below -700 -- or NaN -- stand at -700: such a span weighs e^-700 instead of less, beside spans of weight ~1.  The
+// result is therefore a NORMAL number and the final scaling by 2^e is exact: one v_ldexp_f64 on the device, ldexp() on
+// the host, the same bits.  The main path of dexp() without its range patches, ~18 operations around two lane reads.
+constexpr double kWeightFloor = -700.0;
+template <class Tab>
+WND_HD double dexp_weight(double x, const Tab& tab) {
+  constexpr double kInvStep = 9.23324826168936567e+01;   // 64 / ln 2
+  constexpr double kStepHi = 1.08304246095940471e-02;    // ln 2 / 64, upper 28 bits (k * kStepHi is exact)
+  constexpr double kStepLo = 8.66550983900947049e-11;
+  const double xc = (x > kWeightFloor) ? x : kWeightFloor;  // (NaN compares false)
+  const double kf = __builtin_floor(fmad(xc, kInvStep, 0.5));
+  const int k = static_cast<int>(kf);
+  const double r = fmad(-kf, kStepLo, fmad(-kf, kStepHi, xc));
+  const double t = tab.exp2(k & 63);
   const double r2 = r * r;
-  const double r4 = r2 * r2;
-  const double p1 = fmad(r, 1.66666666666666657e-01, 0.5);
-  const double p2 = fmad(r, 8.33333333333333322e-03, 4.16666666666666644e-02);
-  const double p3 = fmad(r, 1.98412698412698413e-04, 1.38888888888888894e-03);
-  const double q = fmad(r4, 2.48015873015873016e-05, fmad(r2, p3, p2));
-  const double e1 = r + fmad(r2, p1, r4 * q);
-  const double t = S * e1;
-  // log1p(t) = t - t^2/2 + t^3/3 - ... - t^10/10
-  const double t2 = t * t;
-  const double t4 = t2 * t2;
-  const double b0 = fmad(t, 3.33333333333333315e-01, -0.5);
-  const double b1 = fmad(t, 2.00000000000000011e-01, -0.25);
-  const double b2 = fmad(t, 1.42857142857142849e-01, -1.66666666666666657e-01);
-  const double b3 = fmad(t, 1.11111111111111105e-01, -0.125);
-  const double inner = fmad(t4, -0.1, fmad(t2, b3, b2));
-  const double outer = fmad(t4, inner, fmad(t2, b1, b0));
-  const double l = fmad(t2, outer, t);
-  double y = F + l;
-  if (d != d) y = d;
-  return y;
-}
-
-// The same function for an argument known to be a finite number <= 0 (or any finite number: the clamp stays): the
-// main path of dlog1pexp without its NaN patches -- the same operations on the same values, hence the same bits.
-template <bool Uniform>
-WND_HD double dlog1pexp_finite(double d) {
-  const double dc = d < -48.0 ? -48.0 : d;
-  const double kf = __builtin_floor(fmad(dc, 16.0, 0.5));
-  int i = -static_cast<int>(kf);  // 0..768
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (Uniform) i = __builtin_amdgcn_readfirstlane(i);
-#endif
-  const double F = as_f64(wn_tab_l1pe_bits[2 * i]);
-  const double S = as_f64(wn_tab_l1pe_bits[2 * i + 1]);
-  const double r = fmad(-kf, 0.0625, dc);
-  const double r2 = r * r;
-  const double r4 = r2 * r2;
-  const double p1 = fmad(r, 1.66666666666666657e-01, 0.5);
-  const double p2 = fmad(r, 8.33333333333333322e-03, 4.16666666666666644e-02);
-  const double p3 = fmad(r, 1.98412698412698413e-04, 1.38888888888888894e-03);
-  const double q = fmad(r4, 2.48015873015873016e-05, fmad(r2, p3, p2));
-  const double e1 = r + fmad(r2, p1, r4 * q);
-  const double t = S * e1;
-  const double t2 = t * t;
-  const double t4 = t2 * t2;
-  const double b0 = fmad(t, 3.33333333333333315e-01, -0.5);
-  const double b1 = fmad(t, 2.00000000000000011e-01, -0.25);
-  const double b2 = fmad(t, 1.42857142857142849e-01, -1.66666666666666657e-01);
-  const double b3 = fmad(t, 1.11111111111111105e-01, -0.125);
-  const double inner = fmad(t4, -0.1, fmad(t2, b3, b2));
-  const double outer = fmad(t4, inner, fmad(t2, b1, b0));
-  return F + fmad(t2, outer, t);
+  const double lo = fmad(r, 1.66666666666666657e-01, 0.5);
+  const double hi = fmad(r, 8.33333333333333322e-03, 4.16666666666666644e-02);
+  const double p = fmad(r2, fmad(r2, hi, lo), r);
+  return __builtin_ldexp(fmad(t, p, t), k >> 6);
 }
 
 // the tables as plain arrays (host: tests, engine set-up; device: constant memory for the rarely used call sites)
@@ -251,6 +198,7 @@ struct ArrayTables {
 WND_HD ArrayTables array_tables() { return ArrayTables{wn_tab_exp2_bits, wn_tab_rcp_bits, wn_tab_logc_bits}; }
 // forms that read the tables from memory: host code and the element-wise set-up kernels
 WND_HD double dexp(double x) { return dexp(x, array_tables()); }
+WND_HD double dexp_weight(double x) { return dexp_weight(x, array_tables()); }
 WND_HD double dlog(double x) { return dlog(x, array_tables()); }
 
 // x^y for x > 0; the path's only use is Adam's t^decay (adam.hpp:83)

@@ -45,8 +45,8 @@
 
 namespace wn {
 
-// reduction scratch in LDS: two parity halves of (4 per wavefront + 1 carried scalar)
-constexpr int kRedStride(int nw) { return 4 * nw + 1; }
+// reduction scratch in LDS: two parity halves of 4 doubles per wavefront
+constexpr int kRedStride(int nw) { return 4 * nw; }
 constexpr int kRedDoubles(int nw) { return 2 * kRedStride(nw); }
 // cx.shift() scratch: the edge lanes of every wavefront publish one value per pair slot (at most 8 pairs per lane)
 // (LDS tail of a workgroup: per-wave Meta | reduction scratch | broadcast word | next-chain words | shift scratch |
@@ -75,30 +75,6 @@ struct GatherTab {  // every lane has its own argument
   __device__ __forceinline__ double rcp(int i) const { return __shfl(t.rc, i, 64); }
   __device__ __forceinline__ double logc(int i) const { return __shfl(t.lc, i, 64); }
 };
-
-// util.hpp:174-183 on wave-uniform arguments.  One of exp(x1-m), exp(x2-m) is exp(0) == 1 exactly, so the sum inside
-// the logarithm is 1 + e^d with d = min - max <= 0: wnd::dlog1pexp (one table look-up, wn_devmath.h).  Branch-free:
-// the special cases are patched in at the end, so the call sits in ONE basic block with the vector work around it.
-__device__ __forceinline__ double log_sum_exp(double x1, double x2) {
-  const double m = fmax(x1, x2);
-  const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
-  double r = m + wnd::dlog1pexp<true>(d);
-  r = (__builtin_isinf(m) || (x1 + x2) != (x1 + x2)) ? m : r;
-  r = (x1 != x1 || x2 != x2) ? __builtin_nan("") : r;
-  return r;
-}
-
-// The same value where nothing can be overlapped with the call anyway (the level-0 merge of a leaf pair, the first
-// doubling's merge): for finite arguments -- a wave-uniform test, hence a scalar branch -- the lean main path, without
-// the fifteen instructions of special-value patches; anything else takes the general form above.  Bit-identical.
-__device__ __forceinline__ double log_sum_exp_uniform(double x1, double x2) {
-  if (__builtin_isfinite(x1) && __builtin_isfinite(x2)) {
-    const double m = fmax(x1, x2);
-    const double d = (x1 < x2) ? (x1 - m) : (x2 - m);
-    return m + wnd::dlog1pexp_finite<true>(d);
-  }
-  return log_sum_exp(x1, x2);
-}
 
 // ---- optional timeline probe (tests/gpu_probes/timeline.py only; compiled out of the product build) -------------
 #if defined(WN_TIMELINE)
@@ -152,7 +128,7 @@ struct TrajBase {
   // per-wave scalar scratch in LDS
   struct Meta {
     double adam[6];
-    double logsum[kMaxLevels];
+    double weight[kMaxLevels];
     double lpsel[kMaxLevels];
     int in_th[kMaxLevels];
     int in_rh[kMaxLevels];
@@ -175,12 +151,10 @@ struct TrajBase {
   unsigned long long free_mask;
   unsigned long long onchip_mask;  // pool buffers that never leave the chip (all of them for the legacy backends)
   int red_parity;
-  double carry;       // scalar computed by wavefront 0 that the next sum2 hands to the other wavefronts
-  bool carry_armed;
   long long n_grad;
   int n_draw;
-  int draw_base;  // first tree-draw index held in draw_u / draw_lu (-1: none)
-  double draw_u, draw_lu;
+  int draw_base;  // first tree-draw index held in draw_u (-1: none)
+  double draw_u;
   int err;
   // (`err` also carries kNoteExtensionFailed: the failure channel of device models, wn_params.h -- set where an
   // extension fails, in blocks that are cold already.  Anything finer -- a count of non-finite attempts kept in a
@@ -212,8 +186,6 @@ struct TrajBase {
     tid = (wave << 6) | lane;
     Dp = p.dim_padded;
     red_parity = 0;
-    carry = 0.0;
-    carry_armed = false;
     onchip_mask = ~0ull;
     tabs.load(lane);
     adam_err = 0.0;
@@ -282,14 +254,12 @@ struct TrajBase {
     if (NW == 1) {
       a = uni(packed);
       b = lane_value(packed, 32);
-      carry_armed = false;
       return;
     }
     if (NW > 1) {
       WN_LDS double* r = red + red_parity * kRedStride(NW);
       if (lane == 0) r[wave * 2] = packed;
       if (lane == 32) r[wave * 2 + 1] = packed;
-      if (carry_armed && tid == 0) r[NW * 2] = carry;  // wavefront 0's scalar rides along (see lse_on_leader)
       __syncthreads();
       double ta = r[0], tb = r[1];
 #pragma unroll
@@ -299,10 +269,8 @@ struct TrajBase {
       }
       a = ta;
       b = tb;
-      if (carry_armed) carry = uni(r[NW * 2]);
       red_parity ^= 1;
     }
-    carry_armed = false;
     a = uni(a);
     b = uni(b);
   }
@@ -315,7 +283,6 @@ struct TrajBase {
       b = lane_value(p1, 32);
       c = uni(p2);
       d = lane_value(p2, 32);
-      carry_armed = false;
       return;
     }
     if (NW > 1) {
@@ -343,18 +310,10 @@ struct TrajBase {
       d = td;
       red_parity ^= 1;
     }
-    carry_armed = false;
     a = uni(a);
     b = uni(b);
     c = uni(c);
     d = uni(d);
-  }
-  // log_sum_exp for the merge that follows a U-turn test: a hundred instructions of wave-uniform scalar maths.  Only
-  // wavefront 0 evaluates it, BEFORE the test, and the value travels to the other wavefronts of the chain in the LDS
-  // exchange the test's reduction does anyway -- their SIMDs run other chains' waves meanwhile.
-  __device__ __forceinline__ void lse_on_leader(double x1, double x2) {
-    if (NW == 1 || wave == 0) carry = log_sum_exp(x1, x2);
-    carry_armed = NW > 1;
   }
   __device__ __forceinline__ double sum1(double a) {
     double b = 0.0;
@@ -409,7 +368,8 @@ struct TrajBase {
 
   // ---- randomness (util.hpp:102,112 order; counter-based stream or host-fed variates) ----
   // The tree consumes wave-uniform scalars one at a time.  They are produced 64 at a time, lane j computing draw number
-  // draw_base + j and its logarithm, kept in two VGPR pairs and handed out with v_readlane.
+  // draw_base + j, kept in one VGPR pair and handed out with v_readlane.  (The acceptance tests compare u * weight
+  // products -- "span weights" below --, so no logarithm of a draw is ever taken.)
   __device__ __forceinline__ void refill_draws(int base) {
     draw_base = base;
     const int j = base + lane;
@@ -421,10 +381,7 @@ struct TrajBase {
       u = wnd::stream_uniform(Q.seed, Q.chain_offset + chain, transition_now(), wnd::kStreamTree,
                               static_cast<uint32_t>(j));
     }
-    // every lane takes part in the table gather; a host-fed uniform may be anything, the generator's is a normal number
-    const double lu = Q.rng_mode == kRngBuffer ? wnd::dlog(u, gather_tab()) : wnd::dlog_normal(u, gather_tab());
-    draw_u = u;   // lane j holds draw number draw_base + j and its logarithm: handed out with v_readlane
-    draw_lu = lu;
+    draw_u = u;   // lane j holds draw number draw_base + j: handed out with v_readlane
   }
   __device__ __forceinline__ int next_draw_slot() {
     const int j = uni(n_draw);
@@ -438,9 +395,42 @@ struct TrajBase {
     const int slot = next_draw_slot();
     return lane_value(draw_u, slot);
   }
-  __device__ __forceinline__ double log_uniform01() {
-    const int slot = next_draw_slot();
-    return lane_value(draw_lu, slot);
+
+  // ---- span weights: combine (walnuts.hpp:368-387) in the linear domain ---------------------------------------------
+  // The reference carries LOG weights: a leaf's is its joint log density, a merged span's the log_sum_exp of its halves
+  // (util.hpp:174-183), and a merge moves its selection when log u < new - total (Barker, walnuts.hpp:493) or
+  // log u < new - old (Metropolis, :547).  The device carries the weights themselves, relative to a per-transition
+  // reference energy w_ref:
+  //     leaf:  w = exp(logp_joint - w_ref)        merge:  total = w_old + w_new
+  //     Barker:  u * total < w_new                Metropolis:  u * w_old < w_new
+  // -- the same decisions up to rounding (the oracle audits every decision for near ties), at one exp per LEAF (~20
+  // instructions, tables in VGPR lanes) instead of one log_sum_exp per MERGE (~65 around a scalar-memory look-up whose
+  // latency stood in the open: 15 merges per headline transition, an eighth of its issue slots) and no logarithm of
+  // the draws.
+  // Range: w_ref starts at the initial point's energy, whose weight is exactly 1.  An accepted leaf lies within
+  // max_error of its predecessor, so with the default limits (0.5, 5 doublings) no energy of a tree is further than 16
+  // from w_ref.  For ANY limits: a leaf whose energy runs more than kWeightRebase ahead of w_ref moves the reference
+  // there -- every live weight (the accumulated span's, the span stack's, the pair's even leaf) is scaled by
+  // exp(old - new), the leaf weighs 1 -- so weights never overflow; a leaf far BELOW the reference bottoms out at
+  // e^-700 (wnd::dexp_weight), beside a span of weight >= 1 that it is merged into sooner or later: selected with
+  // probability < 2^-53 per draw either way, as in the log domain.
+  static constexpr double kWeightRebase = 256.0;
+  double w_ref;
+  // weight of the leaf just built (energy lj); `sp` stack entries, a_w and pair_w are the weights alive beside it
+  __device__ __forceinline__ double leaf_weight(double lj, int sp, double& a_w, double& pair_w) {
+    const double x = lj - w_ref;
+    if (WN_UNLIKELY(x > kWeightRebase)) {
+      const double f = uni(wnd::dexp_weight(-x, uniform_tab()));  // exp(old reference - new reference)
+      a_w = uni(a_w * f);
+      pair_w = uni(pair_w * f);
+      for (int s = 0; s < sp; ++s) {
+        const double t = uni(meta->weight[s]) * f;
+        if (lane == 0) meta->weight[s] = t;
+      }
+      w_ref = lj;
+      return 1.0;
+    }
+    return uni(wnd::dexp_weight(x, uniform_tab()));
   }
 
   // adam.hpp:70-86, batched.  The reference updates Adam after every macro step (walnuts.hpp:335-338); nothing reads
@@ -687,7 +677,8 @@ struct TrajBase {
       self().put(a_bk[2], kG);
     }
     int a_sel = a_bk[0];
-    double a_lj_bk = lj, a_lj_fw = lj, a_logsum = lj, a_lpsel = lp_pos;
+    double a_lj_bk = lj, a_lj_fw = lj, a_w = 1.0, a_lpsel = lp_pos;  // (a_w: the accumulated span's weight)
+    w_ref = lj;
     // The moving end equals one (initially both) of the accumulated span's ends.  An extended end is
     // written back to its pool buffers only when the walk turns around (`dirty`), not after every doubling.
     bool hot_is_fw = true, hot_is_bk = true, dirty = false;
@@ -733,7 +724,7 @@ struct TrajBase {
       int sp = 0;
       bool ok = true;
       int c_in_th = kHot, c_in_rh = kHot, c_sel = kHot;
-      double c_logsum = 0.0, c_lpsel = 0.0;
+      double c_w = 0.0, c_lpsel = 0.0;
       for (int i = 0; i < nleaf; ++i) {
         double leaf_lp, leaf_lj;
         {
@@ -771,22 +762,24 @@ struct TrajBase {
         c_in_th = kHot;
         c_in_rh = kHot;
         c_sel = kHot;
-        c_logsum = leaf_lj;
+        {
+          double none = 0.0;
+          c_w = leaf_weight(leaf_lj, sp, a_w, none);
+        }
         c_lpsel = leaf_lp;
         for (int l = 0; (i >> l) & 1; ++l) {
           --sp;
           const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
-          const double s_logsum = uni(meta->logsum[sp]), s_lpsel = uni(meta->lpsel[sp]);
+          const double s_w = uni(meta->weight[sp]), s_lpsel = uni(meta->lpsel[sp]);
           WN_PHASE(kPhUturn);
-          lse_on_leader(s_logsum, c_logsum);
           if (uturn_against(s_in_th, s_in_rh, fwd)) {  // walnuts.hpp:490-492
             ok = false;
             break;
           }
           WN_PHASE(kPhCombine);
           // combine<Barker> (walnuts.hpp:370-386): old = s, new = c
-          const double total = uni(carry);
-          const bool update = log_uniform01() < c_logsum - total;
+          const double total = uni(s_w + c_w);
+          const bool update = uniform01() * total < c_w;
           const int n_sel = update ? c_sel : s_sel;
           const double n_lpsel = update ? c_lpsel : s_lpsel;
           release_unless(s_sel, s_in_th, s_in_rh, n_sel);
@@ -797,7 +790,7 @@ struct TrajBase {
           c_in_rh = s_in_rh;
           c_sel = n_sel;
           c_lpsel = n_lpsel;
-          c_logsum = total;
+          c_w = total;
         }
         if (!ok) break;
         WN_PHASE(kPhPush);
@@ -819,7 +812,7 @@ struct TrajBase {
             meta->in_th[sp] = c_in_th;
             meta->in_rh[sp] = c_in_rh;
             meta->sel[sp] = c_sel;
-            meta->logsum[sp] = c_logsum;
+            meta->weight[sp] = c_w;
             meta->lpsel[sp] = c_lpsel;
           }
           ++sp;
@@ -832,10 +825,9 @@ struct TrajBase {
 
       WN_PHASE(kPhTopMerge);
       // ---- merge into the accumulated span (walnuts.hpp:546-548) ----
-      lse_on_leader(a_logsum, c_logsum);
       const bool turned = fwd ? uturn_against(a_bk[0], a_bk[1], true) : uturn_against(a_fw[0], a_fw[1], false);
-      const double total = uni(carry);
-      const bool update = log_uniform01() < c_logsum - a_logsum;  // Metropolis
+      const double total = uni(a_w + c_w);
+      const bool update = uniform01() * a_w < c_w;  // Metropolis
       // the new span's inner end is never read again
       release_unless(c_in_th, c_sel, -3, -3);
       release_unless(c_in_rh, -3, -3, -3);
@@ -858,7 +850,7 @@ struct TrajBase {
         hot_is_fw = false;
       }
       dirty = true;
-      a_logsum = total;
+      a_w = total;
       if (turned) break;  // walnuts.hpp:549,556-558
     }
 

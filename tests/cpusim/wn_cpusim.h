@@ -273,6 +273,7 @@ struct PlainDouble {
 inline void park(PlainDouble& a, double v) { a.v = v; }
 inline double fetch(const PlainDouble& a) { return a.v; }
 inline double lane_value(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+inline bool either_half(bool c) { return __shfl(static_cast<int>(c), 0, 64) != 0 || __shfl(static_cast<int>(c), 32, 64) != 0; }
 inline double wave_sum(double v) {  // xor butterfly, offsets 32,1,2,4,8,16: the device's association order
   v = v + __shfl_xor(v, 32, 64);
   for (int off = 1; off < 32; off <<= 1) v = v + __shfl_xor(v, off, 64);

@@ -68,6 +68,10 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   static constexpr int NP = EPL / 2;
   static constexpr int kDp = L * EPL;  // padded dimension: a compile-time constant of the geometry
   static constexpr bool kNoGrad = Model::kCheapGrad;  // the gradient is recomputed from theta at each use
+  // ... and, for an element-wise model, so are the log density's terms: they are taken ONCE, for the state a macro step
+  // ends in, in the same loop as the kinetic energy's (energy_partials) -- two accumulation chains side by side where
+  // each alone is sixteen dependent multiply-adds of a single wavefront, every one waiting for its predecessor
+  static constexpr bool kLateLogp = kNoGrad && Model::kElementwise;
   static constexpr bool kHasStartState = true;
   static constexpr bool kZeroCopy = false;
   // values that live long and are read rarely sit in accumulator registers -- in the kernels built for one or two
@@ -259,8 +263,36 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   __device__ __forceinline__ double model_eval() {
     ++n_grad;
     double part = 0.0;
-    Model::eval(*this, th[S], g[S], mp, aux, part);
+    if constexpr (!kLateLogp) Model::eval(*this, th[S], g[S], mp, aux, part);
     return part;
+  }
+  // what Model::eval sees when it is handed ONE element (kLateLogp)
+  struct ElemCx {
+    const TrajChip& t;
+    int j;
+    __device__ __forceinline__ static double mad(double a, double b, double c) { return TrajChip::mad(a, b, c); }
+    __device__ __forceinline__ int index(int) const { return t.index(j); }
+    __device__ __forceinline__ bool valid(int) const { return t.valid(j); }
+    __device__ __forceinline__ int dim() const { return t.dim(); }
+  };
+  // the lane's partial sums of the log density (`part`: in for a model that accumulated it during the step, out) and of
+  // the kinetic energy (util.hpp:220-223 before the -0.5) of set S, both in index order
+  template <int S>
+  __device__ __forceinline__ void energy_partials(double& part, double& ke) {
+    if constexpr (kLateLogp) {
+      part = 0.0;
+      ke = 0.0;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        const double t1[1] = {th[S][j]}, m1[1] = {mp[j]};
+        double g1[1];
+        ElemCx cx{*this, j};
+        Model::template eval<1>(cx, t1, g1, m1, aux, part);
+        ke = mad(im[j], rh[S][j] * rh[S][j], ke);
+      }
+    } else {
+      ke = kinetic_partial<S>();
+    }
   }
   // kinetic partial of set S (util.hpp:220-223 before the -0.5)
   template <int S>
@@ -295,12 +327,27 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     logp_pos = uni(Model::finish(lp_sum, aux, P.dim));
     logp_joint = uni(logp_pos + (-0.5 * ke_sum));
   }
+  // One wavefront per chain: the energies and the test |H0 - H1| <= max_error (walnuts.hpp:339, :234) from the packed
+  // butterfly (the log-density sum in lanes 0-31, the kinetic sum in lanes 32-63).  The test is taken on the joint
+  // energy where the arithmetic left it -- its scalar copy is made beside the branch, not in front of the compare.
+  __device__ __forceinline__ bool energies_within(double packed, double logp_start, double& logp_pos, double& logp_joint) {
+    const double lp_sum = uni(packed), ke_sum = lane_value(packed, 32);
+    const double lp_v = Model::finish(lp_sum, aux, P.dim);
+    const double lj_v = lp_v + (-0.5 * ke_sum);
+    // (the same value in every lane, which the compiler cannot always see -- a model's finish() may read lane-held
+    // by-products --: the lane mask of the compare makes the branch a scalar one)
+    const bool ok = either_half(fabs(logp_start - lj_v) <= max_error);
+    logp_pos = uni(lp_v);
+    logp_joint = uni(lj_v);
+    return ok;
+  }
 
   // walnuts.hpp:218-235 in place on set S
   template <int S>
   __device__ __forceinline__ bool within_tolerance(double h, int n, double logp_entry) {
     double part = leapfrog_inplace<S>(h, n, 0.0);
-    double ke = kinetic_partial<S>();
+    double ke;
+    energy_partials<S>(part, ke);
     this->sum2(part, ke);
     double lp, lj;
     finish_energy(part, ke, lp, lj);
@@ -345,21 +392,26 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     return result;
   }
 
-  // walnuts.hpp:192-201 partial sums: `H` is the outer end of the newer span, (a, b) = (theta, rho) of the far end
+  // walnuts.hpp:192-201 partial sums: `H` is the outer end of the newer span, (a, b) = (theta, rho) of the far end.
+  // The products are taken with theta_H - theta_far whatever the direction.  Walking backwards the reference's
+  // difference is theta_far - theta_H = -(theta_H - theta_far) exactly, and negating every term negates every partial
+  // sum and every butterfly stage exactly (rounding to nearest is symmetric): the reference's two sums are MINUS
+  // these, so its tests `sum < 0` read `sum > 0` here (turned_sign) -- no sign flip per element.
   template <int H>
-  __device__ __forceinline__ void uturn_partials(const double (&a)[EPL], const double (&b)[EPL], bool fwd, double& p_hot,
+  __device__ __forceinline__ void uturn_partials(const double (&a)[EPL], const double (&b)[EPL], double& p_hot,
                                                  double& p_far) const {
     p_hot = 0.0;
     p_far = 0.0;
-    // a - th == -(th - a) exactly: one subtraction, then a wave-uniform sign flip on the high word
-    const uint64_t flip = fwd ? 0ull : 0x8000000000000000ull;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
-      const double diff = wnd::as_f64(wnd::as_u64(th[H][j] - a[j]) ^ flip);
-      const double sd = im[j] * diff;
+      const double sd = im[j] * (th[H][j] - a[j]);
       p_hot = mad(rh[H][j], sd, p_hot);
       p_far = mad(b[j], sd, p_far);
     }
+  }
+  // rho_fw . sd < 0 || rho_bk . sd < 0 (walnuts.hpp:199-200) from the two sums as uturn_partials takes them
+  __device__ __forceinline__ static bool turned_sign(double p_hot, double p_far, bool fwd) {
+    return fwd ? (p_hot < 0 || p_far < 0) : (p_hot > 0 || p_far > 0);
   }
   // CH consecutive slots (a whole number of pairs) of a pool vector, starting at slot j0
   template <int CH>
@@ -392,7 +444,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     double p_hot = 0.0, p_far = 0.0;
     if (EPL >= 16) {
       constexpr int CH = EPL >= 16 ? EPL / 2 : EPL;
-      const uint64_t flip = fwd ? 0ull : 0x8000000000000000ull;
 #pragma unroll
       for (int h = 0; h < EPL / CH; ++h) {
         double a[CH], b[CH];
@@ -401,8 +452,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           const int jj = h * CH + j;
-          const double diff = wnd::as_f64(wnd::as_u64(th[0][jj] - a[j]) ^ flip);
-          const double sd = im[jj] * diff;
+          const double sd = im[jj] * (th[0][jj] - a[j]);
           p_hot = mad(rh[0][jj], sd, p_hot);
           p_far = mad(b[j], sd, p_far);
         }
@@ -411,10 +461,19 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       double a[EPL], b[EPL];
       pool_load(bth, a);
       pool_load(brh, b);
-      uturn_partials<0>(a, b, fwd, p_hot, p_far);
+      uturn_partials<0>(a, b, p_hot, p_far);
     }
-    this->sum2(p_hot, p_far);
-    return p_hot < 0 || p_far < 0;
+    return turned_packed(p_hot, p_far, fwd);
+  }
+  // the two sums' reduction and the test, one wavefront per chain: read off the compare's lane mask
+  __device__ __forceinline__ bool turned_packed(double p_hot, double p_far, bool fwd) {
+    if constexpr (NW == 1) {
+      const double packed = wave_sum_packed(p_hot, p_far);
+      return either_half(fwd ? packed < 0 : packed > 0);
+    } else {
+      this->sum2(p_hot, p_far);
+      return turned_sign(p_hot, p_far, fwd);
+    }
   }
 
   // walnuts.hpp:307-345 from set A into set 1-A.  `want_turn`: also evaluate the U-turn test of the two-leaf span
@@ -429,26 +488,40 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       WN_PHASE(kPhLeapfrog);
       double part = micro_step<A, B>(h, 0.5 * h);
       part = leapfrog_inplace<B>(h, n - 1, part);
-      double ke = kinetic_partial<B>();
+      double ke;
+      energy_partials<B>(part, ke);
       double p_hot = 0.0, p_far = 0.0;
       WN_PHASE(kPhEnergy);
-      if (want_turn) {
-        uturn_partials<B>(th[A], rh[A], fwd, p_hot, p_far);
-        this->sum4(part, ke, p_hot, p_far);
+      bool within, turn_now;
+      if constexpr (NW == 1) {
+        double packed_turn = 0.0;
+        if (want_turn) {
+          uturn_partials<B>(th[A], rh[A], p_hot, p_far);
+          packed_turn = wave_sum_packed(p_hot, p_far);
+        }
+        within = energies_within(wave_sum_packed(part, ke), logp_start, logp_pos, logp_joint);
+        turn_now = want_turn && either_half(fwd ? packed_turn < 0 : packed_turn > 0);
       } else {
-        this->sum2(part, ke);
+        if (want_turn) {
+          uturn_partials<B>(th[A], rh[A], p_hot, p_far);
+          this->sum4(part, ke, p_hot, p_far);
+        } else {
+          this->sum2(part, ke);
+        }
+        finish_energy(part, ke, logp_pos, logp_joint);
+        within = fabs(logp_start - logp_joint) <= max_error;
+        turn_now = turned_sign(p_hot, p_far, fwd);
       }
-      finish_energy(part, ke, logp_pos, logp_joint);
       if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
         // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
         if (is_warmup() && wave == 0) this->adam_record(fabs(logp_start - logp_joint));
       }
       WN_PHASE(kPhRestart);
-      if (WN_LIKELY(fabs(logp_start - logp_joint) <= max_error)) {
+      if (WN_LIKELY(within)) {
         WN_PHASE(kPhReversible);
         const bool rev = reversible<B>(h, n, logp_joint);
         WN_PHASE(kPhRestart);
-        turned = p_hot < 0 || p_far < 0;
+        turned = turn_now;
         return rev;
       }
     }
@@ -490,7 +563,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     double lp_pos, lj;
     {
       double part = begin_transition(row, warm);
-      double ke = kinetic_partial<0>();
+      double ke;
+      energy_partials<0>(part, ke);
       this->sum2(part, ke);
       finish_energy(part, ke, lp_pos, lj);
     }
@@ -699,9 +773,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
             a[j] = fetch(oth[j]);
             b[j] = fetch(orh[j]);
           }
-          uturn_partials<0>(a, b, fwd, p_hot, p_far);
-          this->sum2(p_hot, p_far);
-          turned = p_hot < 0 || p_far < 0;
+          uturn_partials<0>(a, b, p_hot, p_far);
+          turned = turned_packed(p_hot, p_far, fwd);
         } else {
           turned = uturn_pool(o_th, o_rh, fwd);
         }
@@ -854,9 +927,11 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     if (warm) {
       // adaptive_walnuts.hpp:247-248: observe (theta_sel, grad_sel).  grad_sel is a pure
       // function of theta_sel, so it is re-evaluated instead of being carried through the tree.
-      const long long keep_grad = n_grad;
-      (void)model_eval<0>();
-      n_grad = keep_grad;
+      if constexpr (!kNoGrad) {
+        const long long keep_grad = n_grad;
+        (void)model_eval<0>();
+        n_grad = keep_grad;
+      }
       const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(this->warmup_iter_now()));
       const double wd = discount * w_draw0 + 1;
       const double ws = discount * w_score0 + 1;

@@ -76,6 +76,10 @@ __device__ __forceinline__ double wave_sum_packed(double a, double b) {
   }
   return v;
 }
+// A per-lane condition on a value the packed butterfly left uniform within each half of the wavefront, as a SCALAR
+// branch condition: does it hold in lane 0 or in lane 32 (= in any lane)?  One v_cmp into a lane mask and a scalar
+// test of the mask: no v_readlane round trip in front of the compare.
+__device__ __forceinline__ bool either_half(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 // value held by lane `src_lane` (wave-uniform index) as a scalar
 __device__ __forceinline__ double lane_value(double v, int src_lane) {
   const uint64_t u = bits_of(v);

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
         }
         double part = t.template model_eval<0>();
         double lp, lj0, lj1;
-        double ke = t.template kinetic_partial<0>();
+        double ke;
+        t.template energy_partials<0>(part, ke);
         t.sum2(part, ke);
         t.finish_energy(part, ke, lp, lj0);
 #pragma unroll
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(64 * NW) void init_kernel(const InitParams Q) {
         part = t.template model_eval<0>();
 #pragma unroll
         for (int j = 0; j < EPL; ++j) t.rh[0][j] = t.rh[0][j] + 0.5 * h * t.template G<0>(j);
-        ke = t.template kinetic_partial<0>();
+        t.template energy_partials<0>(part, ke);
         t.sum2(part, ke);
         t.finish_energy(part, ke, lp, lj1);
         return lj1 - lj0;

@@ -273,6 +273,9 @@ struct PlainDouble {
 inline void park(PlainDouble& a, double v) { a.v = v; }
 inline double fetch(const PlainDouble& a) { return a.v; }
 inline double lane_value(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+inline int lane_value(int v, int src_lane) { return __shfl(v, src_lane, 64); }
+inline void set_lane(int& reg, int v, int dst_lane) { if (static_cast<int>(wnsim::tidx.x & 63u) == dst_lane) reg = v; }
+inline void set_lane(double& reg, double v, int dst_lane) { if (static_cast<int>(wnsim::tidx.x & 63u) == dst_lane) reg = v; }
 inline bool either_half(bool c) { return __shfl(static_cast<int>(c), 0, 64) != 0 || __shfl(static_cast<int>(c), 32, 64) != 0; }
 inline double wave_sum(double v) {  // xor butterfly, offsets 32,1,2,4,8,16: the device's association order
   v = v + __shfl_xor(v, 32, 64);
@@ -284,6 +287,8 @@ inline double wave_sum_packed(double a, double b) {  // a's total in lanes 0-31,
   return (wnsim::tidx.x & 63u) < 32u ? sa : sb;
 }
 inline int opaque_scalar_add(int a, int b) { return a + b; }
+inline double opaque_uniform(double v) { return v; }
+inline void launder(double&) {}
 inline int opaque_lane_id() { return static_cast<int>(wnsim::tidx.x & 63u); }
 inline int wave_in_workgroup() { return static_cast<int>(wnsim::tidx.x >> 6); }
 template <class T>

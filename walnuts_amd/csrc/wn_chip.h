@@ -439,29 +439,48 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   }
   // the moving end (always set 0 when a pool-resident span is merged) against a span end kept in the pool.  With 16
   // elements per lane the two operands are taken half a vector at a time: the kernel is at its register limit there,
-  // and 64 more live registers mean as many moves to and from the accumulator file.
-  __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
-    double p_hot = 0.0, p_far = 0.0;
-    if (EPL >= 16) {
-      constexpr int CH = EPL >= 16 ? EPL / 2 : EPL;
+  // and 64 more live registers mean as many moves to and from the accumulator file.  Both operands in LDS -- the usual
+  // case -- is decided by ONE test in front of the loads.
+  template <bool LDS_ONLY, int CH>
+  __device__ __forceinline__ void pool_operands(int b, int j0, double (&v)[CH]) {
+    if constexpr (LDS_ONLY) {
+      WN_COUNT(1, CH);
+      const WN_LDS double* base = lds_pool + b * kDp;
 #pragma unroll
-      for (int h = 0; h < EPL / CH; ++h) {
-        double a[CH], b[CH];
-        pool_load_slots<CH>(bth, h * CH, a);
-        pool_load_slots<CH>(brh, h * CH, b);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const int jj = h * CH + j;
-          const double sd = im[jj] * (th[0][jj] - a[j]);
-          p_hot = mad(rh[0][jj], sd, p_hot);
-          p_far = mad(b[j], sd, p_far);
-        }
+      for (int k = 0; k < CH / 2; ++k) {
+        const v2f64 t = *reinterpret_cast<const WN_LDS v2f64*>(base + ((j0 / 2 + k) * L + tid) * 2);
+        v[2 * k] = t[0];
+        v[2 * k + 1] = t[1];
       }
     } else {
-      double a[EPL], b[EPL];
-      pool_load(bth, a);
-      pool_load(brh, b);
-      uturn_partials<0>(a, b, p_hot, p_far);
+      pool_load_slots<CH>(b, j0, v);
+    }
+  }
+  template <bool LDS_ONLY>
+  __device__ __forceinline__ void uturn_pool_partials(int bth, int brh, double& p_hot, double& p_far) {
+    constexpr int CH = EPL >= 16 ? EPL / 2 : EPL;
+    p_hot = 0.0;
+    p_far = 0.0;
+#pragma unroll
+    for (int h = 0; h < EPL / CH; ++h) {
+      double a[CH], b[CH];
+      pool_operands<LDS_ONLY, CH>(bth, h * CH, a);
+      pool_operands<LDS_ONLY, CH>(brh, h * CH, b);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int jj = h * CH + j;
+        const double sd = im[jj] * (th[0][jj] - a[j]);
+        p_hot = mad(rh[0][jj], sd, p_hot);
+        p_far = mad(b[j], sd, p_far);
+      }
+    }
+  }
+  __device__ __forceinline__ bool uturn_pool(int bth, int brh, bool fwd) {
+    double p_hot, p_far;
+    if (WN_LIKELY(bth < n_lds && brh < n_lds)) {
+      uturn_pool_partials<true>(bth, brh, p_hot, p_far);
+    } else {
+      uturn_pool_partials<false>(bth, brh, p_hot, p_far);
     }
     return turned_packed(p_hot, p_far, fwd);
   }
@@ -476,56 +495,88 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     }
   }
 
-  // walnuts.hpp:307-345 from set A into set 1-A.  `want_turn`: also evaluate the U-turn test of the two-leaf span
-  // (previous leaf = set A, new leaf = set 1-A), whose two sums share the energy reduction.
-  template <int A>
+  // One attempt of a macro step (the body of walnuts.hpp:323-343's loop): n micro steps of size h from set A into set
+  // 1-A, the new state's energies, the test |H0 - H1| <= max_error.  `want_turn`: also the U-turn test of the two-leaf
+  // span (previous leaf = set A, new leaf = set 1-A), whose two sums share the energy reduction.  ONE: n == 1 is known.
+  template <int A, bool ONE, bool want_turn>
+  __device__ __forceinline__ bool leaf_attempt(double h, int n, bool fwd, double logp_start, double& logp_pos,
+                                               double& logp_joint, bool first, bool& turn_now) {
+    constexpr int B = 1 - A;
+    WN_PHASE(kPhLeapfrog);
+    h = opaque_uniform(h);
+    double part = micro_step<A, B>(h, 0.5 * h);
+    if constexpr (!ONE) part = leapfrog_inplace<B>(h, n - 1, part);
+    double ke;
+    energy_partials<B>(part, ke);
+    double p_hot = 0.0, p_far = 0.0;
+    WN_PHASE(kPhEnergy);
+    bool within;
+    if constexpr (NW == 1) {
+      double packed_turn = 0.0;
+      if (want_turn) {
+        uturn_partials<B>(th[A], rh[A], p_hot, p_far);
+        packed_turn = wave_sum_packed(p_hot, p_far);
+      }
+      within = energies_within(wave_sum_packed(part, ke), logp_start, logp_pos, logp_joint);
+      turn_now = want_turn && either_half(fwd ? packed_turn < 0 : packed_turn > 0);
+    } else {
+      if (want_turn) {
+        uturn_partials<B>(th[A], rh[A], p_hot, p_far);
+        this->sum4(part, ke, p_hot, p_far);
+      } else {
+        this->sum2(part, ke);
+      }
+      finish_energy(part, ke, logp_pos, logp_joint);
+      within = fabs(logp_start - logp_joint) <= max_error;
+      turn_now = turned_sign(p_hot, p_far, fwd);
+    }
+    if (first) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
+      // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
+      if (is_warmup() && wave == 0) this->adam_record(fabs(logp_start - logp_joint));
+    }
+    WN_PHASE(kPhRestart);
+    return within;
+  }
+
+  // walnuts.hpp:307-345 from set A into set 1-A.
+  // Control flow is laid out for the usual leaf -- one micro step, accepted at the first step size --: a scalar branch
+  // costs a lone wavefront 15-30 cycles (tests/gpu_probes/branch_cost.hip), and a loop with two ways out makes the
+  // compiler test its exit flags again behind it.  So the usual leaf is straight-line code behind ONE test (n == 1)
+  // and leaves through ONE more (accepted); everything else -- more micro steps, halvings, the reversibility check --
+  // is the general loop below it, which the usual leaf never enters.
+  template <int A, bool want_turn>
   __device__ __forceinline__ bool macro_step(bool fwd, double logp_start, double& logp_pos, double& logp_joint,
-                                             bool want_turn, bool& turned) {
+                                             bool& turned) {
     constexpr int B = 1 - A;
     double h = fwd ? step : -step;
     int n = min_micro;
-    for (int halvings = 0; halvings < P.max_halvings; ++halvings, n *= 2, h *= 0.5) {
-      WN_PHASE(kPhLeapfrog);
-      double part = micro_step<A, B>(h, 0.5 * h);
-      part = leapfrog_inplace<B>(h, n - 1, part);
-      double ke;
-      energy_partials<B>(part, ke);
-      double p_hot = 0.0, p_far = 0.0;
-      WN_PHASE(kPhEnergy);
-      bool within, turn_now;
-      if constexpr (NW == 1) {
-        double packed_turn = 0.0;
-        if (want_turn) {
-          uturn_partials<B>(th[A], rh[A], p_hot, p_far);
-          packed_turn = wave_sum_packed(p_hot, p_far);
-        }
-        within = energies_within(wave_sum_packed(part, ke), logp_start, logp_pos, logp_joint);
-        turn_now = want_turn && either_half(fwd ? packed_turn < 0 : packed_turn > 0);
-      } else {
-        if (want_turn) {
-          uturn_partials<B>(th[A], rh[A], p_hot, p_far);
-          this->sum4(part, ke, p_hot, p_far);
-        } else {
-          this->sum2(part, ke);
-        }
-        finish_energy(part, ke, logp_pos, logp_joint);
-        within = fabs(logp_start - logp_joint) <= max_error;
-        turn_now = turned_sign(p_hot, p_far, fwd);
-      }
-      if (halvings == 0) {  // num_steps == min_micro_steps, walnuts.hpp:335-338
-        // Adam's state lives in wavefront 0's scratch (store_scalars reads it there): the others skip the update
-        if (is_warmup() && wave == 0) this->adam_record(fabs(logp_start - logp_joint));
-      }
-      WN_PHASE(kPhRestart);
-      if (WN_LIKELY(within)) {
-        WN_PHASE(kPhReversible);
-        const bool rev = reversible<B>(h, n, logp_joint);
-        WN_PHASE(kPhRestart);
+    int halvings = 0;
+    bool turn_now = false;
+    if (WN_LIKELY(n == 1)) {
+      if (WN_LIKELY((leaf_attempt<A, true, want_turn>(h, 1, fwd, logp_start, logp_pos, logp_joint, true, turn_now)))) {
         turned = turn_now;
-        return rev;
+        return true;  // (one micro step is reversible by definition, walnuts.hpp:261-263)
       }
+      halvings = 1;
+      if (halvings >= P.max_halvings) return false;
+      n = 2;
+      h *= 0.5;
     }
-    return false;
+    for (;;) {
+      // (the restart state does not change from one attempt to the next, and left to itself the optimiser computes
+      // what this loop derives from it -- the gradient -theta, sixteen negated copies -- in front of the loop, i.e. on
+      // the usual leaf's path into the next macro step)
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) launder(th[A][j]);
+      if (leaf_attempt<A, false, want_turn>(h, n, fwd, logp_start, logp_pos, logp_joint, halvings == 0, turn_now)) {
+        turned = turn_now;
+        WN_PHASE(kPhReversible);
+        return reversible<B>(h, n, logp_joint);
+      }
+      if (++halvings >= P.max_halvings) return false;
+      n *= 2;
+      h *= 0.5;
+    }
   }
 
   // give a symbolic vector (kHot = set 0, kStart = set 1) a pool buffer
@@ -602,7 +653,10 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     auto doubling = [&](auto first_tag) -> bool {
       constexpr bool kFirst = decltype(first_tag)::value;
       WN_PHASE(kPhDoublingStart);
-      const bool fwd = this->uniform01() < 0.5;  // bernoulli(0.5), walnuts.hpp:552
+      // (draws are asked for in stretches, wn_traj.h ensure_draws: here this one and, for the single leaf of the first
+      // doubling, the Metropolis draw of its merge)
+      this->ensure_draws(2);
+      const bool fwd = this->uniform01_ready() < 0.5;  // bernoulli(0.5), walnuts.hpp:552
       if (kFirst) {
         hot_fw = fwd;
       } else if (fwd != hot_fw) {
@@ -661,7 +715,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         // a single leaf: its U-turn test against the span's other end (= the initial point, still in set 0 when
         // the leaf is done) rides in the leaf's reduction
         double leaf_lp, leaf_lj;
-        ok = macro_step<0>(fwd, h_cur, leaf_lp, leaf_lj, true, top_turned);
+        ok = macro_step<0, true>(fwd, h_cur, leaf_lp, leaf_lj, top_turned);
         if (WN_LIKELY(ok)) {
 #pragma unroll
           for (int j = 0; j < EPL; ++j) {
@@ -678,20 +732,21 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         for (int i = 0; i < nleaf; i += 2) {
           double e_lp, e_lj, leaf_lp, leaf_lj;
           bool pair_turned = false, unused = false;
-          if (WN_UNLIKELY(!macro_step<0>(fwd, h_cur, e_lp, e_lj, false, unused))) {  // build_leaf, walnuts.hpp:420-442
+          if (WN_UNLIKELY((!macro_step<0, false>(fwd, h_cur, e_lp, e_lj, unused)))) {  // build_leaf, walnuts.hpp:420-442
             ok = false;
             break;
           }
-          if (WN_UNLIKELY(!macro_step<1>(fwd, e_lj, leaf_lp, leaf_lj, true, pair_turned))) {
+          if (WN_UNLIKELY((!macro_step<1, true>(fwd, e_lj, leaf_lp, leaf_lj, pair_turned)))) {
             ok = false;
             break;
           }
-          // the two leaves' weights (wn_traj.h, "span weights"), in the order the leaves were built: two independent
-          // chains of scalar maths side by side.  (Had the odd leaf failed, the extension -- and with it the
-          // transition's tree -- would have ended: the even leaf's weight is not missed.)
-          double none = 0.0;
-          double e_w = this->leaf_weight(e_lj, sp, a_w, none);
-          const double leaf_w = this->leaf_weight(leaf_lj, sp, a_w, e_w);
+          // the draws this pair's merges can take: its own, one per stack level, the doubling's Metropolis draw
+          this->ensure_draws(kMaxLevels + 2);
+          // the two leaves' weights (wn_traj.h, "span weights"), in the order the leaves were built.  (Had the odd
+          // leaf failed, the extension -- and with it the transition's tree -- would have ended: the even leaf's
+          // weight is not missed.)
+          double e_w, leaf_w;
+          this->pair_weights(e_lj, leaf_lj, sp, a_w, e_w, leaf_w);
           if (is_warmup() && wave == 0) this->adam_make_room();
           h_cur = leaf_lj;
           // level-0 merge, combine<Barker> (walnuts.hpp:370-386): old = the even leaf (set 1), new = the odd leaf (set 0)
@@ -702,7 +757,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
               break;
             }
             const double total = uni(e_w + leaf_w);
-            const bool update = this->uniform01() * total < leaf_w;
+            const bool update = this->uniform01_ready() * total < leaf_w;
             c_in_th = kStart;
             c_in_rh = kStart;
             c_sel = update ? kHot : kStart;
@@ -711,8 +766,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
           }
           for (int l = 1; ((i + 1) >> l) & 1; ++l) {
             --sp;
-            const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
-            const double s_w = uni(meta->weight[sp]), s_lpsel = uni(meta->lpsel[sp]);
+            int s_in_th, s_in_rh, s_sel;
+            double s_w, s_lpsel;
+            this->stack_read(sp, s_in_th, s_in_rh, s_sel, s_w, s_lpsel);
             WN_PHASE(kPhUturn);
             if (WN_UNLIKELY(uturn_pool(s_in_th, s_in_rh, fwd))) {  // walnuts.hpp:490-492
               ok = false;
@@ -720,13 +776,15 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
             }
             WN_PHASE(kPhCombine);
             const double total = uni(s_w + c_w);
-            const bool update = this->uniform01() * total < c_w;
+            const bool update = this->uniform01_ready() * total < c_w;
             const int n_sel = update ? c_sel : s_sel;
             const double n_lpsel = update ? c_lpsel : s_lpsel;
-            this->release_unless(s_sel, s_in_th, s_in_rh, n_sel);
-            this->release_unless(c_in_th, s_in_th, s_in_rh, n_sel);
-            this->release_unless(c_in_rh, s_in_th, s_in_rh, n_sel);
-            this->release_unless(c_sel, s_in_th, s_in_rh, n_sel);
+            // The merged span keeps the older span's inner end and one of the two selections; what goes back to the
+            // pool: the newer span's inner momentum, its inner position unless that is the selection kept, and the
+            // selection not kept -- the older span's stays if it is that span's inner end.  (An index of the newer
+            // span can be symbolic -- a leaf still in its register set -- and has no bit.)
+            free_mask |= Base::pool_bit(c_in_rh) | (c_in_th != n_sel ? Base::pool_bit(c_in_th) : 0ull) |
+                         (update ? (s_sel != s_in_th ? (1ull << s_sel) : 0ull) : Base::pool_bit(c_sel));
             c_in_th = s_in_th;
             c_in_rh = s_in_rh;
             c_sel = n_sel;
@@ -737,25 +795,38 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
           WN_PHASE(kPhPush);
           if (i + 2 < nleaf) {
             // the next pair overwrites both sets: whatever is still symbolic gets pool buffers
-            const bool sel_is_inner = (c_sel == c_in_th);
-            c_in_th = materialize(c_in_th, false);
-            c_in_rh = materialize(c_in_rh, true);
-            c_sel = sel_is_inner ? c_in_th : materialize(c_sel, false);
-            if (lane == 0) {
-              meta->in_th[sp] = c_in_th;
-              meta->in_rh[sp] = c_in_rh;
-              meta->sel[sp] = c_sel;
-              meta->weight[sp] = c_w;
-              meta->lpsel[sp] = c_lpsel;
+            if (((i + 1) & 2) == 0) {
+              // no merge above level 0 (the cascade's first test is bit 1 of i + 1): the span is the pair itself, its
+              // inner end the even leaf (set 1), its selection one of the two leaves.  Buffers in the order inner
+              // position, inner momentum, selection; one tier test for all of them (the lowest free index comes first,
+              // LDS buffers are the low indices).
+              const bool sel_hot = c_sel == kHot;
+              const int b0 = this->alloc(), b1 = this->alloc();
+              const int b2 = this->alloc_if(sel_hot, b0);
+              if (WN_LIKELY((b1 > b2 ? b1 : b2) < n_lds)) {
+                WN_COUNT(0, (sel_hot ? 3 : 2) * EPL);
+                lds_store(lds_pool + b0 * kDp, th[1]);
+                lds_store(lds_pool + b1 * kDp, rh[1]);
+                if (sel_hot) lds_store(lds_pool + b2 * kDp, th[0]);
+              } else {
+                pool_store(b0, th[1]);
+                pool_store(b1, rh[1]);
+                if (sel_hot) pool_store(b2, th[0]);
+              }
+              c_in_th = b0;
+              c_in_rh = b1;
+              c_sel = b2;
+            } else if (c_sel < 0) {
+              // after a cascade the ends are the older span's pool buffers; the selection may still be a leaf of the pair
+              c_sel = materialize(c_sel, false);
             }
+            this->stack_push(sp, c_in_th, c_in_rh, c_sel, c_w, c_lpsel);
             ++sp;
           }
         }
       }
       if (WN_UNLIKELY(!ok)) {  // walnuts.hpp:543-545
-#if !defined(WN_NO_FAILURE_COUNT)  // (probe switch: tests/gpu_probes A/B of what the flag costs)
         err |= static_cast<int>(kNoteExtensionFailed);
-#endif
         return false;
       }
 
@@ -779,7 +850,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
           turned = uturn_pool(o_th, o_rh, fwd);
         }
       }
-      const bool update = this->uniform01() * a_w < c_w;  // Metropolis
+      const bool update = this->uniform01_ready() * a_w < c_w;  // Metropolis
       // the new span's inner end is never read again
       this->release_unless(c_in_th, c_sel, -3, -3);
       this->release_unless(c_in_rh, -3, -3, -3);

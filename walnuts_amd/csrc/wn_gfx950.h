@@ -88,6 +88,14 @@ __device__ __forceinline__ double lane_value(double v, int src_lane) {
   return double_of((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
+__device__ __forceinline__ int lane_value(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+// reg[dst_lane] = v for a wave-uniform value and index: a select on the lane id (v_writelane_b32 would do it in one
+// instruction per dword, but this compiler has no builtin for it and hands an inline-asm "s" operand a VECTOR
+// register whenever it knows the value uniform without having it in a scalar one)
+__device__ __forceinline__ int opaque_lane_id();
+__device__ __forceinline__ void set_lane(int& reg, int v, int dst_lane) { reg = opaque_lane_id() == dst_lane ? v : reg; }
+__device__ __forceinline__ void set_lane(double& reg, double v, int dst_lane) { reg = opaque_lane_id() == dst_lane ? v : reg; }
+
 // A double parked in the accumulator half of the register file (AGPRs).  Vector arithmetic cannot read AGPRs, so the
 // compiler uses them only as spill space and shuffles whole vectors in and out at region boundaries as it sees
 // fit; a value parked explicitly stays put, and a vector that is read once per doubling costs exactly one
@@ -139,6 +147,17 @@ __device__ __forceinline__ int opaque_scalar_add(int a, int b) {
   asm volatile("s_add_u32 %0, %0, %1" : "+s"(a) : "s"(b) : "scc");
   return a;
 }
+// a (wave-uniform) double the optimiser cannot see through: what is computed from it stays where it is written (the
+// step size of a leaf: h * inv_mass, hoisted out of the leaf loop, is sixteen products kept in -- and fetched back
+// from -- the accumulator file for every leaf instead of sixteen multiplications)
+__device__ __forceinline__ double opaque_uniform(double v) {
+  unsigned long long b = bits_of(v);
+  asm volatile("" : "+v"(b));  // (a vector register: an "s" operand fails to compile where the value sits in one)
+  return double_of(b);
+}
+// "this register may have changed" as far as the optimiser can tell (no instruction): what is computed from it cannot
+// be hoisted across this point
+__device__ __forceinline__ void launder(double& v) { asm volatile("" : "+v"(v)); }
 // the wavefront's index within its workgroup, read once at the kernel entry (wave-uniform: a scalar register)
 __device__ __forceinline__ int wave_in_workgroup() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
 

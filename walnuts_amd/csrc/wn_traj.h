@@ -128,11 +128,6 @@ struct TrajBase {
   // per-wave scalar scratch in LDS
   struct Meta {
     double adam[6];
-    double weight[kMaxLevels];
-    double lpsel[kMaxLevels];
-    int in_th[kMaxLevels];
-    int in_rh[kMaxLevels];
-    int sel[kMaxLevels];
 #if defined(WN_TIMELINE)
     unsigned long long tl[kTimelineMarks];
 #endif
@@ -155,6 +150,33 @@ struct TrajBase {
   int n_draw;
   int draw_base;  // first tree-draw index held in draw_u (-1: none)
   double draw_u;
+  // The span stack of the post-order walk (one entry per level: three buffer indices and two scalars, SpanW
+  // walnuts.hpp:34-131 reduced to what a merge reads) lives in the LANES of three registers -- entry l's weight and
+  // selected log density in lanes 2l, 2l+1 of a register pair, its buffer indices packed into lane l of a third --
+  // written with v_writelane and read with v_readlane at a wave-uniform index: no LDS round trip and no exec masking
+  // at a push, a pop hands the values to scalar registers directly.  (Every wavefront of a chain keeps its own copy.)
+  double stk_d;
+  int stk_i;
+  static_assert(kMaxLevels <= 32, "two doubles per level in the 64 lanes of a register pair");
+  __device__ __forceinline__ void stack_push(int sp, int in_th, int in_rh, int sel, double weight, double lpsel) {
+    // (indices are -2 .. kMaxPool-1: seven bits each, offset by two)
+    set_lane(stk_i, (in_th + 2) | ((in_rh + 2) << 7) | ((sel + 2) << 14), sp);
+    set_lane(stk_d, weight, 2 * sp);
+    set_lane(stk_d, lpsel, 2 * sp + 1);
+  }
+  __device__ __forceinline__ void stack_read(int sp, int& in_th, int& in_rh, int& sel, double& weight, double& lpsel) const {
+    const int packed = lane_value(stk_i, sp);
+    in_th = (packed & 127) - 2;
+    in_rh = ((packed >> 7) & 127) - 2;
+    sel = (packed >> 14) - 2;
+    weight = lane_value(stk_d, 2 * sp);
+    lpsel = lane_value(stk_d, 2 * sp + 1);
+  }
+  __device__ __forceinline__ void stack_buffers(int sp, int& in_th, int& in_rh) const {
+    const int packed = lane_value(stk_i, sp);
+    in_th = (packed & 127) - 2;
+    in_rh = ((packed >> 7) & 127) - 2;
+  }
   int err;
   // (`err` also carries kNoteExtensionFailed: the failure channel of device models, wn_params.h -- set where an
   // extension fails, in blocks that are cold already.  Anything finer -- a count of non-finite attempts kept in a
@@ -186,6 +208,8 @@ struct TrajBase {
     tid = (wave << 6) | lane;
     Dp = p.dim_padded;
     red_parity = 0;
+    stk_d = 0.0;
+    stk_i = 0;
     onchip_mask = ~0ull;
     tabs.load(lane);
     adam_err = 0.0;
@@ -322,14 +346,21 @@ struct TrajBase {
   }
 
   // ---- span pool: wave-uniform buffer indices over a 64-bit free mask ---------------------
+  // (no branch: an exhausted pool hands out buffer 0 and raises the error bit)
   __device__ __forceinline__ int alloc() {
-    if (WN_UNLIKELY(free_mask == 0ull)) {
-      err |= 1;
-      return 0;
-    }
-    const int b = uni(__builtin_ctzll(free_mask));
-    free_mask &= free_mask - 1ull;
+    const unsigned long long m = free_mask;
+    err |= static_cast<int>(m == 0ull);
+    const int b = uni(m != 0ull ? __builtin_ctzll(m) : 0);
+    free_mask = m & (m - 1ull);
     return b;
+  }
+  // alloc() when `want`, else `otherwise` (no branch either)
+  __device__ __forceinline__ int alloc_if(bool want, int otherwise) {
+    const unsigned long long m = free_mask;
+    err |= static_cast<int>(want && m == 0ull);
+    const int b = uni(m != 0ull ? __builtin_ctzll(m) : 0);
+    free_mask = want ? (m & (m - 1ull)) : m;
+    return want ? b : otherwise;
   }
   // long-lived vectors (accumulated span ends) take the highest free buffer so that the LDS-resident low
   // indices stay available for the short-lived span-stack entries
@@ -395,6 +426,19 @@ struct TrajBase {
     const int slot = next_draw_slot();
     return lane_value(draw_u, slot);
   }
+  // The register backend asks ONCE per doubling / leaf pair for the draws that stretch can consume (ensure_draws) and
+  // then takes them without a test each (uniform01_ready): a scalar branch costs a lone wavefront 15-30 cycles
+  // (tests/gpu_probes/branch_cost.hip), more than the lane read it guards.  Which index a draw has -- its counter in
+  // the stream -- does not depend on where a block of 64 starts.
+  __device__ __forceinline__ void ensure_draws(int need) {
+    const int j = uni(n_draw);
+    if (WN_UNLIKELY(draw_base < 0 || j + need > draw_base + kDrawCache)) refill_draws(j);
+  }
+  __device__ __forceinline__ double uniform01_ready() {
+    const int j = uni(n_draw);
+    ++n_draw;
+    return lane_value(draw_u, j - draw_base);
+  }
 
   // ---- span weights: combine (walnuts.hpp:368-387) in the linear domain ---------------------------------------------
   // The reference carries LOG weights: a leaf's is its joint log density, a merged span's the log_sum_exp of its halves
@@ -423,15 +467,28 @@ struct TrajBase {
       const double f = uni(wnd::dexp_weight(-x, uniform_tab()));  // exp(old reference - new reference)
       a_w = uni(a_w * f);
       pair_w = uni(pair_w * f);
-      for (int s = 0; s < sp; ++s) {
-        const double t = uni(meta->weight[s]) * f;
-        if (lane == 0) meta->weight[s] = t;
-      }
+      for (int s = 0; s < sp; ++s) set_lane(stk_d, uni(lane_value(stk_d, 2 * s) * f), 2 * s);
       w_ref = lj;
       return 1.0;
     }
     return uni(wnd::dexp_weight(x, uniform_tab()));
   }
+  // the weights of a pair of leaves, even leaf first -- leaf_weight() for one after the other, behind ONE test for the
+  // usual case that neither moves the reference (two independent chains of scalar maths side by side)
+  __device__ __forceinline__ void pair_weights(double lj_even, double lj_odd, int sp, double& a_w, double& w_even,
+                                               double& w_odd) {
+    const double xe = lj_even - w_ref, xo = lj_odd - w_ref;
+    if (WN_UNLIKELY(xe > kWeightRebase || xo > kWeightRebase)) {
+      double none = 0.0;
+      w_even = leaf_weight(lj_even, sp, a_w, none);
+      w_odd = leaf_weight(lj_odd, sp, a_w, w_even);
+      return;
+    }
+    w_even = uni(wnd::dexp_weight(xe, uniform_tab()));
+    w_odd = uni(wnd::dexp_weight(xo, uniform_tab()));
+  }
+  // free-mask bit of a buffer index; a symbolic (negative) index has none
+  __device__ __forceinline__ static unsigned long long pool_bit(int b) { return b >= 0 ? (1ull << b) : 0ull; }
 
   // adam.hpp:70-86, batched.  The reference updates Adam after every macro step (walnuts.hpp:335-338); nothing reads
   // its state before the NEXT transition (the step size is fixed at a transition's start, adaptive_walnuts.hpp:237),
@@ -742,12 +799,10 @@ struct TrajBase {
             nfar = 1;
           }
           if ((i & 3) == 3) {
-            far_th[1] = uni(meta->in_th[sp - 2]);
-            far_rh[1] = uni(meta->in_rh[sp - 2]);
+            stack_buffers(sp - 2, far_th[1], far_rh[1]);
             nfar = 2;
             if ((i & 7) == 7) {
-              far_th[2] = uni(meta->in_th[sp - 3]);
-              far_rh[2] = uni(meta->in_rh[sp - 3]);
+              stack_buffers(sp - 3, far_th[2], far_rh[2]);
               nfar = 3;
             }
           }
@@ -769,8 +824,9 @@ struct TrajBase {
         c_lpsel = leaf_lp;
         for (int l = 0; (i >> l) & 1; ++l) {
           --sp;
-          const int s_in_th = uni(meta->in_th[sp]), s_in_rh = uni(meta->in_rh[sp]), s_sel = uni(meta->sel[sp]);
-          const double s_w = uni(meta->weight[sp]), s_lpsel = uni(meta->lpsel[sp]);
+          int s_in_th, s_in_rh, s_sel;
+          double s_w, s_lpsel;
+          stack_read(sp, s_in_th, s_in_rh, s_sel, s_w, s_lpsel);
           WN_PHASE(kPhUturn);
           if (uturn_against(s_in_th, s_in_rh, fwd)) {  // walnuts.hpp:490-492
             ok = false;
@@ -808,13 +864,7 @@ struct TrajBase {
             c_in_rh = materialize(c_in_rh, true);
             c_sel = sel_is_inner ? c_in_th : materialize(c_sel, false);
           }
-          if (lane == 0) {
-            meta->in_th[sp] = c_in_th;
-            meta->in_rh[sp] = c_in_rh;
-            meta->sel[sp] = c_sel;
-            meta->weight[sp] = c_w;
-            meta->lpsel[sp] = c_lpsel;
-          }
+          stack_push(sp, c_in_th, c_in_rh, c_sel, c_w, c_lpsel);
           ++sp;
         }
       }

@@ -407,7 +407,12 @@ struct TrajBase {
     const auto& Q = cold();
     double u;
     if (WN_UNLIKELY(Q.rng_mode == kRngBuffer)) {
-      u = j < Q.u_stride ? Q.u_buf[static_cast<long long>(chain) * Q.u_stride + j] : 0.5;
+      // (no branch on the lane's index: a lane past the supplied variates reads the row's first one and discards it.
+      // A per-lane branch in here would make everything that meets at its join -- draw_base with it -- divergent in
+      // the compiler's eyes, and every test of draw_base in the tree loop a branch to be structurised)
+      const bool have = j < Q.u_stride;
+      const double fed_u = Q.u_buf[static_cast<long long>(chain) * Q.u_stride + (have ? j : 0)];
+      u = have ? fed_u : 0.5;
     } else {
       u = wnd::stream_uniform(Q.seed, Q.chain_offset + chain, transition_now(), wnd::kStreamTree,
                               static_cast<uint32_t>(j));

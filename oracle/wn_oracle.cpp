@@ -212,8 +212,14 @@ struct Model {
         const double ev = m.exp(-v);
         const double hd = 0.5 * static_cast<double>(D - 1);
         const double hev = 0.5 * ev;
-        logp = ((-(v * v) / 18.0) - hev * S) - hd * v;
-        g[0] = ((-v / 9.0) + hev * S) - hd;
+        if (m.mode == WNO_MATH_PORTABLE) {
+          // device arithmetic: the engine multiplies by the once-rounded reciprocals (wn_models.h)
+          logp = ((-(v * v) * (1.0 / 18.0)) - hev * S) - hd * v;
+          g[0] = ((-v * (1.0 / 9.0)) + hev * S) - hd;
+        } else {
+          logp = ((-(v * v) / 18.0) - hev * S) - hd * v;
+          g[0] = ((-v / 9.0) + hev * S) - hd;
+        }
         for (size_t i = 1; i < D; ++i) g[i] = -(x[i] * ev);
         break;
       }

@@ -1,6 +1,6 @@
 """CPU tier: the product's device maths header (walnuts_amd/csrc/wn_devmath.h), compiled for the host,
 against the oracle's independently written copy (bit for bit), libm (few ulp) and the Random123 known-answer
-vectors for Philox4x32-10."""
+vectors for Philox4x32 (7 and 10 rounds)."""
 import ctypes as C
 import os
 import subprocess
@@ -20,6 +20,9 @@ double p_pow(double x, double y) { return wnd::dpow_pos(x, y); }
 void p_sincospi(double a, double* s, double* c) { wnd::dsincospi(a, *s, *c); }
 void p_philox(const unsigned* c, const unsigned* k, unsigned* o) {
   wnd::U4 r = wnd::philox(c[0], c[1], c[2], c[3], k[0], k[1]); o[0]=r.x; o[1]=r.y; o[2]=r.z; o[3]=r.w; }
+void p_philox10(const unsigned* c, const unsigned* k, unsigned* o) {
+  wnd::U4 r = wnd::philox<10>(c[0], c[1], c[2], c[3], k[0], k[1]); o[0]=r.x; o[1]=r.y; o[2]=r.z; o[3]=r.w; }
+int p_rounds() { return wnd::kPhiloxRounds; }
 double p_uniform(unsigned long long seed, unsigned chain, unsigned t, unsigned stream, unsigned idx) {
   return wnd::stream_uniform(seed, chain, t, stream, idx); }
 void p_normal_pair(unsigned long long seed, unsigned chain, unsigned t, unsigned stream, unsigned pair, double* z) {
@@ -48,15 +51,21 @@ def shim(tmp_path_factory):
 
 
 def test_philox_known_answers(shim):
-    # Random123 kat_vectors, philox4x32 10 rounds
-    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
-            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
-            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
-             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
-    for ctr, key, want in kats:
-        c, k, o = (C.c_uint * 4)(*ctr), (C.c_uint * 2)(*key), (C.c_uint * 4)()
-        shim.p_philox(c, k, o)
-        assert tuple(o) == want
+    # Random123 kat_vectors: philox4x32 with 10 rounds (the round function) and with 7, the engine's stream generator
+    kats10 = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+              ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+              ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+               (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    kats7 = [((0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+             ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+             ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+              (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a))]
+    assert shim.p_rounds() == 7
+    for fn, kats in ((shim.p_philox10, kats10), (shim.p_philox, kats7)):
+        for ctr, key, want in kats:
+            c, k, o = (C.c_uint * 4)(*ctr), (C.c_uint * 2)(*key), (C.c_uint * 4)()
+            fn(c, k, o)
+            assert tuple(o) == want
 
 
 def test_exp_log_bitwise_equal_to_oracle_copy_and_close_to_libm(shim, oracle):

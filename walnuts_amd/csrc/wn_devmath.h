@@ -13,7 +13,7 @@
 // multiply-adds (wnd::fmad = one v_fma_f64, or libm's correctly rounded fma() on the host): half the instructions and
 // half the depth of the mul-then-add form, identical bits on both sides.
 // sin/cos kernels: Sun fdlibm 5.3 polynomial schemes and coefficients.
-// Generator: Philox4x32-10 (Salmon et al., SC'11).
+// Generator: Philox4x32-7 (Salmon et al., SC'11).
 #pragma once
 
 #include <stdint.h>
@@ -241,7 +241,7 @@ WND_HD void dsincospi(double a, double& sn, double& cs) {
 }
 
 // ---------------------------------------------------------------------------
-// Philox4x32-10
+// Philox4x32
 // ---------------------------------------------------------------------------
 struct U4 {
   uint32_t x, y, z, w;
@@ -257,9 +257,16 @@ WND_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
+// The engine's streams use SEVEN rounds (stream version 2, round 5): the fewest with which Philox4x32 passes the full
+// BigCrush battery (Salmon et al., SC'11, table 2; Random123 ships known answers for 7 and for 10 rounds, and
+// tests/test_portable_math.py checks both).  The momentum refresh is ~30 % of a headline transition's vector
+// instructions and the generator a third of that; v_mad_u64_u32 runs at half rate.  Version 1 (rounds 1-4) used ten.
+constexpr int kPhiloxRounds = 7;
+constexpr int kStreamVersion = 2;
+template <int ROUNDS = kPhiloxRounds>
 WND_HD U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int round = 0; round < 10; ++round) {
+  for (int round = 0; round < ROUNDS; ++round) {
     const uint64_t pa = static_cast<uint64_t>(0xD2511F53u) * c0;
     const uint64_t pb = static_cast<uint64_t>(0xCD9E8D57u) * c2;
     const uint32_t n0 = xor3(static_cast<uint32_t>(pb >> 32), c1, k0);

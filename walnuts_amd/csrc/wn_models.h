@@ -85,7 +85,12 @@ struct DiagNormalModel {  // examples/examples.cpp:20-31, params = 1 / sigma_sq
   }
 };
 
+// The device multiplies by the (once-rounded) reciprocals 1/18 and 1/9 where the definition divides: within an ulp of
+// the quotients, one instruction instead of the ~25 of a correctly rounded fp64 division, at every gradient evaluation
+// and every energy (as the diagonal normal does with 1/sigma^2; the oracle's device-order mode does the same, its
+// reference-order mode divides).
 struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the reference)
+  static constexpr double kInv18 = 1.0 / 18.0, kInv9 = 1.0 / 9.0;
   static constexpr int kKind = kFunnel;
   static constexpr bool kUsesParams = false;
   static constexpr bool kElementwise = false;  // the gradient needs sum(x^2): register backend only
@@ -112,7 +117,7 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       double gj = -(th[j] * ev);
-      if (cx.index(j) == 0) gj = ((-v / 9.0) + hev * S) - hd;
+      if (cx.index(j) == 0) gj = ((-v * kInv9) + hev * S) - hd;
       g[j] = cx.valid(j) ? gj : 0.0;
     }
     aux.v = v;
@@ -152,7 +157,7 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       double gj = -(th[j] * aux.ev);
-      if (cx.index(j) == 0) gj = ((-aux.v / 9.0) + aux.hev * aux.S) - hd;
+      if (cx.index(j) == 0) gj = ((-aux.v * kInv9) + aux.hev * aux.S) - hd;
       g[j] = cx.valid(j) ? gj : 0.0;
     }
   }
@@ -161,7 +166,7 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
                                                      const double (&)[2], const Aux&, double&) {}  // finish() has it all
   __device__ __forceinline__ static double finish(double, const Aux& a, int D) {
     const double hd = 0.5 * static_cast<double>(D - 1);
-    return ((-(a.v * a.v) / 18.0) - a.hev * a.S) - hd * a.v;
+    return ((-(a.v * a.v) * kInv18) - a.hev * a.S) - hd * a.v;
   }
   static void validate(int num_params) {
     if (num_params < 2) throw std::invalid_argument("funnel needs num_params >= 2");

@@ -237,7 +237,7 @@ struct TrajBase {
   __device__ __forceinline__ int dim() const { return P.dim; }
   __device__ __forceinline__ double element0(double mine) {
     // element 0 is slot 0 of thread 0
-    if (NW == 1) return __shfl(mine, 0, 64);
+    if (NW == 1) return lane_value(mine, 0);  // (v_readlane: a scalar, no LDS crossbar round trip)
     if (tid == 0) bcast[0] = mine;
     __syncthreads();
     const double v = bcast[0];

@@ -175,8 +175,13 @@ def measured_traffic(args, D, chains_local, transitions_per_average_launch):
                 args.model, chains_local, D, args.phase, max(1, args.transitions_per_launch)):
             if e.get("csrc_sha") == sha:
                 scale = transitions_per_average_launch / e.get("transitions_per_launch", 1)
+                # (the counter passes run ONE chain group so that a launch is one dispatch; the same chains do the same
+                # work in two concurrent kernels, so the bytes per launch carry over -- but say so)
+                groups = (f"; recorded with {e['chain_groups']} chain group(s) per launch, this run: "
+                          f"{os.environ.get('WALNUTS_AMD_CHAIN_GROUPS') or args.chain_groups or 'the engine default (2)'}"
+                          if "chain_groups" in e else "")
                 return e["bytes_per_launch"] * scale, ("RECORDED, not measured in this run (" + e["source"] +
-                                                        "; same source hash, same workload)")
+                                                        "; same source hash, same workload" + groups + ")")
             stale = f"stale PMC entry refused (recorded for csrc {e.get('csrc_sha')}, this build is {sha})"
     return None, stale or "this workload was not profiled"
 

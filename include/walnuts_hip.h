@@ -51,6 +51,9 @@ WALNUTS_HIP_EXPORT void walnutpie_destroy_error(WalnutpyError* err);
 
 /* progress callback: python/src/walnutpie/handlers.hpp:15 */
 typedef void (*PRINT_CALLBACK)(const char* msg, size_t len, bool bad);
+/* BridgeStan's print callback, as walnutpie_sample_bridgestan takes it (thirdparty/bridgestan/bridgestan.h:400,
+ * python/src/walnutpie/walnutpy.cpp:227-229) */
+typedef void (*STREAM_CALLBACK)(const char* data, size_t size);
 
 /* ---- the reference's host-model entry points: present, never sampling (see above) -------------
  * walnutpy.cpp:131-149 (LOGP_CFUNC model), :227-245 (BridgeStan model), :224-225 (the separator of
@@ -69,7 +72,7 @@ typedef int (*WN_LOGP_CFUNC)(size_t size, const double* theta, double* grad, dou
 WALNUTS_HIP_EXPORT int walnutpie_sample_cfunc(WN_LOGP_CFUNC logp_c, void* data, int num_params, const double* inits,
                                               WN_REFERENCE_SAMPLING_PARAMS);
 WALNUTS_HIP_EXPORT int walnutpie_sample_bridgestan(const char* bs_dll, const char* json_data,
-                                                   PRINT_CALLBACK callback, unsigned int model_seed,
+                                                   STREAM_CALLBACK callback, unsigned int model_seed,
                                                    const char* inits, WN_REFERENCE_SAMPLING_PARAMS);
 WALNUTS_HIP_EXPORT char walnutpie_separator_char(void);
 

@@ -45,8 +45,8 @@ ap.add_argument("--transitions-per-launch", type=int, default=bench.DEFAULT_TRAN
 known, _ = ap.parse_known_args("$ARGS".split())
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     json.dump({"model": known.model, "chains": known.chains, "dim": known.dim, "phase": known.phase,
-               "transitions_per_launch": max(1, known.transitions_per_launch), "csrc_sha": bench.csrc_sha(), "bytes_per_launch": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
-               "source": "profiles/${PROFILE_ROUND:-r04}/pmc_$TAG.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, last "
+               "transitions_per_launch": max(1, known.transitions_per_launch), "csrc_sha": bench.csrc_sha(), "chain_groups": 1, "bytes_per_launch": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
+               "source": "profiles/${PROFILE_ROUND:-r05}/pmc_$TAG.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, last "
                          "(steady-state) dispatch, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 note in MI355X_MICROARCH.md"},
               open("$OUT/traffic.json", "w"))
 if "SQ_WAVE_CYCLES" in vals:

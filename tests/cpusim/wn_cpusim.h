@@ -304,6 +304,10 @@ constexpr hipError_t hipSuccess = 0;
 inline const char* hipGetErrorString(hipError_t) { return "cpusim error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) {
+  *d = 0;
+  return hipSuccess;
+}
 inline hipError_t hipGetDeviceCount(int* n) {
   *n = 1;
   return hipSuccess;

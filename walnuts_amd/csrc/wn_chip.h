@@ -205,38 +205,20 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     }
   }
   __device__ __forceinline__ void lds_load(const WN_LDS double* base, double (&v)[EPL]) const {
-#if defined(WN_EXP_FILL_POP)
-    double fill0 = 1.0, fill1 = 1.0;  // (the same probe behind every ds_read_b128 of a pop)
-#endif
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const v2f64 t = *reinterpret_cast<const WN_LDS v2f64*>(base + (k * L + tid) * 2);
       v[2 * k] = t[0];
       v[2 * k + 1] = t[1];
-#if defined(WN_EXP_FILL_POP)
-#pragma unroll
-      for (int f = 0; f < WN_EXP_FILL_POP / 2; ++f)
-        asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1" : "+v"(fill0), "+v"(fill1) : : "memory");
-#endif
     }
   }
   __device__ __forceinline__ void lds_store(WN_LDS double* base, const double (&v)[EPL]) const {
-#if defined(WN_EXP_FILL_PUSH)
-    // probe (profiles/r04/headline_attempts.md, "are there idle issue slots under the span pool's LDS traffic"):
-    // WN_EXP_FILL_PUSH independent vector instructions behind every ds_write_b128 of a push
-    double fill0 = 1.0, fill1 = 1.0;
-#endif
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       v2f64 t;
       t[0] = v[2 * k];
       t[1] = v[2 * k + 1];
       *reinterpret_cast<WN_LDS v2f64*>(base + (k * L + tid) * 2) = t;
-#if defined(WN_EXP_FILL_PUSH)
-#pragma unroll
-      for (int f = 0; f < WN_EXP_FILL_PUSH / 2; ++f)
-        asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1" : "+v"(fill0), "+v"(fill1) : : "memory");
-#endif
     }
   }
   __device__ __forceinline__ void pool_load(int b, double (&v)[EPL]) {
@@ -921,20 +903,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
                                 this->gather_tab());
       }
     }
-#if defined(WN_EXP_REFRESH_TWICE)
-    // probe: what the momentum refresh costs where it stands (a second, discarded generation from another stream)
-    if (!fed) {
-      const uint64_t seed = Q.seed;
-      const uint32_t key_chain = Q.chain_offset + chain, key_tr = this->transition_now();
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        const uint32_t pair = static_cast<uint32_t>(k * L + tid);
-        double z0, z1;
-        wnd::stream_normal_pair(seed, key_chain, key_tr, wnd::kStreamMomentum + 7u, pair, z0, z1, this->gather_tab());
-        asm volatile("" : : "v"(z0), "v"(z1));
-      }
-    }
-#endif
     WN_MARK(kPhMomentum);
     this->finish_tuning(warm);
     WN_MARK(kPhTuned);

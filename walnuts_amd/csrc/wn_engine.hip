@@ -281,6 +281,7 @@ struct wn_engine {
       for (int g = 1; g < groups; ++g) HIP_OK(hipStreamWaitEvent(gstream[g], main_point, 0));
       main_moved = false;
     }
+    std::pair<hipEvent_t, hipEvent_t>* timed = timing ? &next_events() : nullptr;
     for (int g = 0; g < groups; ++g) {
       // The chain counter is never reset: every launch performs exactly as many fetches as it has chains (one per
       // processed chain), so a group's launch n starts at n * its chain count (mod 2^32) -- one memset per transition
@@ -293,16 +294,10 @@ struct wn_engine {
       P.arena = arena.p + static_cast<size_t>(g) * static_cast<size_t>(grid) * static_cast<size_t>(arena_stride);
       hipStream_t s = g == 0 ? stream : gstream[g];
       try {
-        if (timing && g == 0) {  // HIP events around the launch: only between wn_engine_timing_reset and the read-back
-          auto& ev = next_events();
-          HIP_OK(hipEventRecord(ev.first, s));
-          wn::launch_transition(model, geo, group_grid[g], smem, s, P);
-          HIP_OK(hipGetLastError());
-          HIP_OK(hipEventRecord(ev.second, s));
-        } else {
-          wn::launch_transition(model, geo, group_grid[g], smem, s, P);
-          HIP_OK(hipGetLastError());
-        }
+        // (per-launch HIP events: only between wn_engine_timing_reset and the read-back)
+        if (timing && g == 0) HIP_OK(hipEventRecord(timed->first, s));
+        wn::launch_transition(model, geo, group_grid[g], smem, s, P);
+        HIP_OK(hipGetLastError());
       } catch (...) {
         // a launch that did not happen fetched nothing: counter and base start over together (a kernel that did start
         // and then failed leaves the device in an error state anyway; the memset then fails too and is ignored)
@@ -315,6 +310,12 @@ struct wn_engine {
         HIP_OK(hipEventRecord(gdone[g], s));
         groups_ahead = true;
       }
+    }
+    if (timing) {
+      // the launch has ended when its LAST kernel has: the end event waits for every group (per-launch timing is a
+      // diagnostic mode -- it joins the groups' streams at every launch, which the plain mode never does)
+      for (int g = 1; g < groups; ++g) HIP_OK(hipStreamWaitEvent(stream, gdone[g], 0));
+      HIP_OK(hipEventRecord(timed->second, stream));
     }
     ++region_launches;
     variates_pending = false;

@@ -206,13 +206,22 @@ class Prefault {
     for (int t = 0; t < n; ++t) {
       const uintptr_t a = lo + pages * static_cast<size_t>(t) / static_cast<size_t>(n) * page;
       const uintptr_t b = lo + pages * static_cast<size_t>(t + 1) / static_cast<size_t>(n) * page;
+      try {
       workers_.emplace_back([a, b, this] {
         // in slices, so that a call that ends early (an error, Ctrl-C) does not wait for gigabytes of faults
         uintptr_t slice = uintptr_t{256} << 20;
-        if (const char* env = std::getenv("WALNUTS_AMD_PREFAULT_SLICE_KB")) slice = static_cast<uintptr_t>(std::atoll(env)) << 10;
+        if (const char* env = std::getenv("WALNUTS_AMD_PREFAULT_SLICE_KB")) {
+          // (at least one page: a zero or non-numeric value would leave the loop below spinning in place)
+          const long long kb = std::atoll(env);
+          slice = std::max<uintptr_t>(static_cast<uintptr_t>(sysconf(_SC_PAGESIZE)),
+                                      static_cast<uintptr_t>(kb > 0 ? kb : 0) << 10);
+        }
         for (uintptr_t p = a; p < b && !stop_.load(std::memory_order_relaxed); p += slice)
           if (madvise(reinterpret_cast<void*>(p), static_cast<size_t>(std::min(slice, b - p)), MADV_POPULATE_WRITE) != 0) return;
       });
+      } catch (...) {  // no thread to be had: the pages are then populated by whoever writes them first
+        break;
+      }
     }
 #else
     (void)ptr, (void)bytes;
@@ -252,7 +261,8 @@ class BounceRing {
       : device_(device), C_(chains), rows_(rows), D_(dim), out_(out), copy_(copy) {
     const size_t per_chain = span * D_ * sizeof(double);
     cc_ = std::max<size_t>(1, std::min(C_, kChunkBytes / std::max<size_t>(1, per_chain)));
-    if (cc_ * per_chain > 4 * kChunkBytes) return;  // one chain's rows alone are too large for a chunk: direct copies
+    // one chain's rows alone are larger than a chunk (the ring would pin kRing times that): direct copies
+    if (cc_ * per_chain > kChunkBytes) return;
     for (int k = 0; k < kRing; ++k) {
       void* p = nullptr;
       if (hipHostMalloc(&p, cc_ * per_chain, hipHostMallocDefault) != hipSuccess) {
@@ -266,11 +276,18 @@ class BounceRing {
         return;
       }
     }
-    usable_ = true;
-    dispatcher_ = std::thread([this] { dispatch(); });
     int nworkers = kWorkers;
     if (const char* env = std::getenv("WALNUTS_AMD_BOUNCE_WORKERS")) nworkers = std::max(1, std::atoi(env));
-    for (int w = 0; w < nworkers; ++w) workers_.emplace_back([this] { work(); });
+    try {
+      dispatcher_ = std::thread([this] { dispatch(); });
+      for (int w = 0; w < nworkers; ++w) workers_.emplace_back([this] { work(); });
+      usable_ = true;
+    } catch (...) {
+      // a thread could not be started: stop and join the ones that were (a joinable std::thread must not be destroyed)
+      // and leave the ring unusable -- the sink then copies directly, as it does for outputs too small for the ring
+      shut_down(true);
+      release();
+    }
   }
   BounceRing(const BounceRing&) = delete;
   BounceRing& operator=(const BounceRing&) = delete;
@@ -1169,7 +1186,7 @@ extern "C" int walnutpie_sample_cfunc(WN_LOGP_CFUNC, void*, int, const double*, 
   (void)refresh, (void)print;
   return refuse_host_model("walnutpie_sample_cfunc", err);
 }
-extern "C" int walnutpie_sample_bridgestan(const char*, const char*, PRINT_CALLBACK, unsigned int, const char*,
+extern "C" int walnutpie_sample_bridgestan(const char*, const char*, STREAM_CALLBACK, unsigned int, const char*,
                                            WN_REFERENCE_SAMPLING_PARAMS) {
   (void)num_chains, (void)seed, (void)id, (void)init_radius, (void)init_inv_metric, (void)min_warmup_iter;
   (void)max_warmup_iter, (void)min_sampling_iter, (void)max_sampling_iter, (void)max_trajectory_doublings;
@@ -1309,6 +1326,11 @@ static int sample_multi_impl(const ResidentRequest* resident, WN_SAMPLE_PARAMS_N
       // gather: shard s's [count_s][S][D] block is rows [begin_s, begin_s + count_s) of the whole [C][S][D] block
       const size_t S = static_cast<size_t>(max_sampling_iter);
       const int dev0 = devices[0];
+      struct RestoreDevice {  // the gather selects devices[0]: the calling thread gets its current device back
+        int before = -1;
+        RestoreDevice() { if (hipGetDevice(&before) != hipSuccess) before = -1; }
+        ~RestoreDevice() { if (before >= 0) (void)hipSetDevice(before); }
+      } restore_device;
       if (hipSetDevice(dev0) != hipSuccess) throw std::runtime_error("cannot select the device");
       DevBlock whole;
       if (!whole.alloc(num_chains * S * D)) throw std::runtime_error("cannot allocate the gathered draw block");

@@ -1509,14 +1509,21 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     }
     const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(this->warmup_iter_now()));
     const double wd = discount * w_draw0 + 1, ws = discount * w_score0 + 1;
+    double* const out = P.draws_out != nullptr ? this->draw_row() : nullptr;
+    // a draw row on a 16-byte boundary takes whole pairs (streamed: written once, read by nobody here); the pair that
+    // straddles the end of an odd-length row, or a row at an odd offset, goes element by element
+    const bool pair_rows = (reinterpret_cast<unsigned long long>(out) & 15ull) == 0ull;
     for (int k = 0; k < tiles; ++k) {
       const int o = pair_offset(k);
       const v2f64 t0 = ld(sel + o);
       st(P.theta + row + o, t0[0], t0[1]);
-      if (P.draws_out != nullptr) {
-        double* out = this->draw_row();
-        if (o < P.dim) out[o] = t0[0];
-        if (o + 1 < P.dim) out[o + 1] = t0[1];
+      if (out != nullptr) {
+        if (pair_rows && o + 1 < P.dim) {
+          stream_store(t0, reinterpret_cast<v2f64*>(out + o));
+        } else {
+          if (o < P.dim) stream_store(t0[0], &out[o]);
+          if (o + 1 < P.dim) stream_store(t0[1], &out[o + 1]);
+        }
       }
       if (warm) {  // adaptive_walnuts.hpp:247-248, online_moments.hpp:184-191
         double th2[2] = {t0[0], t0[1]}, g2[2], mp2[2] = {1.0, 1.0};

@@ -37,28 +37,33 @@ class WalnutsOutputArray(np.ndarray):  # python/src/walnutpie/pyfunc.py (ndarray
 
 
 class ChainResults(Sequence):
-    """The per-chain results of a call with MANY chains, built on access: ``results[c]`` is what the reference's list
-    holds at index c (pyfunc.py:270-286: the chain's sampling draws as an array carrying ``.warmup``).  Creating 65 536
-    array views and WarmupInfo objects up front costs 0.2 s -- more than the 0.14 s the device needs for 20 + 32
-    iterations of 65 536 x 1 024 (profiles/r04/sample_device_e2e.txt) -- so beyond ``LIST_LIMIT`` chains the call returns
-    this sequence (len, indexing, slicing, iteration, ``list(results)``) instead of a list."""
-
-    LIST_LIMIT = 4096
+    """The per-chain results of a call with MANY chains, built on access (``walnuts_device(..., lazy_results=True)``):
+    ``results[c]`` is what the reference's list holds at index c (pyfunc.py:270-286: the chain's sampling draws as an
+    array carrying ``.warmup``).  Creating 65 536 array views and WarmupInfo objects up front costs 0.2 s -- more than
+    the 0.14 s the device needs for 20 + 32 iterations of 65 536 x 1 024 (profiles/r04/sample_device_e2e.txt).  A
+    read-only sequence (len, indexing, slicing, iteration, ``list(results)``); an item is built once and kept, so
+    ``results[c] is results[c]``.  The default of ``walnuts_device`` is the reference's plain list."""
 
     def __init__(self, make, n):
-        self._make, self._n = make, n
+        self._make, self._n, self._built = make, n, {}
 
     def __len__(self):
         return self._n
 
+    def _item(self, c):
+        item = self._built.get(c)
+        if item is None:
+            item = self._built[c] = self._make(c)
+        return item
+
     def __getitem__(self, i):
         if isinstance(i, slice):
-            return [self._make(c) for c in range(*i.indices(self._n))]
+            return [self._item(c) for c in range(*i.indices(self._n))]
         if i < 0:
             i += self._n
         if not 0 <= i < self._n:
             raise IndexError("chain index out of range")
-        return self._make(i)
+        return self._item(i)
 
 
 def _prepare_output_buffer(*, num_chains, num_params, max_sampling_iter, max_warmup_iter, save_warmup):
@@ -124,6 +129,7 @@ def walnuts_device(
     keep_on_device: bool = False,
     thin: int = 0,
     devices=None,
+    lazy_results: bool = False,
     lib_path: Optional[str] = None,
     print_callback=None,
 ):
@@ -232,9 +238,8 @@ def walnuts_device(
             n_samp = 0 if thin == 0 else -(-n_samp // thin)
         return WalnutsOutputArray(out[c, n_warm:n_warm + n_samp], info)
 
-    # a list, as the reference returns it; for very many chains the same thing built on access (ChainResults)
-    results = (ChainResults(result_of, num_chains) if num_chains > ChainResults.LIST_LIMIT
-               else [result_of(c) for c in range(num_chains)])
+    # a list, as the reference returns it (pyfunc.py:270-286); on request the same thing built on access
+    results = ChainResults(result_of, num_chains) if lazy_results else [result_of(c) for c in range(num_chains)]
     if timing:
         print(f"[walnuts_amd] {'C entry point (all phases above)':34s} {(t_done - t_call) * 1e3:9.3f} ms\n"
               f"[walnuts_amd] {'per-chain result objects (Python)':34s} {(time.perf_counter() - t_done) * 1e3:9.3f} ms",

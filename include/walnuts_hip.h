@@ -233,6 +233,20 @@ WALNUTS_HIP_EXPORT void wn_default_config(wn_config* cfg);
  * (walnuts_amd/csrc/wn_model_api.h; INTEGRATION.md "Adding a device model").  -> the id registered under `name`
  * ("std_normal" 0, "diag_normal" 1, "funnel" 2, "rw1" 3, ...), or -1. */
 WALNUTS_HIP_EXPORT int wn_model_id(const char* name);
+/* Device models compiled at RUN time -- the device counterpart of handing the reference a host callable
+ * (LOGP_CFUNC / a numba cfunc: python/src/walnutpie/walnutpy.cpp:131-132, pyfunc.py:216).  The model's five-line
+ * translation unit is compiled against the installed headers (walnuts_amd/csrc) into a shared object of its own
+ * (walnuts_amd.build_device_model: one hipcc -shared with -DWN_MODEL_PLUGIN and the ONE launch geometry
+ * wn_geometry_for() names); loading that object (dlopen / ctypes.CDLL) runs its static initialiser, which enters the
+ * model into THIS library's registry through wn_plugin_register_model.  wn_model_id(name) then resolves it and every
+ * entry point takes the id.  A failed registration (id taken, headers of another build) is kept in wn_model_error()
+ * and reported by the next wn_engine_create as a `config` error. */
+WALNUTS_HIP_EXPORT int wn_plugin_register_model(const void* model_ops, const void* model_abi);
+WALNUTS_HIP_EXPORT const char* wn_model_error(void);
+WALNUTS_HIP_EXPORT void wn_model_clear_error(void);
+WALNUTS_HIP_EXPORT int wn_geometry_for(int num_params, int waves_per_chain, int elems_per_lane,
+                                       int preferred_elems_per_lane, int* waves_out, int* elems_per_lane_out,
+                                       int* streaming_out, WalnutpyError** err);
 
 /* model_params: host pointer (copied). */
 WALNUTS_HIP_EXPORT int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params,

@@ -23,7 +23,7 @@ CFG_FIELDS = ("max_trajectory_doublings", "max_step_halvings", "min_micro_steps"
 
 
 def model_params(model: str, D: int):
-    if model != "diag_normal":
+    if model not in ("diag_normal", "user_diag"):   # (user_diag: tests/test_runtime_model.py)
         return None
     return np.array([(1.0 + (d % 16)) ** 2 for d in range(D)])  # sigma_d = 1 + (d mod 16), SURVEY.md §8d cfg4
 

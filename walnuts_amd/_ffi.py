@@ -88,6 +88,10 @@ SYMBOLS = [
     ("walnutpie_mcse", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("wn_default_config", None, [C.POINTER(Config)]),
     ("wn_model_id", _i32, [C.c_char_p]),
+    ("wn_plugin_register_model", _i32, [_vp, _vp]),
+    ("wn_model_error", C.c_char_p, []),
+    ("wn_model_clear_error", None, []),
+    ("wn_geometry_for", _i32, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _errpp]),
     ("wn_engine_create", _i32, [C.POINTER(_vp), _i32, _i32, _dp, _sz, C.POINTER(Config), _errpp]),
     ("wn_engine_destroy", None, [_vp]),
     ("wn_engine_set_positions", _i32, [_vp, _dp, _errpp]),

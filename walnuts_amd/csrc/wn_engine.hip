@@ -549,6 +549,38 @@ int wn_model_id(const char* name) {
   return -1;
 }
 
+// ---- device models compiled at run time (walnuts_amd/models.py; INTEGRATION.md "Adding a device model") --------------
+// the registration of a model's own shared object, called from its static initialiser when it is loaded
+int wn_plugin_register_model(const void* ops, const void* abi) {
+  const auto* theirs = static_cast<const wn::ModelAbi*>(abi);
+  const wn::ModelAbi ours = wn::model_abi();
+  const auto* m = static_cast<const wn::ModelOps*>(ops);
+  if (theirs == nullptr || m == nullptr || theirs->version != ours.version || theirs->sizeof_ops != ours.sizeof_ops ||
+      theirs->sizeof_params != ours.sizeof_params || theirs->sizeof_geometry != ours.sizeof_geometry) {
+    wn::registry_error() = "a device model was compiled against other headers than this library (wn_launch.h "
+                           "kModelAbiVersion / struct sizes differ): rebuild it with walnuts_amd.build_device_model";
+    return -1;
+  }
+  return wn::register_model_here(m) ? 0 : -1;
+}
+// what went wrong in the last registration ("" if nothing has); the message stays until the next failure
+const char* wn_model_error(void) { return wn::registry_error().c_str(); }
+// forget a failed registration (a run-time model whose id was taken is reported once, not by every later engine)
+void wn_model_clear_error(void) { wn::registry_error().clear(); }
+// The launch geometry an engine for `num_params` parameters would use (waves_per_chain / elems_per_lane: a wn_config's
+// requests, 0 = the engine's choice; preferred_elems_per_lane: the model's kPreferredElemsPerLane, 0 = none) -- a
+// model built at run time instantiates exactly this one.  *streaming: the vectors live in HBM (elems_per_lane is 0).
+int wn_geometry_for(int num_params, int waves_per_chain, int elems_per_lane, int preferred_elems_per_lane, int* nw,
+                    int* epl, int* streaming, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (num_params < 1) throw std::invalid_argument("num_params must be positive");
+    const wn::Geometry g = wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, false, preferred_elems_per_lane);
+    if (nw != nullptr) *nw = g.nw;
+    if (epl != nullptr) *epl = g.epl;
+    if (streaming != nullptr) *streaming = g.mem ? 1 : 0;
+  });
+}
+
 // WALNUTS_AMD_FMA=0/1 overrides the library default (fused) for callers that do not build a wn_config themselves
 // (walnutpie_sample_device keeps the reference's argument list)
 static int default_fma() {

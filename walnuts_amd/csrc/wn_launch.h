@@ -21,7 +21,13 @@ struct Geometry {
 };
 
 // X(NW) -- wavefronts per chain of the streaming kernels
-#if defined(WN_SIM_GEOMETRIES)
+// (WN_ONLY_*: a device model compiled at run time -- walnuts_amd/models.py -- instantiates the ONE geometry its engine
+// will launch, which the library names through wn_geometry_for(): seconds of hipcc instead of minutes)
+#if defined(WN_ONLY_MEM_NW)
+#define WN_FOR_EACH_MEM_GEOMETRY(X) X(WN_ONLY_MEM_NW)
+#elif defined(WN_ONLY_NW)
+#define WN_FOR_EACH_MEM_GEOMETRY(X)
+#elif defined(WN_SIM_GEOMETRIES)
 #define WN_FOR_EACH_MEM_GEOMETRY(X) X(1) X(2) X(4)
 #elif defined(WN_FAST_BUILD)
 #define WN_FOR_EACH_MEM_GEOMETRY(X) X(4)
@@ -46,7 +52,11 @@ inline int default_mem_waves() {
 constexpr int kMaxRegisterDim = 8192;
 
 // X(NW, EPL) -- the register kernels (TrajChip, wn_chip.h)
-#if defined(WN_SIM_GEOMETRIES)  // tests/cpusim: a cross-section (the headline's (1, 16) and its neighbours included)
+#if defined(WN_ONLY_NW)
+#define WN_FOR_EACH_GEOMETRY(X) X(WN_ONLY_NW, WN_ONLY_EPL)
+#elif defined(WN_ONLY_MEM_NW)
+#define WN_FOR_EACH_GEOMETRY(X)
+#elif defined(WN_SIM_GEOMETRIES)  // tests/cpusim: a cross-section (the headline's (1, 16) and its neighbours included)
 #define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(1, 4) X(2, 2) X(1, 16) X(2, 8) X(4, 4) X(8, 8)
 #elif defined(WN_FAST_BUILD)
 #define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(4, 4) X(2, 8) X(1, 16)
@@ -159,7 +169,20 @@ inline std::string& registry_error() {
   static std::string msg;
   return msg;
 }
-inline bool register_model(const ModelOps* ops) {
+// Everything a separately compiled model and the library must agree on: the layout of what crosses the boundary.
+constexpr int kModelAbiVersion = 5;
+struct ModelAbi {
+  int version;
+  unsigned sizeof_ops, sizeof_params, sizeof_geometry;
+};
+}  // namespace wn
+// A device model compiled at RUN time (walnuts_amd/models.py: one hipcc -shared of its five-line translation unit
+// against these headers) is a shared object of its own; when it is loaded, its registration lands in the LIBRARY's
+// registry through this exported entry point (wn_engine.hip) -- the device counterpart of handing the reference a
+// LOGP_CFUNC / numba cfunc (python/src/walnutpie/walnutpy.cpp:131-132, pyfunc.py:216).  -> 0, or -1 (wn_model_error()).
+extern "C" __attribute__((visibility("default"))) int wn_plugin_register_model(const void* ops, const void* abi);
+namespace wn {
+inline bool register_model_here(const ModelOps* ops) {
   if (ops->id < 0 || ops->id >= kMaxModels) {
     registry_error() = std::string("device model '") + ops->name + "': WN_MODEL_ID " + std::to_string(ops->id) +
                        " is out of range (0 <= id < " + std::to_string(kMaxModels) + ")";
@@ -173,6 +196,18 @@ inline bool register_model(const ModelOps* ops) {
   model_table()[ops->id] = ops;
   return true;
 }
+inline ModelAbi model_abi() {
+  return ModelAbi{kModelAbiVersion, static_cast<unsigned>(sizeof(ModelOps)), static_cast<unsigned>(sizeof(Params)),
+                  static_cast<unsigned>(sizeof(Geometry))};
+}
+#if defined(WN_MODEL_PLUGIN)
+inline bool register_model(const ModelOps* ops) {  // (a static initialiser of the model's shared object)
+  const ModelAbi abi = model_abi();
+  return wn_plugin_register_model(ops, &abi) == 0;
+}
+#else
+inline bool register_model(const ModelOps* ops) { return register_model_here(ops); }
+#endif
 inline const ModelOps& model_ops(int model) {
   if (model < 0 || model >= kMaxModels || model_table()[model] == nullptr)
     throw std::invalid_argument("unknown device model id");

@@ -1,0 +1,98 @@
+"""Device models compiled at run time -- the device counterpart of handing the reference a host callable.
+
+The reference takes any host function as a model: a ``LOGP_CFUNC`` pointer, a numba cfunc or a ctypes trampoline
+(python/src/walnutpie/pyfunc.py:45-286, :216; walnutpy.cpp:131-132).  A host function cannot be called from a
+GPU-resident trajectory, so here a model is a header of static device functions (``walnuts_amd/csrc/wn_model_api.h``)
+that is compiled INTO the transition kernels.  ``build_device_model`` does that at call time, without touching
+``libwalnuts_hip.so``: it writes the model's five-line translation unit, compiles it against the installed headers
+(``walnuts_amd/csrc``) with one ``hipcc -shared`` -- instantiating only the ONE launch geometry the engine will use
+for ``num_params`` parameters (``wn_geometry_for``), which takes seconds where the whole table takes minutes -- and
+``load_device_model`` loads the result; the shared object's static initialiser enters the model into the library's
+registry (``wn_plugin_register_model``).  From then on ``model_id(name)`` resolves it and every entry point takes it.
+"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+from typing import Optional, Sequence
+
+from . import _ffi
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+# the flags the library itself is built with (walnuts_amd/csrc/Makefile): same arithmetic (-ffp-contract=off), same code
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+               "-mllvm", "-structurizecfg-skip-uniform-regions=1"]
+_loaded = {}   # path -> CDLL (kept alive: the registry holds pointers into the object)
+
+
+def translation_unit(header: str, type_name: str, tag: str, model_id: int) -> str:
+    """The five lines that enter a model into the registry (wn_model_api.h, "Registration")."""
+    return (f'#include "{os.path.basename(header)}"\n#define WN_MODEL_ID {int(model_id)}\n#define WN_MODEL_TAG {tag}\n'
+            f"#define WN_MODEL_TYPE {type_name}\n" '#include "wn_kernels.inc"\n')
+
+
+def geometry_for(num_params: int, *, waves_per_chain: int = 0, elems_per_lane: int = 0,
+                 preferred_elems_per_lane: int = 0, lib_path: Optional[str] = None):
+    """-> (waves per chain, elements per lane, streaming?) of the engine's kernel for ``num_params`` parameters."""
+    lib = _ffi.load_library(lib_path)
+    nw, epl, mem, err = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
+    _ffi.check(lib, lib.wn_geometry_for(num_params, waves_per_chain, elems_per_lane, preferred_elems_per_lane,
+                                        C.byref(nw), C.byref(epl), C.byref(mem), C.byref(err)), err)
+    return nw.value, epl.value, bool(mem.value)
+
+
+def geometry_defines(nw: int, epl: int, streaming: bool) -> Sequence[str]:
+    return [f"-DWN_ONLY_MEM_NW={nw}"] if streaming else [f"-DWN_ONLY_NW={nw}", f"-DWN_ONLY_EPL={epl}"]
+
+
+def build_device_model(header: str, type_name: str, tag: str, model_id: int, num_params: int, *,
+                       out_dir: Optional[str] = None, waves_per_chain: int = 0, elems_per_lane: int = 0,
+                       preferred_elems_per_lane: int = 0, lib_path: Optional[str] = None,
+                       compiler: Optional[Sequence[str]] = None, extra_flags: Sequence[str] = ()) -> str:
+    """Compile the model in ``header`` (a struct ``type_name`` implementing wn_model_api.h) for engines of
+    ``num_params`` parameters -> path of its shared object (pass it to :func:`load_device_model`).
+
+    ``tag`` is the name ``model_id(tag)`` will find, ``model_id`` its registry slot (4..63; 0-3 are the built-in
+    models).  ``waves_per_chain`` / ``elems_per_lane``: the same requests a ``wn_config`` can make (0 = the engine's
+    choice); ``preferred_elems_per_lane``: the model's ``kPreferredElemsPerLane`` if it states one.  An engine created
+    with other requests than the ones given here finds no kernel and says so.  ``compiler``: the command in front of
+    the flags (default ``["hipcc"] + HIPCC_FLAGS``; the CPU test tier passes g++ with the emulation's flags)."""
+    header = os.path.abspath(header)
+    lib_file = os.path.abspath(lib_path or os.environ.get("WALNUTS_AMD_LIB") or _ffi.DEFAULT_LIB)
+    nw, epl, streaming = geometry_for(num_params, waves_per_chain=waves_per_chain, elems_per_lane=elems_per_lane,
+                                      preferred_elems_per_lane=preferred_elems_per_lane, lib_path=lib_path)
+    out_dir = out_dir or tempfile.mkdtemp(prefix="wn_model_")
+    os.makedirs(out_dir, exist_ok=True)
+    src = os.path.join(out_dir, f"wn_kernels_{tag}.hip")
+    with open(src, "w") as f:
+        f.write(translation_unit(header, type_name, tag, model_id))
+    geo = f"mem{nw}" if streaming else f"{nw}x{epl}"
+    out = os.path.join(out_dir, f"libwn_model_{tag}_{geo}.so")
+    cmd = list(compiler) if compiler is not None else ["hipcc"] + HIPCC_FLAGS
+    cmd += ["-DWN_MODEL_PLUGIN", *geometry_defines(nw, epl, streaming), "-I", CSRC, "-I", os.path.dirname(header),
+            *extra_flags, "-shared", src, "-o", out,
+            # the registration call resolves against the library the engines come from
+            "-L", os.path.dirname(lib_file), "-l:" + os.path.basename(lib_file),
+            "-Wl,-rpath," + os.path.dirname(lib_file)]
+    done = subprocess.run(cmd, capture_output=True, text=True)
+    if done.returncode != 0:
+        raise _ffi.WalnutsHipError("compiling the device model failed:\n" + " ".join(cmd) + "\n" + done.stderr[-4000:])
+    return out
+
+
+def load_device_model(path: str, tag: str, *, lib_path: Optional[str] = None) -> int:
+    """Load a model built by :func:`build_device_model` -> its id (what ``model_id(tag)`` returns from now on)."""
+    lib = _ffi.load_library(lib_path)
+    path = os.path.abspath(path)
+    if path not in _loaded:
+        lib.wn_model_clear_error()
+        _loaded[path] = C.CDLL(path)   # (its static initialiser calls wn_plugin_register_model)
+        msg = lib.wn_model_error()
+        if msg:
+            text = msg.decode("utf-8", "replace")
+            lib.wn_model_clear_error()
+            raise ValueError(text)
+    mid = lib.wn_model_id(tag.encode())
+    if mid < 0:
+        raise ValueError(f"{path} did not register a device model named {tag!r}")
+    return mid

@@ -74,6 +74,10 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   static constexpr bool kLateLogp = kNoGrad && Model::kElementwise;
   static constexpr bool kHasStartState = true;
   static constexpr bool kZeroCopy = false;
+  // The transition's initial point is loaded into -- and its result left in -- set 1: the first doubling's single leaf
+  // then runs 1 -> 0 and ends where every later leaf pair starts (the moving end is set 0 at pair boundaries) without
+  // the copy of two vectors that a 0 -> 1 leaf needed.
+  static constexpr int kI = 1;
   // values that live long and are read rarely sit in accumulator registers -- in the kernels built for one or two
   // wavefronts per SIMD; the others name no accumulator register (wn_gfx950.h: PlainDouble)
   static constexpr bool kPark = chip_waves_per_simd<Model, EPL>() <= 2;
@@ -597,7 +601,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     {
       double part = begin_transition(row, warm);
       double ke;
-      energy_partials<0>(part, ke);
+      energy_partials<kI>(part, ke);
       this->sum2(part, ke);
       finish_energy(part, ke, lp_pos, lj);
     }
@@ -610,17 +614,17 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     if (kOtherRegs) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
-        park(oth[j], th[0][j]);
-        park(orh[j], rh[0][j]);
+        park(oth[j], th[kI][j]);
+        park(orh[j], rh[kI][j]);
       }
       a_sel = kOther;
     } else {
       o_th = this->alloc_cold();
       o_rh = this->alloc_cold();
       o_g = kNoGrad ? -1 : this->alloc_cold();
-      pool_store(o_th, th[0]);
-      pool_store(o_rh, rh[0]);
-      if (!kNoGrad) pool_store(o_g, g[0]);
+      pool_store(o_th, th[kI]);
+      pool_store(o_rh, rh[kI]);
+      if (!kNoGrad) pool_store(o_g, g[kI]);
       a_sel = o_th;
     }
     // (a_w: the accumulated span's weight -- wn_traj.h, "span weights"; the initial point weighs exactly 1)
@@ -694,17 +698,11 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       int c_in_th = kHot, c_in_rh = kHot, c_sel = kHot;
       double c_w = 0.0, c_lpsel = 0.0;
       if (kFirst) {
-        // a single leaf: its U-turn test against the span's other end (= the initial point, still in set 0 when
-        // the leaf is done) rides in the leaf's reduction
+        // a single leaf, from the initial point in set 1 into set 0: its U-turn test against the span's other end (= the
+        // initial point, still in set 1 when the leaf is done) rides in the leaf's reduction
         double leaf_lp, leaf_lj;
-        ok = macro_step<0, true>(fwd, h_cur, leaf_lp, leaf_lj, top_turned);
+        ok = macro_step<kI, true>(fwd, h_cur, leaf_lp, leaf_lj, top_turned);
         if (WN_LIKELY(ok)) {
-#pragma unroll
-          for (int j = 0; j < EPL; ++j) {
-            th[0][j] = th[1][j];
-            rh[0][j] = rh[1][j];
-            if (!kNoGrad) g[0][j] = g[1][j];
-          }
           h_cur = leaf_lj;
           double none = 0.0;
           c_w = this->leaf_weight(leaf_lj, 0, a_w, none);
@@ -877,9 +875,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     // lane), and only then is anything loaded looked at -- the round trips to HBM hide behind the generator.
     this->request_tuning(warm);
     // (a launch runs Params::fused transitions of the chain back to back: after the first one the position is the
-    // selected state the previous epilogue left in set 0, and the frozen inverse mass is still in its registers)
+    // selected state the previous epilogue left in set 1, and the frozen inverse mass is still in its registers)
     const bool first_of_launch = this->fuse_t == 0;
-    if (first_of_launch) vload_stream(Q.theta + row, th[0]);
+    if (first_of_launch) vload_stream(Q.theta + row, th[kI]);
     if (Model::kUsesParams) vload(Q.model_params, mp);
     double ds[EPL], ss[EPL];  // warmup: the estimator's two sums of squared deviations; sampling: ds = cholesky_mass
     if (warm) {
@@ -892,14 +890,14 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     WN_MARK(kPhLoadsIssued);
     const bool fed = Q.rng_mode == kRngBuffer;
     if (WN_UNLIKELY(fed)) {
-      vload_stream(Q.z_buf + row, rh[0]);
+      vload_stream(Q.z_buf + row, rh[kI]);
     } else {
       const uint64_t seed = Q.seed;
       const uint32_t key_chain = Q.chain_offset + chain, key_tr = this->transition_now();
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const uint32_t pair = static_cast<uint32_t>(k * L + tid);
-        wnd::stream_normal_pair(seed, key_chain, key_tr, wnd::kStreamMomentum, pair, rh[0][2 * k], rh[0][2 * k + 1],
+        wnd::stream_normal_pair(seed, key_chain, key_tr, wnd::kStreamMomentum, pair, rh[kI][2 * k], rh[kI][2 * k + 1],
                                 this->gather_tab());
       }
     }
@@ -920,10 +918,10 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         // when this was measured (round 2): 2.22 ms / 3.7 GB streamed against 2.27 ms / 3.15 GB recomputed.
         chol = ds[j];
       }
-      const double r = chol * rh[0][j];
-      rh[0][j] = (fed || valid(j)) ? r : 0.0;
+      const double r = chol * rh[kI][j];
+      rh[kI][j] = (fed || valid(j)) ? r : 0.0;
     }
-    return model_eval<0>();
+    return model_eval<kI>();
   }
 
   __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
@@ -943,23 +941,23 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     }
     if (kOtherRegs && a_sel == kOther) {
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) th[0][j] = fetch(oth[j]);
+      for (int j = 0; j < EPL; ++j) th[kI][j] = fetch(oth[j]);
     } else {
-      pool_load(a_sel, th[0]);
+      pool_load(a_sel, th[kI]);
     }
     WN_MARK(kPhSelLoaded);
     // the position plane is read again by the NEXT launch only: the launch's last transition of the chain writes it
-    if (this->fuse_t + 1 >= Q.fused) vstore_stream(Q.theta + row, th[0]);
+    if (this->fuse_t + 1 >= Q.fused) vstore_stream(Q.theta + row, th[kI]);
     double* draws = Q.draws_out;
     if (WN_LIKELY(draws != nullptr)) {
       double* out = this->draw_row();
       // an unpadded row on a 16-byte boundary takes the pair stores; anything else goes element by element
       if (WN_LIKELY(P.dim == kDp && ((reinterpret_cast<unsigned long long>(out) & 15ull) == 0ull))) {
-        vstore_stream(out, th[0]);
+        vstore_stream(out, th[kI]);
       } else {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-          if (valid(j)) stream_store(th[0][j], &out[index(j)]);
+          if (valid(j)) stream_store(th[kI][j], &out[index(j)]);
         }
       }
     }
@@ -968,7 +966,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       // function of theta_sel, so it is re-evaluated instead of being carried through the tree.
       if constexpr (!kNoGrad) {
         const long long keep_grad = n_grad;
-        (void)model_eval<0>();
+        (void)model_eval<kI>();
         n_grad = keep_grad;
       }
       const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(this->warmup_iter_now()));
@@ -976,15 +974,15 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       const double ws = discount * w_score0 + 1;
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {  // online_moments.hpp:184-191 (lazy delta => (y - mean_new)^2)
-        mean[j] += (th[0][j] - mean[j]) / wd;
-        ssd[j] = discount * ssd[j] + (th[0][j] - mean[j]) * (th[0][j] - mean[j]);
+        mean[j] += (th[kI][j] - mean[j]) / wd;
+        ssd[j] = discount * ssd[j] + (th[kI][j] - mean[j]) * (th[kI][j] - mean[j]);
       }
       vstore_stream(Q.est_draw_mean + row, mean);
       vstore_stream(Q.est_draw_ssd + row, ssd);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
-        smean[j] += (G<0>(j) - smean[j]) / ws;
-        sssd[j] = discount * sssd[j] + (G<0>(j) - smean[j]) * (G<0>(j) - smean[j]);
+        smean[j] += (G<kI>(j) - smean[j]) / ws;
+        sssd[j] = discount * sssd[j] + (G<kI>(j) - smean[j]) * (G<kI>(j) - smean[j]);
       }
       vstore_stream(Q.est_score_mean + row, smean);
       vstore_stream(Q.est_score_ssd + row, sssd);

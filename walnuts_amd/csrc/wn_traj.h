@@ -159,10 +159,11 @@ struct TrajBase {
   int stk_i;
   static_assert(kMaxLevels <= 32, "two doubles per level in the 64 lanes of a register pair");
   __device__ __forceinline__ void stack_push(int sp, int in_th, int in_rh, int sel, double weight, double lpsel) {
-    // (indices are -2 .. kMaxPool-1: seven bits each, offset by two)
-    set_lane(stk_i, (in_th + 2) | ((in_rh + 2) << 7) | ((sel + 2) << 14), sp);
-    set_lane(stk_d, weight, 2 * sp);
-    set_lane(stk_d, lpsel, 2 * sp + 1);
+    // (indices are -2 .. kMaxPool-1: seven bits each, offset by two; one lane id for the three selects)
+    const int me = opaque_lane_id();
+    const int packed = (in_th + 2) | ((in_rh + 2) << 7) | ((sel + 2) << 14);
+    stk_i = me == sp ? packed : stk_i;
+    stk_d = me == 2 * sp ? weight : (me == 2 * sp + 1 ? lpsel : stk_d);
   }
   __device__ __forceinline__ void stack_read(int sp, int& in_th, int& in_rh, int& sel, double& weight, double& lpsel) const {
     const int packed = lane_value(stk_i, sp);

@@ -620,6 +620,12 @@ def main():
                         # rho in and out and the inverse mass in, the element-wise gradient recomputed = 40*D
                         "design_bytes": {"per_grad_eval_per_dim": 40, "GBps": algorithmic_gbps * 40.0 / 56.0,
                                          "frac": algorithmic_gbps * 40.0 / 56.0 / HBM_PEAK_GBPS},
+                        # a model whose gradient needs sums over all coordinates or its neighbours (funnel, rw1) takes
+                        # TWO passes per micro step: theta, rho and the inverse mass in and theta, rho out in the
+                        # first, theta, rho in and rho out in the second = 72*D by design
+                        "two_pass_floor": ({"per_grad_eval_per_dim": 72, "GBps": algorithmic_gbps * 72.0 / 56.0,
+                                            "frac": algorithmic_gbps * 72.0 / 56.0 / HBM_PEAK_GBPS}
+                                           if args.model in ("funnel", "rw1") else None),
                         "note": "achieved / frac price the launch at SURVEY.md section 8(d)'s 56*D bytes per grad-eval (theta, "
                                 "rho, gradient and inverse mass read; theta, rho, gradient written).  The one-pass streaming "
                                 "kernel never stores a gradient (element-wise: recomputed) and, when it fits, keeps the "

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): the round's bench lines of every BASELINE configuration + the rocprofv3
-# kernel trace of the headline.  Outputs land in gpurun_out/$PROFILE_ROUND/ (default r04); PMC passes are profiles/pmc.sh's.
+# kernel trace of the headline.  Outputs land in gpurun_out/$PROFILE_ROUND/ (default r05); PMC passes are profiles/pmc.sh's.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-R=${PROFILE_ROUND:-r04}
+R=${PROFILE_ROUND:-r05}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -33,7 +33,7 @@ python3 $ROOT/profiles/summarize.py $R $(find $OUT/headline_trace -name "*result
 rm -rf $OUT/headline_trace
 # the whole drop-in call, phase by phase (WALNUTS_AMD_TIMING), and a longer run of the randomised parity campaign
 (cd $ROOT && WALNUTS_AMD_TIMING=1 timeout 900 python3 tests/gpu_probes/sample_device_e2e.py > $OUT/sample_device_e2e.txt 2>&1)
-(cd $ROOT && timeout 600 python3 tests/gpu_probes/fuzz_parity.py --seconds 240 --seed 404 > $OUT/fuzz_parity.txt 2>&1; tail -3 $OUT/fuzz_parity.txt)
+(cd $ROOT && timeout 600 python3 tests/gpu_probes/fuzz_parity.py --seconds 240 --seed 506 > $OUT/fuzz_parity.txt 2>&1; tail -3 $OUT/fuzz_parity.txt)
 for f in $OUT/bench_*.json; do python3 -c "
 import json,sys
 d=json.load(open('$f')); r=d['roofline']

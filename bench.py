@@ -610,16 +610,19 @@ def main():
         streaming = bool(eng.streaming)
         traffic, traffic_source = measured_traffic(args, D, C, args.steps / max(launches, 1))
         if streaming:
+            design_b = 16.0 if eng.held_tiles > 0 else 40.0
             roofline = {"bound": "hbm", "achieved": algorithmic_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": algorithmic_gbps / HBM_PEAK_GBPS, "traffic": traffic,
                         "traffic_source": traffic_source,
                         "traffic_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                         "kernel": "wn::transition_kernel_mem", "avg_launch_ms": avg_kernel_ms, "avg_launch_ms_from": timing_method,
                         "algorithmic_bytes_per_launch": algorithmic_bytes,
-                        # the same launch priced on what a one-pass streaming kernel has to move by design: theta and
-                        # rho in and out and the inverse mass in, the element-wise gradient recomputed = 40*D
-                        "design_bytes": {"per_grad_eval_per_dim": 40, "GBps": algorithmic_gbps * 40.0 / 56.0,
-                                         "frac": algorithmic_gbps * 40.0 / 56.0 / HBM_PEAK_GBPS},
+                        # the same launch priced on what the kernel has to move by design.  Both ends streamed: theta
+                        # and rho in and out and the inverse mass in, the element-wise gradient recomputed = 40*D.  The
+                        # moving end held in registers, the inverse mass in LDS (engine.held_tiles > 0): only the new
+                        # state goes out = 16*D (the U-turn tests' far ends come on top in either case)
+                        "design_bytes": {"per_grad_eval_per_dim": design_b, "GBps": algorithmic_gbps * design_b / 56.0,
+                                         "frac": algorithmic_gbps * design_b / 56.0 / HBM_PEAK_GBPS},
                         # a model whose gradient needs sums over all coordinates or its neighbours (funnel, rw1) takes
                         # TWO passes per micro step: theta, rho and the inverse mass in and theta, rho out in the
                         # first, theta, rho in and rho out in the second = 72*D by design
@@ -630,7 +633,8 @@ def main():
                                 "rho, gradient and inverse mass read; theta, rho, gradient written).  The one-pass streaming "
                                 "kernel never stores a gradient (element-wise: recomputed) and, when it fits, keeps the "
                                 "inverse mass in LDS for the whole transition, so it moves 32-40*D plus the U-turn tests' "
-                                "span ends: frac can exceed 1 on the 56*D definition.  The bandwidth actually drawn is "
+                                "span ends -- 16*D plus those where the trajectory's moving end stays in registers "
+                                "(geometry.held_tiles > 0) --: frac exceeds 1 on the 56*D definition.  The bandwidth actually drawn is "
                                 "traffic_frac (rocprofv3 PMC; part of it served by the 256 MiB Infinity Cache); models "
                                 "whose gradient needs two passes per micro step (funnel, rw1) move 72*D"}
         else:
@@ -671,7 +675,8 @@ def main():
                                                        f"{args.gather_every} launch(es), one collective per block of {T} draw planes" if world > 1 else ""),
                 "geometry": {"lanes_per_chain": eng.lanes, "dim_padded": eng.dim_padded,
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
-                             "reserved_cus": reserved, "chain_groups": groups},
+                             "reserved_cus": reserved, "chain_groups": groups,
+                             "held_tiles": eng.held_tiles if eng.streaming else 0},
                 "grad_evals_per_transition_per_chain": grad_evals / max(args.steps, 1) / C,
                 "transitions_per_launch": T, "launches": launches,
                 "arithmetic": ("fused multiply-adds in the integrator (as an FMA-target build of the reference)"

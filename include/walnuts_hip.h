@@ -362,6 +362,8 @@ WALNUTS_HIP_EXPORT int wn_engine_warmup_max_rel(wn_engine* e, double sum_log_ste
 WALNUTS_HIP_EXPORT int wn_engine_lanes(const wn_engine* e);        /* L = 64*NW: the reduction width   */
 WALNUTS_HIP_EXPORT int wn_engine_dim_padded(const wn_engine* e);   /* Dp                                */
 WALNUTS_HIP_EXPORT int wn_engine_is_streaming(const wn_engine* e); /* 1: vectors streamed from HBM      */
+WALNUTS_HIP_EXPORT int wn_engine_held_tiles(const wn_engine* e);   /* streaming: pairs per lane of the moving end
+                                                                      kept in registers (0: both ends streamed) */
 WALNUTS_HIP_EXPORT int wn_engine_workgroups(const wn_engine* e);   /* persistent grid size              */
 WALNUTS_HIP_EXPORT int wn_engine_chain_groups(const wn_engine* e); /* concurrent kernels per transition launch */
 WALNUTS_HIP_EXPORT int wn_engine_lds_vectors(const wn_engine* e);  /* pool vectors resident in LDS      */

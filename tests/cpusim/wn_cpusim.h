@@ -289,6 +289,10 @@ inline double wave_sum_packed(double a, double b) {  // a's total in lanes 0-31,
 inline int opaque_scalar_add(int a, int b) { return a + b; }
 inline double opaque_uniform(double v) { return v; }
 inline void launder(double&) {}
+using GlobalBytes = char*;
+inline GlobalBytes opaque_scalar_pointer(const void* p) { return const_cast<char*>(static_cast<const char*>(p)); }
+inline v2f64 load_pair_at(GlobalBytes base, unsigned byte_offset) { return *reinterpret_cast<const v2f64*>(base + byte_offset); }
+inline void store_pair_at(GlobalBytes base, unsigned byte_offset, v2f64 v) { *reinterpret_cast<v2f64*>(base + byte_offset) = v; }
 inline int opaque_lane_id() { return static_cast<int>(wnsim::tidx.x & 63u); }
 inline int wave_in_workgroup() { return static_cast<int>(wnsim::tidx.x >> 6); }
 template <class T>

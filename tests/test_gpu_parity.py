@@ -66,7 +66,9 @@ def _need_gpu(gpu):
     ("rw1", 1024, 48, None),                # 4th model, added through csrc/models/rw1.h: neighbour-coupled gradient
     ("rw1", 200, 64, (2, 2)),               # ... wavefront edges through LDS
     ("rw1", 2000, 16, (4, 8)),               # ... pair-row wrap-around across four wavefronts
-    ("diag_normal", 16384, 12, None),       # config #4 dimension: streaming backend (vectors in HBM)
+    ("diag_normal", 16384, 12, None),       # config #4 dimension: streaming backend, the moving end held in registers
+    ("diag_normal", 16384, 8, (16, -1)),    # ... sixteen wavefronts streaming both ends (the kernels beyond 16 384 dimensions)
+    ("std_normal", 12100, 6, None),         # held moving end, 12 of the 16 tiles, the last one ragged
     ("std_normal", 20000, 8, (8, -1)),      # streaming, 8 wavefronts per chain, ragged last tile
     ("std_normal", 1000, 24, (2, -1)),      # streaming forced at a small dimension
     ("diag_normal", 5000, 12, (16, -1)),

@@ -64,6 +64,9 @@ def test_emulated_engine_matches_oracle(sim, oracle, model, D, geometry, fma):
     ("funnel", 16384, (2, -1), 1),        # streaming, two passes per micro step
     ("rw1", 12000, (4, -1), 2),           # streaming with halo reads
     ("std_normal", 20000, (2, -1), 1),    # ragged last tile
+    ("diag_normal", 2048, (1, -1), 2),    # streaming with the moving end held in registers: all 16 tiles in use
+    ("std_normal", 3900, (2, -1), 1),     # ... 16 tiles, the last one ragged
+    ("diag_normal", 1100, (1, -1), 1),    # ... 9 of the 16
 ])
 def test_emulated_full_size_geometries(sim, oracle, model, D, geometry, fused, fma):
     """The geometries the benchmarks run at -- the headline's (1, 16) at 1 024 dimensions, its multi-wavefront

@@ -136,6 +136,7 @@ SYMBOLS = [
     ("wn_engine_is_streaming", _i32, [_vp]),
     ("wn_engine_workgroups", _i32, [_vp]),
     ("wn_engine_chain_groups", _i32, [_vp]),
+    ("wn_engine_held_tiles", _i32, [_vp]),
     ("wn_engine_lds_vectors", _i32, [_vp]),
     ("wn_engine_iteration", _i64, [_vp]),
     ("wn_engine_stream", _vp, [_vp]),

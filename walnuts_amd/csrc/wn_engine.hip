@@ -47,6 +47,7 @@ struct wn_engine {
   int pool_lds = 0, pool_total = 0;
   bool im_in_lds = false;  // streaming kernels: the chain's inverse mass parked in LDS (wn_traj.h: TrajMem::im_lds)
   bool no_far_end_sums = false;  // experiment switch (WALNUTS_AMD_NO_FAR_END_SUMS=1)
+  bool hold_moving_end = false;  // streaming kernels: the moving end's (theta, rho) stay in registers (TrajMem, HOLD)
   int64_t arena_stride = 0;  // doubles per persistent workgroup: HBM part of the span pool (+ streaming scratch)
   size_t smem = 0;
   hipStream_t stream = nullptr;
@@ -250,7 +251,7 @@ struct wn_engine {
     P.arena = arena.p;
     P.arena_stride = arena_stride;
     P.pool_lds = pool_lds;
-    P.im_in_lds = (im_in_lds ? 1u : 0u) | (no_far_end_sums ? 2u : 0u);
+    P.im_in_lds = (im_in_lds ? 1u : 0u) | (no_far_end_sums ? 2u : 0u) | (hold_moving_end ? 4u : 0u);
     P.pool_total = pool_total;
     P.work_counter = counter.p;
     P.error_flags = error_flags.p;
@@ -388,7 +389,8 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.C = num_chains;
   e.cfg = cfg;
   e.device = cfg.device;
-  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params, ops.preferred_epl);
+  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params, ops.preferred_epl,
+                              ops.hold_tiles(wn::kHeldWaves));
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
@@ -403,6 +405,11 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
     throw std::invalid_argument("max_trajectory_doublings needs more span-pool vectors than the device free mask holds");
   const int wps = wn::waves_per_simd(model, e.geo);
   int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo, wps);
+  // a streaming kernel that can hold the moving end in registers wants the CU -- its LDS for the inverse mass, a
+  // wavefront's full register budget -- for ONE chain
+  const int hold_tiles = e.geo.mem ? ops.hold_tiles(e.geo.nw) : 0;
+  const bool hold_fits = hold_tiles > 0 && num_params <= 2 * 64 * e.geo.nw * hold_tiles;
+  if (hold_fits && cfg.workgroups_per_cu <= 0) wg_per_cu = 1;
   wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
   if (!e.geo.mem) wg_per_cu = std::min(wg_per_cu, std::max(1, 4 * wps / e.geo.nw));
   const size_t fixed = wn::transition_smem_bytes(e.geo.nw, 0, e.Dp);
@@ -422,6 +429,11 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
     if (e.smem + vec_bytes <= budget && !(off != nullptr && off[0] == '1')) {
       e.im_in_lds = true;
       e.smem += vec_bytes;
+      // ... and, if the chain's vectors fit the registers the kernels set aside for it, the moving end (TrajMem, HOLD)
+      const char* nh = std::getenv("WALNUTS_AMD_NO_HELD_STATE");
+      const size_t tables = sizeof(double) * wn::kLdsTableDoubles;  // (such a kernel keeps the exp / log tables in LDS too)
+      e.hold_moving_end = hold_fits && e.smem + tables <= budget && !(nh != nullptr && nh[0] == '1');
+      if (e.hold_moving_end) e.smem += tables;
     }
   }
   const int usable_cus = std::max(1, e.num_cus - std::max(0, cfg.reserved_cus));
@@ -447,7 +459,10 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   {
     int want = cfg.chain_groups;
     if (const char* v = std::getenv("WALNUTS_AMD_CHAIN_GROUPS")) want = std::atoi(v);
-    if (want <= 0) want = num_chains > static_cast<size_t>(e.grid) ? 2 : 1;
+    // (... and one when a CU holds a single workgroup of this kernel -- the streaming kernels with the inverse mass in
+    // LDS --: the second group's workgroups then start only as the first group's retire, i.e. two tails instead of one;
+    // config #4 measured 15.3 ms per step with one group against 15.9 ms with two)
+    if (want <= 0) want = (num_chains > static_cast<size_t>(e.grid) && !(e.geo.mem && wg_per_cu == 1)) ? 2 : 1;
     e.groups = std::max(1, std::min({want, wn_engine::kMaxGroups, static_cast<int>(num_chains)}));
   }
   for (int g = 0; g <= e.groups; ++g) e.group_begin[g] = num_chains * static_cast<size_t>(g) / static_cast<size_t>(e.groups);
@@ -996,6 +1011,9 @@ int wn_engine_is_streaming(const wn_engine* e) { return e->geo.mem ? 1 : 0; }
 int wn_engine_dim_padded(const wn_engine* e) { return e->Dp; }
 int wn_engine_workgroups(const wn_engine* e) { return e->grid; }
 int wn_engine_chain_groups(const wn_engine* e) { return e->groups; }
+int wn_engine_held_tiles(const wn_engine* e) {
+  return (e->geo.mem && e->hold_moving_end) ? wn::model_ops(e->model).hold_tiles(e->geo.nw) : 0;
+}
 int wn_engine_lds_vectors(const wn_engine* e) { return e->pool_lds; }
 int64_t wn_engine_iteration(const wn_engine* e) { return e->iteration; }
 void* wn_engine_stream(const wn_engine* e) { return reinterpret_cast<void*>(e->stream); }
@@ -1095,7 +1113,7 @@ int wn_engine_release_stream(wn_engine* e, void* stream, WalnutpyError** err) {
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {
   try {
     return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, wn::model_ops(model).uses_params,
-                                    wn::model_ops(model).preferred_epl).nw;
+                                    wn::model_ops(model).preferred_epl, wn::model_ops(model).hold_tiles(wn::kHeldWaves)).nw;
   } catch (...) {
     return -1;
   }

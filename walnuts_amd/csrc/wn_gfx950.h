@@ -155,6 +155,27 @@ __device__ __forceinline__ double opaque_uniform(double v) {
   asm volatile("" : "+v"(b));  // (a vector register: an "s" operand fails to compile where the value sits in one)
   return double_of(b);
 }
+// a wave-uniform pointer into global memory, pinned in a scalar register pair the optimiser cannot see through: address
+// arithmetic on it stays "scalar base + vector offset" instead of being re-associated into per-lane 64-bit addresses
+// (the address space is kept: the accesses stay global_load / global_store)
+using GlobalBytes = __attribute__((address_space(1))) char*;
+using GlobalV2 = __attribute__((address_space(1))) v2f64*;
+__device__ __forceinline__ GlobalBytes opaque_scalar_pointer(const void* p) {
+  // (readfirstlane: nothing when the value already sits in scalar registers, which is where a uniform pointer usually
+  // is; where the allocator kept it in vector registers an "s" operand alone does not compile)
+  const unsigned long long bits = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(bits >> 32));
+  GlobalBytes g = (GlobalBytes)((static_cast<unsigned long long>(hi) << 32) | lo);
+  asm volatile("" : "+s"(g));
+  return g;
+}
+__device__ __forceinline__ v2f64 load_pair_at(GlobalBytes base, unsigned byte_offset) {
+  return *reinterpret_cast<GlobalV2>(base + byte_offset);
+}
+__device__ __forceinline__ void store_pair_at(GlobalBytes base, unsigned byte_offset, v2f64 v) {
+  *reinterpret_cast<GlobalV2>(base + byte_offset) = v;
+}
 // "this register may have changed" as far as the optimiser can tell (no instruction): what is computed from it cannot
 // be hoisted across this point
 __device__ __forceinline__ void launder(double& v) { asm volatile("" : "+v"(v)); }

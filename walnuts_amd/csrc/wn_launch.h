@@ -23,7 +23,9 @@ struct Geometry {
 // X(NW) -- wavefronts per chain of the streaming kernels
 // (WN_ONLY_*: a device model compiled at run time -- walnuts_amd/models.py -- instantiates the ONE geometry its engine
 // will launch, which the library names through wn_geometry_for(): seconds of hipcc instead of minutes)
-#if defined(WN_ONLY_MEM_NW)
+#if defined(WN_ONLY_MEM_NW) && defined(WN_ONLY_MEM_NW_ALSO)  // (the default streaming choice depends on the model: both)
+#define WN_FOR_EACH_MEM_GEOMETRY(X) X(WN_ONLY_MEM_NW) X(WN_ONLY_MEM_NW_ALSO)
+#elif defined(WN_ONLY_MEM_NW)
 #define WN_FOR_EACH_MEM_GEOMETRY(X) X(WN_ONLY_MEM_NW)
 #elif defined(WN_ONLY_NW)
 #define WN_FOR_EACH_MEM_GEOMETRY(X)
@@ -50,6 +52,11 @@ inline int default_mem_waves() {
   return best;
 }
 constexpr int kMaxRegisterDim = 8192;
+// Streaming kernels of kHeldWaves wavefronts per chain keep the moving end of the trajectory in registers (wn_traj.h,
+// TrajMem HOLD) for models whose gradient takes one pass, up to hold_tiles x 2 x 64 x kHeldWaves dimensions (16 384):
+// measured on config #4 1.65e7 gradient evaluations per second against 1.05e7 for sixteen wavefronts streaming both
+// ends (profiles/r05).  They are the default where they apply.
+constexpr int kHeldWaves = 8;
 
 // X(NW, EPL) -- the register kernels (TrajChip, wn_chip.h)
 #if defined(WN_ONLY_NW)
@@ -75,12 +82,14 @@ inline bool geometry_exists(int nw, int epl) {
 }
 
 // elems_per_lane == -1 requests the streaming backend explicitly (it is the default above kMaxRegisterDim)
+// held_tiles: the model's ModelOps::hold_tiles(kHeldWaves) -- 0 for a model without such kernels (or not known yet)
 inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool params_in_registers = false,
-                                int preferred_epl = 0) {
+                                int preferred_epl = 0, int held_tiles = 0) {
   Geometry g{0, 0, false};
   if (epl_req < 0 || (dim > kMaxRegisterDim && epl_req == 0)) {
     g.mem = true;
-    g.nw = nw_req > 0 ? nw_req : default_mem_waves();
+    const bool held = held_tiles > 0 && dim <= 2 * 64 * kHeldWaves * held_tiles && mem_geometry_exists(kHeldWaves);
+    g.nw = nw_req > 0 ? nw_req : held ? kHeldWaves : default_mem_waves();
     if (!mem_geometry_exists(g.nw)) throw std::invalid_argument("unsupported waves_per_chain for the streaming kernels");
     return g;
   }
@@ -156,6 +165,7 @@ struct ModelOps {
   int (*waves_per_simd)(const Geometry&);
   void (*host_params)(double* params, int num_params);  // validate / transform the parameter vector before upload
   void (*validate)(int num_params);
+  int (*hold_tiles)(int nw);  // streaming kernels of nw wavefronts: tiles of the moving end held in registers (0: none)
 };
 constexpr int kMaxModels = 64;
 inline const ModelOps** model_table() {
@@ -170,7 +180,7 @@ inline std::string& registry_error() {
   return msg;
 }
 // Everything a separately compiled model and the library must agree on: the layout of what crosses the boundary.
-constexpr int kModelAbiVersion = 5;
+constexpr int kModelAbiVersion = 6;
 struct ModelAbi {
   int version;
   unsigned sizeof_ops, sizeof_params, sizeof_geometry;

@@ -9,7 +9,11 @@ constexpr int kMaxLevels = 16;   // span-stack levels => max_trajectory_doubling
 constexpr int kMaxPool = 64;     // vector buffers per resident chain (free mask is 64 bits)
 constexpr int kDrawCache = 64;    // tree draws (and their logs) produced per refill, one per lane
 #if defined(WN_TIMELINE)
+#if defined(WN_TIMELINE_MARKS)  // (the streaming probe: every wavefront's scratch carries the array, beside 128 KB of inverse mass)
+constexpr int kTimelineMarks = WN_TIMELINE_MARKS;
+#else
 constexpr int kTimelineMarks = 1536;
+#endif
 constexpr int kMetaDoubles = 128 + kTimelineMarks + 8;
 #else
 constexpr int kMetaDoubles = 128;
@@ -81,7 +85,8 @@ struct Params {
   uint32_t* work_counter;  // chains fetched so far by all launches of this engine (mod 2^32; never reset)
   uint32_t work_base;      // its value when this launch starts
   uint32_t im_in_lds;      // streaming kernels: bit 0 = the chain's inverse mass is parked in LDS for the whole
-                           // transition; bit 1 = (experiment switch) no far-end sums in the leaf's pass
+                           // transition; bit 1 = (experiment switch) no far-end sums in the leaf's pass; bit 2 = the
+                           // vectors fit the registers a kernel with a held moving end has for them (TrajMem, HOLD)
   int32_t chain_begin;    // first chain of this launch
   int32_t pad3;
   uint32_t* error_flags;  // OR of kErr* bits of every chain and transition since wn_engine_check last read (and cleared) it

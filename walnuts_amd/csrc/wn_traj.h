@@ -76,6 +76,21 @@ struct GatherTab {  // every lane has its own argument
   __device__ __forceinline__ double logc(int i) const { return __shfl(t.lc, i, 64); }
 };
 
+// The same tables as 3 x 64 doubles in LDS (the streaming kernels with a held moving end, TrajMem HOLD): those kernels
+// fill their registers in the leaf passes, values that live for the whole kernel are spilled there, and a reload from
+// scratch waits -- vmcnt counts in order -- behind every store the pass has just issued.  An LDS read does not.
+constexpr int kLdsTableDoubles = 3 * 64;
+struct LdsTables {
+  const WN_LDS double* t;  // [0, 64) exp2, [64, 128) rcp, [128, 192) logc (entries past 48 repeat entry 48)
+  __device__ __forceinline__ double exp2(int j) const { return t[j]; }
+  __device__ __forceinline__ double rcp(int i) const { return t[64 + i]; }
+  __device__ __forceinline__ double logc(int i) const { return t[128 + i]; }
+};
+template <class S, class = void>
+struct tables_in_lds : std::false_type {};
+template <class S>
+struct tables_in_lds<S, std::enable_if_t<S::kTablesInLds>> : std::true_type {};
+
 // ---- optional timeline probe (tests/gpu_probes/timeline.py only; compiled out of the product build) -------------
 #if defined(WN_TIMELINE)
 // tests/gpu_probes only: (shader clock, mark id) pairs of workgroup 0's transitions, kept in LDS and copied out when
@@ -188,8 +203,11 @@ struct TrajBase {
   int min_micro;
   typename Model::Aux aux;
   LaneTables tabs;
-  __device__ __forceinline__ UniformTab uniform_tab() const { return UniformTab{tabs}; }
-  __device__ __forceinline__ GatherTab gather_tab() const { return GatherTab{tabs}; }
+  // (a backend may keep the tables elsewhere: make_uniform_tab / make_gather_tab of the derived class)
+  __device__ __forceinline__ auto uniform_tab() const { return static_cast<const Self*>(this)->make_uniform_tab(); }
+  __device__ __forceinline__ auto gather_tab() const { return static_cast<const Self*>(this)->make_gather_tab(); }
+  __device__ __forceinline__ UniformTab make_uniform_tab() const { return UniformTab{tabs}; }
+  __device__ __forceinline__ GatherTab make_gather_tab() const { return GatherTab{tabs}; }
 
   __device__ __forceinline__ Self& self() { return *static_cast<Self*>(this); }
 
@@ -212,7 +230,7 @@ struct TrajBase {
     stk_d = 0.0;
     stk_i = 0;
     onchip_mask = ~0ull;
-    tabs.load(lane);
+    if constexpr (!tables_in_lds<Self>::value) tabs.load(lane);
     adam_err = 0.0;
     adam_n = 0;
     fuse_t = 0;
@@ -706,7 +724,7 @@ struct TrajBase {
   // one MCMC transition (walnuts.hpp:520-563 wrapped as adaptive_walnuts.hpp:234-251 or
   // walnuts.hpp:682-692)
   // ------------------------------------------------------------------------------------
-  __device__ void run(int chain_id) {
+  __device__ __forceinline__ void run(int chain_id) {
     WN_PHASE(kPhPrologue);
     chain = chain_id;
     err = 0;
@@ -718,6 +736,7 @@ struct TrajBase {
     const long long row = static_cast<long long>(chain) * Dp;
     const bool warm = P.warmup != 0;
     load_tuning(warm);
+    WN_MARK(kPhTuned);
 
     // momentum refresh + initial point (walnuts.hpp:528-535)
     double lp_pos, lj;
@@ -913,8 +932,10 @@ struct TrajBase {
     WN_PHASE(kPhEpilogue);
     // ---- selected state out (walnuts.hpp:560-562), estimator update (adaptive_walnuts.hpp:247-248) ----
     self().finish_transition(a_sel, row, warm);
+    WN_MARK(kPhSelLoaded);
     if (warm && wave == 0) adam_flush();
     store_scalars(warm, depth, a_lpsel);
+    WN_MARK(kPhScalars);
   }
 };
 
@@ -946,9 +967,31 @@ struct StreamTraits<M, false> {
   static constexpr int kSums = M::kStreamSums > 0 ? M::kStreamSums : 1;
 };
 
-template <class Model, int NW, bool FMA = false>
-struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
-  using Base = TrajBase<TrajMem<Model, NW, FMA>, Model, NW>;
+// The momentum refresh's standard normals (walnuts.hpp:528-531 through util.hpp:102: element pair k * L + tid of the
+// kStreamMomentum stream) for `tiles` tiles of one lane, written to the lane's LDS slots.  NOT inlined: inside the
+// transition kernel the generator's polynomial coefficients are hoisted to the kernel's entry, kept in registers for
+// the whole kernel and -- where the leaf passes fill the register file -- spilled; every reload then waits, in order,
+// behind the loads or stores in flight (measured: 9 000 cycles per tile for ~130 instructions).  A function of its own
+// has its own registers.
+template <int L>
+__device__ __attribute__((noinline)) void momentum_normals_to_lds(WN_LDS double* slots, const WN_LDS double* tables,
+                                                                  int tiles, int tid, uint64_t seed, uint32_t chain,
+                                                                  uint32_t transition) {
+  const LdsTables tab{tables};
+#pragma unroll 2
+  for (int k = 0; k < tiles; ++k) {
+    double z0, z1;
+    wnd::stream_normal_pair(seed, chain, transition, wnd::kStreamMomentum, static_cast<uint32_t>(k * L + tid), z0, z1, tab);
+    v2f64 z;
+    z[0] = z0;
+    z[1] = z1;
+    *reinterpret_cast<WN_LDS v2f64*>(slots + (k * L + tid) * 2) = z;
+  }
+}
+
+template <class Model, int NW, bool FMA = false, int HOLD = 0>
+struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
+  using Base = TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW>;
   using typename Base::Meta;
   using Base::P; using Base::arena; using Base::tid; using Base::chain; using Base::Dp; using Base::aux;
   using Base::n_grad; using Base::max_error; using Base::min_micro; using Base::w_draw0; using Base::w_score0;
@@ -962,6 +1005,31 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   using ST = StreamTraits<Model>;
   static constexpr bool kTwoPass = ST::kTwoPass;
   typename Model::Aux auxs[4];  // kTwoPass: the model's by-products (sums) for the states in cur, alt, work, tmp
+  // Round 5: HOLD > 0 -- the moving end's (theta, rho) also live in registers (2 * HOLD elements per lane and vector:
+  // 128 registers at HOLD = 16, half of what a wavefront of an 8-wavefront workgroup may use; 8 wavefronts x 64 lanes x
+  // 32 elements = 16 384 dimensions).  A micro step then reads NOTHING of its input from the memory system -- only the
+  // new state goes out, because later U-turn tests, the selection and a turn-around name it as a pool buffer --, and
+  // the steps of a multi-step leaf before the last one touch no memory at all.  `held`: the registers equal `cur`.
+  static constexpr bool kHold = HOLD > 0 && !kTwoPass;
+  static constexpr int kHeld = kHold ? 2 * HOLD : 1;
+  double hth[kHeld], hrh[kHeld];
+  bool held;
+  static constexpr bool kTablesInLds = kHold;  // (LdsTables above: behind the inverse mass)
+  const WN_LDS double* tab_lds;
+  __device__ __forceinline__ auto make_uniform_tab() const {
+    if constexpr (kTablesInLds) {
+      return LdsTables{tab_lds};
+    } else {
+      return UniformTab{this->tabs};
+    }
+  }
+  __device__ __forceinline__ auto make_gather_tab() const {
+    if constexpr (kTablesInLds) {
+      return LdsTables{tab_lds};
+    } else {
+      return GatherTab{this->tabs};
+    }
+  }
 
   // The vector sets are pool buffers themselves (role slot r: 0-2 cur, 3-5 alt, 6-8 work, 9-11 tmp).  Handing a
   // vector to the span pool (put_new) or taking one from it (get) moves a buffer index, not 8*Dp bytes; a slot
@@ -989,6 +1057,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   int pend_bth[kMaxPending], pend_brh[kMaxPending];
   double pend_hot[kMaxPending], pend_far[kMaxPending];
   int n_pend;
+  int pend_mask;  // bit q: slot q is in use
   bool pend_valid;
   double ke_part;   // kinetic partial of the state produced by the last pass
   double ut_hot, ut_far;  // per-lane partials of the level-0 U-turn sums of the last forward pass
@@ -1002,10 +1071,26 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     im_buf = ar + static_cast<long long>(p.pool_total - p.pool_lds) * p.dim_padded;
     im = im_buf;
     own = 0u;
+    held = false;
     ut_valid = false;
     ut_hot = ut_far = 0.0;
     im_lds = (p.im_in_lds & 1u) ? bc + 2 + kShiftDoubles(NW) : nullptr;
+    tab_lds = nullptr;
+    if constexpr (kTablesInLds) {
+      // (a kernel with HOLD is launched only with the inverse mass in LDS: wn_kernels.inc, Params::im_in_lds bit 2)
+      WN_LDS double* tl = bc + 2 + kShiftDoubles(NW) + p.dim_padded;
+      if (this->wave == 0) {
+        LaneTables t;
+        t.load(this->lane);
+        tl[this->lane] = t.e2;
+        tl[64 + this->lane] = t.rc;
+        tl[128 + this->lane] = t.lc;
+      }
+      tab_lds = tl;
+      __syncthreads();
+    }
     n_pend = 0;
+    pend_mask = 0;
     pend_valid = false;
     for (int r = 0; r < 12; ++r) slot_buf[r] = -1;
     for (int i = 0; i < 3; ++i) cur[i] = alt[i] = work[i] = tmp[i] = nullptr;
@@ -1040,6 +1125,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   // the tree loop's announcement (TrajBase::run): buffers of the far ends the coming tests will name
   __device__ __forceinline__ void expect_far_ends(int n, const int* bth, const int* brh) {
     n_pend = 0;
+    pend_mask = 0;
     pend_valid = false;
     if constexpr (!kTwoPass) {
       if (P.im_in_lds & 2u) n = 0;  // (experiment switch WALNUTS_AMD_NO_FAR_END_SUMS: every test reads its five vectors)
@@ -1053,6 +1139,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
           pend_th[k] = pool_ptr(bth[k]);
           pend_rh[k] = pool_ptr(brh[k]);
           n_pend = k + 1;
+          pend_mask |= 1 << k;
         }
       }
     }
@@ -1098,6 +1185,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     const int r = slot_of(c);
     if ((own >> r) & 1u) this->release(slot_buf[r]);
     set_slot(r, b, false);
+    if (kHold && r < 2) held = false;
   }
 
   // ---- two-pass models -------------------------------------------------------------------------------------
@@ -1313,11 +1401,216 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     }
     return part;
   }
+  // ---- HOLD: the moving end in registers -------------------------------------------------------------------
+  // Addresses in these passes are (wave-uniform base + tile offset) + this lane's 16 bytes.  The tile's base is made
+  // opaque in a scalar register pair: otherwise the optimiser re-associates it into one 64-bit vector address per
+  // (vector, tile), hoists those out of every loop around the pass and spills them (measured: each access then sits
+  // behind a scratch reload and its wait).
+  // (formed anew -- two mbcnt instructions the optimiser does not merge -- by every pass that uses it: as ONE value
+  // derived from the thread index it lives from the kernel's entry to its end, is spilled where the leaf passes fill
+  // the register file, and comes back from scratch -- behind a wait for every access in flight -- before each load)
+  __device__ __forceinline__ unsigned lane_bytes() const {
+    return static_cast<unsigned>(this->wave * 64 + opaque_lane_id()) * 16u;
+  }
+  // (the tile's offset joins the LANE's 32-bit offset, not the base: sixteen tile bases per vector, formed ahead of
+  // the asm statement that pins them, are sixteen scalar pairs the allocator parks in the lanes of a vector register
+  // -- and that register in scratch, behind a wait before every access)
+  __device__ __forceinline__ static v2f64 ld_tile(const double* base, int k, unsigned lb) {
+    return load_pair_at(opaque_scalar_pointer(base), lb + static_cast<unsigned>(k) * (L * 16u));
+  }
+  __device__ __forceinline__ static void st_tile(double* base, int k, unsigned lb, double x, double y) {
+    v2f64 t;
+    t[0] = x;
+    t[1] = y;
+    store_pair_at(opaque_scalar_pointer(base), lb + static_cast<unsigned>(k) * (L * 16u), t);
+  }
+  __device__ __forceinline__ v2f64 mass_tile(int k, unsigned lb) const {  // (held kernels run with the mass in LDS)
+    return *reinterpret_cast<const WN_LDS v2f64*>(reinterpret_cast<const WN_LDS char*>(im_lds) + k * (L * 16) + lb);
+  }
+  // the registers hold nothing any more: said in so many words, because the optimiser cannot tell that the next
+  // transition's prologue overwrites them -- it would carry 128 live registers through the epilogue and the prologue
+  // (where the normal generator and the planes' loads need them) and spill them around both
+  __device__ __forceinline__ void drop_held() {
+    if constexpr (kHold) {
+#pragma unroll
+      for (int i = 0; i < kHeld; ++i) hth[i] = hrh[i] = 0.0;
+      held = false;
+    }
+  }
+  __device__ __forceinline__ void ensure_held() {
+    if constexpr (kHold) {
+      if (!held) {
+        const unsigned lb = lane_bytes();
+#pragma unroll
+        for (int k = 0; k < HOLD; ++k) {
+          if (k < tiles) {
+            const v2f64 t0 = ld_tile(cur[0], k, lb), r0 = ld_tile(cur[1], k, lb);
+            hth[2 * k] = t0[0];
+            hth[2 * k + 1] = t0[1];
+            hrh[2 * k] = r0[0];
+            hrh[2 * k + 1] = r0[1];
+          }
+        }
+        held = true;
+      }
+    }
+  }
+  // What one tile's arithmetic reads from memory: the inverse mass (LDS), the model's parameters, the announced far
+  // ends.  The passes below issue a tile's loads kPrefetch tiles AHEAD of its arithmetic (a ring of load sets, every
+  // index a compile-time constant): with two wavefronts per SIMD nothing else hides a load's latency.
+  struct TileLoads {
+    v2f64 mp, av[kMaxPending], bv[kMaxPending];
+  };
+  template <int MASK>
+  __device__ __forceinline__ void issue_tile(TileLoads& t, int k, unsigned lb) const {
+    if (Model::kUsesParams) t.mp = ld_tile(P.model_params, k, lb);
+#pragma unroll
+    for (int q = 0; q < kMaxPending; ++q) {
+      if ((MASK >> q) & 1) {
+        t.av[q] = ld_tile(pend_th[q], k, lb);
+        t.bv[q] = ld_tile(pend_rh[q], k, lb);
+      }
+    }
+  }
+  // Tiles in flight ahead of the arithmetic: what ~64 registers hold as a ring of PD + 1 load sets, 4 registers per
+  // 16-byte load (of a wavefront's 256: 128 hold the moving end, ~20 the pass's sums, ~40 the tree's state and a tile's
+  // temporaries).  The inverse mass comes from LDS: one tile ahead is enough for it.
+  static constexpr int prefetch_tiles(int mask) {
+    const int loads = (Model::kUsesParams ? 1 : 0) + 2 * ((mask & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1));
+    if (loads == 0) return 1;
+    const int sets = 16 / loads;
+    return sets < 2 ? 1 : sets > 5 ? 4 : sets - 1;
+  }
+  // One micro step on the registers.  MASK: the announced far ends whose sums ride along (FUSE: with the level-0 sums
+  // against the step's own input) -- a template parameter, so that a tile is straight-line code; STORE: the new state
+  // goes out to `alt`.
+  template <int MASK, bool FUSE, bool STORE>
+  __device__ __forceinline__ void held_step(double h, double& part, double& ke, double& p_hot, double& p_far) {
+    const double half = 0.5 * h;
+    const unsigned lb = lane_bytes();
+    constexpr int PD = prefetch_tiles(MASK);
+    TileLoads ring[PD + 1];
+    v2f64 mass[2];
+    part = 0.0;
+    ke = 0.0;
+    mass[0] = mass_tile(0, lb);
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {
+      if (k < tiles) issue_tile<MASK>(ring[k % (PD + 1)], k, lb);
+    }
+#pragma unroll
+    for (int k = 0; k < HOLD; ++k) {
+      if (k + PD < HOLD) {
+        if (k + PD < tiles) issue_tile<MASK>(ring[(k + PD) % (PD + 1)], k + PD, lb);
+      }
+      if (k + 1 < HOLD) {
+        if (k + 1 < tiles) mass[(k + 1) & 1] = mass_tile(k + 1, lb);
+      }
+      if (k < tiles) {
+        const TileLoads& in = ring[k % (PD + 1)];
+        const int o = pair_offset(k);
+        const v2f64 m0 = mass[k & 1];
+        const double t0[2] = {hth[2 * k], hth[2 * k + 1]}, r0[2] = {hrh[2 * k], hrh[2 * k + 1]};
+        double th2[2] = {t0[0], t0[1]}, rh2[2] = {r0[0], r0[1]};
+        double g2[2], mp2[2] = {1.0, 1.0};
+        if (Model::kUsesParams) {
+          mp2[0] = in.mp[0];
+          mp2[1] = in.mp[1];
+        }
+        TileCx cx{o, P.dim};
+        Model::grad(cx, th2, g2, mp2, aux);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) th2[j] = mad(h * m0[j], rh2[j], th2[j]);
+        Model::eval(cx, th2, g2, mp2, aux, part);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ke = mad(m0[j], rh2[j] * rh2[j], ke);
+        if (FUSE) {
+          // (the forward expressions; a backward step's sums are their negatives, bit for bit: rounding is symmetric)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const double sd = m0[j] * (th2[j] - t0[j]);
+            p_hot = mad(rh2[j], sd, p_hot);
+            p_far = mad(r0[j], sd, p_far);
+          }
+#pragma unroll
+          for (int q = 0; q < kMaxPending; ++q) {
+            if ((MASK >> q) & 1) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const double sd = m0[j] * (th2[j] - in.av[q][j]);
+                pend_hot[q] = mad(rh2[j], sd, pend_hot[q]);
+                pend_far[q] = mad(in.bv[q][j], sd, pend_far[q]);
+              }
+            }
+          }
+        }
+        hth[2 * k] = th2[0];
+        hth[2 * k + 1] = th2[1];
+        hrh[2 * k] = rh2[0];
+        hrh[2 * k + 1] = rh2[1];
+      }
+    }
+    // The new state goes out AFTER the last tile's arithmetic, from the registers it stays in: loads and stores share
+    // one in-order counter (vmcnt), so a store issued between two tiles' loads would put its acknowledgement -- an HBM
+    // write's round trip -- into the wait for the next tile's operands.
+    if (STORE) {
+#pragma unroll
+      for (int k = 0; k < HOLD; ++k) {
+        if (k < tiles) {
+          st_tile(alt[0], k, lb, hth[2 * k], hth[2 * k + 1]);
+          st_tile(alt[1], k, lb, hrh[2 * k], hrh[2 * k + 1]);
+        }
+      }
+    }
+    ++n_grad;
+  }
+  // leapfrog_sets(cur, alt, false, h, n) with the input taken from -- and every intermediate state kept in -- the
+  // registers: the same expressions in the same order, element by element
+  __device__ __forceinline__ double leapfrog_held(double h, int n) {
+    double part = 0.0, ke = 0.0, p_hot = 0.0, p_far = 0.0;
+    const bool fuse = n == 1;
+    const bool fwd = h > 0;
+#pragma unroll
+    for (int q = 0; q < kMaxPending; ++q) pend_hot[q] = pend_far[q] = 0.0;
+    ensure_held();
+    held = false;  // (the registers are about to hold the candidate: `cur` again once macro_commit has swapped the sets)
+    if (fuse) {
+      switch (pend_mask) {
+        case 0: held_step<0, true, true>(h, part, ke, p_hot, p_far); break;
+        case 1: held_step<1, true, true>(h, part, ke, p_hot, p_far); break;
+        case 2: held_step<2, true, true>(h, part, ke, p_hot, p_far); break;
+        case 3: held_step<3, true, true>(h, part, ke, p_hot, p_far); break;
+        case 4: held_step<4, true, true>(h, part, ke, p_hot, p_far); break;
+        case 5: held_step<5, true, true>(h, part, ke, p_hot, p_far); break;
+        case 6: held_step<6, true, true>(h, part, ke, p_hot, p_far); break;
+        default: held_step<7, true, true>(h, part, ke, p_hot, p_far); break;
+      }
+    } else {
+      for (int s = 1; s < n; ++s) held_step<0, false, false>(h, part, ke, p_hot, p_far);
+      held_step<0, false, true>(h, part, ke, p_hot, p_far);
+    }
+    ke_part = ke;
+    ut_valid = fuse;
+    ut_hot = fwd ? p_hot : -p_hot;
+    ut_far = fwd ? p_far : -p_far;
+#pragma unroll
+    for (int q = 0; q < kMaxPending; ++q) {
+      pend_hot[q] = fwd ? pend_hot[q] : -pend_hot[q];
+      pend_far[q] = fwd ? pend_far[q] : -pend_far[q];
+    }
+    pend_valid = fuse;
+    return part;
+  }
   __device__ __forceinline__ double leapfrog(double h, int n) {
     if constexpr (kTwoPass) {
       return leapfrog_two_pass(0, 1, false, h, n);
     } else {
       ensure_writable(3);
+      if constexpr (kHold) return leapfrog_held(h, n);
       return leapfrog_sets(cur, alt, false, h, n);
     }
   }
@@ -1340,6 +1633,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
       slot_buf[3 + i] = b;
     }
     own = (own & ~0x3fu) | ((own & 0x7u) << 3) | ((own >> 3) & 0x7u);
+    if constexpr (kHold) held = true;  // (leapfrog_held left the accepted candidate in the registers)
     if constexpr (kTwoPass) {
       const typename Model::Aux t = auxs[0];
       auxs[0] = auxs[1];
@@ -1369,6 +1663,41 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   // walnuts.hpp:192-201 against the far end (a, b) = (theta, rho)
   __device__ __forceinline__ bool uturn_ptrs(const double* a, const double* b, bool fwd) {
     double p_hot = 0.0, p_far = 0.0;
+    if constexpr (kHold) {
+      ensure_held();
+      const unsigned lb = lane_bytes();
+      constexpr int PD = 4;
+      v2f64 rm[PD + 1], ra[PD + 1], rb[PD + 1];
+#pragma unroll
+      for (int k = 0; k < PD; ++k) {
+        if (k < tiles) {
+          rm[k] = mass_tile(k, lb);
+          ra[k] = ld_tile(a, k, lb);
+          rb[k] = ld_tile(b, k, lb);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HOLD; ++k) {
+        if (k + PD < HOLD) {
+          if (k + PD < tiles) {
+            rm[(k + PD) % (PD + 1)] = mass_tile(k + PD, lb);
+            ra[(k + PD) % (PD + 1)] = ld_tile(a, k + PD, lb);
+            rb[(k + PD) % (PD + 1)] = ld_tile(b, k + PD, lb);
+          }
+        }
+        if (k < tiles) {
+          const v2f64 m = rm[k % (PD + 1)], av = ra[k % (PD + 1)], bv = rb[k % (PD + 1)];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const double sd = m[j] * (hth[2 * k + j] - av[j]);
+            p_hot = mad(hrh[2 * k + j], sd, p_hot);
+            p_far = mad(bv[j], sd, p_far);
+          }
+        }
+      }
+      this->sum2(p_hot, p_far);
+      return fwd ? (p_hot < 0 || p_far < 0) : (p_hot > 0 || p_far > 0);
+    }
     for (int k = 0; k < tiles; ++k) {
       const int o = pair_offset(k);
       const v2f64 t = ld(cur[0] + o), r = ld(cur[1] + o), m = mass_at(o), av = ld(a + o), bv = ld(b + o);
@@ -1411,14 +1740,138 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     return uturn_ptrs(pool_ptr(bth), pool_ptr(brh), fwd);
   }
 
+  // begin_transition_held's sweep over the tiles, four at a time: the inverse mass (WARM: the two estimator planes it
+  // is computed from) and the model's parameters of kAhead chunks are in flight while a chunk is worked on; each tile
+  // takes its normals from its LDS slot and leaves the inverse mass there.
+  template <bool WARM>
+  __device__ __forceinline__ void initial_state_sweep(long long row, unsigned lb, double& part, double& ke) {
+    constexpr int kChunk = 4, kChunks = (HOLD + kChunk - 1) / kChunk;
+    constexpr int kAhead = WARM ? 2 : 4;  // (three planes' loads per tile in warmup, two otherwise)
+    const double wd = w_draw0, ws = w_score0;
+    const double* plane_a = WARM ? P.est_draw_ssd + row : P.inv_mass + row;
+    struct Chunk {
+      v2f64 pa[kChunk], pb[kChunk], mp[kChunk];
+    };
+    Chunk ring[kAhead];
+    auto issue = [&](Chunk& ch, int c) {
+#pragma unroll
+      for (int i = 0; i < kChunk; ++i) {
+        const int k = c * kChunk + i;
+        if (k < HOLD && k < tiles) {
+          ch.pa[i] = ld_tile(plane_a, k, lb);
+          if (WARM) ch.pb[i] = ld_tile(P.est_score_ssd + row, k, lb);
+          if (Model::kUsesParams) ch.mp[i] = ld_tile(P.model_params, k, lb);
+        }
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < kAhead - 1 && c < kChunks; ++c) issue(ring[c % kAhead], c);
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+      if (c + kAhead - 1 < kChunks) issue(ring[(c + kAhead - 1) % kAhead], c + kAhead - 1);
+      const Chunk& ch = ring[c % kAhead];
+#pragma unroll
+      for (int i = 0; i < kChunk; ++i) {
+        const int k = c * kChunk + i;
+        if (k < HOLD && k < tiles) {
+          const int o = pair_offset(k);
+          const v2f64 z = mass_tile(k, lb);  // (this tile's normals, parked in its slot)
+          v2f64 m0 = ch.pa[i];
+          if (WARM) {  // adaptive_walnuts.hpp:235-236, :89-94
+#pragma unroll
+            for (int j = 0; j < 2; ++j) m0[j] = __builtin_sqrt((ch.pa[i][j] / wd) / (ch.pb[i][j] / ws));
+          }
+          *reinterpret_cast<WN_LDS v2f64*>(im_lds + o) = m0;
+          double th2[2] = {hth[2 * k], hth[2 * k + 1]}, g2[2], mp2[2] = {1.0, 1.0}, ch2[2];
+          if (Model::kUsesParams) {
+            mp2[0] = ch.mp[i][0];
+            mp2[1] = ch.mp[i][1];
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            ch2[j] = WARM ? __builtin_sqrt(1.0 / m0[j])    // adaptive_walnuts.hpp:89-94
+                          : 1.0 / __builtin_sqrt(m0[j]);   // walnuts.hpp:647 (= the chol_mass plane)
+          }
+          double rh2[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) rh2[j] = (o + j < P.dim) ? ch2[j] * z[j] : 0.0;
+          TileCx cx{o, P.dim};
+          Model::eval(cx, th2, g2, mp2, aux, part);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ke = mad(m0[j], rh2[j] * rh2[j], ke);
+          hrh[2 * k] = rh2[0];
+          hrh[2 * k + 1] = rh2[1];
+        }
+      }
+    }
+  }
+  // begin_transition for a kernel with a held moving end: the same expressions element by element, arranged for two
+  // wavefronts per SIMD.  The runtime loop below it takes a tile at a time -- three loads, their round trip, the
+  // normal generator, two stores and their acknowledgement (measured at 16 tiles per lane: 210 us per transition, as
+  // much as fifteen leapfrog passes).  Here (1) every tile of the position is requested at once, straight into the
+  // registers that will hold it; (2) the momentum's normals are drawn while those loads are in flight -- in a loop
+  // that is NOT unrolled, with the register file to itself (unrolled beside 128 held registers the generator's
+  // constants are spilled, and every reload waits, in order, behind the loads in flight) -- and parked in the LDS
+  // slots of the inverse mass, which is not there yet; (3) the inverse mass (warmup: the two estimator planes it is
+  // computed from) arrives in chunks of four tiles, several chunks ahead of the arithmetic (initial_state_sweep above),
+  // and each tile reads its normals from its slot before the mass takes it.  The Cholesky factor of a sampling transition is computed, 1 / sqrt(inverse mass) as freeze_kernel
+  // (wn_elementwise.h) wrote its plane -- the same operations, the same bits -- instead of being loaded.  The initial
+  // state goes out to `cur` from the registers after the last tile.
+  __device__ __forceinline__ double begin_transition_held(long long row, bool warm) {
+    const bool fed = P.rng_mode == kRngBuffer;
+    if (fed) {
+#pragma nounroll
+      for (int k = 0; k < tiles; ++k) {
+        const int o = pair_offset(k);
+        *reinterpret_cast<WN_LDS v2f64*>(im_lds + o) = ld(P.z_buf + row + o);
+      }
+    } else {
+      momentum_normals_to_lds<L>(im_lds, tab_lds, tiles, tid, P.seed, P.chain_offset + chain, this->transition_now());
+    }
+    WN_MARK(kPhMomentum);
+    const unsigned lb = lane_bytes();
+#pragma unroll
+    for (int k = 0; k < HOLD; ++k) {
+      if (k < tiles) {
+        const v2f64 t0 = ld_tile(P.theta + row, k, lb);
+        hth[2 * k] = t0[0];
+        hth[2 * k + 1] = t0[1];
+      }
+    }
+    double part = 0.0, ke = 0.0;
+    if (warm) {
+      initial_state_sweep<true>(row, lb, part, ke);
+    } else {
+      initial_state_sweep<false>(row, lb, part, ke);
+    }
+    WN_MARK(kPhEvaluated);
+#pragma unroll
+    for (int k = 0; k < HOLD; ++k) {
+      if (k < tiles) {
+        st_tile(cur[0], k, lb, hth[2 * k], hth[2 * k + 1]);
+        st_tile(cur[1], k, lb, hrh[2 * k], hrh[2 * k + 1]);
+      }
+    }
+    WN_MARK(kPhStored);
+    held = true;
+    ++n_grad;
+    ke_part = ke;
+    return part;
+  }
+
   __device__ __forceinline__ double begin_transition(long long row, bool warm) {
     const double wd = w_draw0, ws = w_score0;
     im = warm ? im_buf : P.inv_mass + row;
     n_pend = 0;
+    pend_mask = 0;
     pend_valid = false;
+    drop_held();
     own = 0u;  // the base has just marked every pool buffer free
     for (int r = 0; r < 12; ++r) slot_buf[r] = -1;
     ensure_writable(0);
+    if constexpr (kHold) {
+      if (im_lds != nullptr) return begin_transition_held(row, warm);
+    }
     double part = 0.0, ke = 0.0;
     double sums[ST::kSums];
     for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
@@ -1503,6 +1956,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
   }
 
   __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
+    drop_held();
     const double* sel = pool_ptr(a_sel);
     typename Model::Aux aux_sel{};
     if constexpr (kTwoPass) {
@@ -1514,6 +1968,35 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA>, Model, NW> {
     // a draw row on a 16-byte boundary takes whole pairs (streamed: written once, read by nobody here); the pair that
     // straddles the end of an odd-length row, or a row at an odd offset, goes element by element
     const bool pair_rows = (reinterpret_cast<unsigned long long>(out) & 15ull) == 0ull;
+    if constexpr (kHold) {
+      // sampling: every tile of the selected state is in flight before the first store (a tile at a time the copy
+      // is sixteen round trips back to back)
+      if (!warm) {
+        const unsigned lb = lane_bytes();
+        v2f64 all[HOLD];  // (the registers that held the moving end: it has just been dropped)
+#pragma unroll
+        for (int k = 0; k < HOLD; ++k) {
+          if (k < tiles) all[k] = ld_tile(sel, k, lb);
+        }
+#pragma unroll
+        for (int k = 0; k < HOLD; ++k) {
+          if (k < tiles) {
+            const int o = pair_offset(k);
+            const v2f64 t0 = all[k];
+            st_tile(P.theta + row, k, lb, t0[0], t0[1]);
+            if (out != nullptr) {
+              if (pair_rows && o + 1 < P.dim) {
+                stream_store(t0, reinterpret_cast<v2f64*>(out + o));
+              } else {
+                if (o < P.dim) stream_store(t0[0], &out[o]);
+                if (o + 1 < P.dim) stream_store(t0[1], &out[o + 1]);
+              }
+            }
+          }
+        }
+        return;
+      }
+    }
     for (int k = 0; k < tiles; ++k) {
       const int o = pair_offset(k);
       const v2f64 t0 = ld(sel + o);
@@ -1620,9 +2103,27 @@ __device__ __forceinline__ void persistent_loop(const Params& P) {
 #endif
 }
 
-template <class Model, int NW, bool FMA>
+// Tiles (pairs per lane) of the moving end a streaming kernel keeps in registers (TrajMem, HOLD); 0 = it keeps none.
+// Eight wavefronts per chain, one chain per CU: 256 registers each, 128 of them for 16 tiles of (theta, rho) = 16 384
+// dimensions.  (Sixteen wavefronts with 8 tiles have 64 registers left for everything else: measured, the operands of
+// a tile then arrive one round trip at a time and part of the held state is spilled.)
+constexpr int kMemHoldTiles = 16;
+template <class Model>
+constexpr int mem_hold_tiles(int nw) {
+  if constexpr (!(Model::kElementwise || is_streamable<Model>::value)) {
+    return 0;  // (no streaming kernels at all)
+  } else {
+#if defined(WN_SIM_GEOMETRIES)
+    return StreamTraits<Model>::kTwoPass ? 0 : kMemHoldTiles;  // (tests/cpusim: every geometry it builds)
+#else
+    return (nw == 8 && !StreamTraits<Model>::kTwoPass) ? kMemHoldTiles : 0;
+#endif
+  }
+}
+
+template <class Model, int NW, bool FMA, int HOLD = 0>
 __global__ __launch_bounds__(64 * NW) void transition_kernel_mem(const Params P) {
-  persistent_loop<TrajMem<Model, NW, FMA>, NW>(P);
+  persistent_loop<TrajMem<Model, NW, FMA, HOLD>, NW>(P);
 }
 
 inline size_t transition_smem_bytes(int nw, int lds_vectors, int dim_padded) {

@@ -283,6 +283,12 @@ class DeviceEngine:
         return bool(self.lib.wn_engine_is_streaming(self.h))
 
     @property
+    def held_tiles(self) -> int:
+        """Streaming kernels: 16-byte pairs per lane of the trajectory's moving end kept in registers (0: both ends of
+        every micro step stream through HBM)."""
+        return self.lib.wn_engine_held_tiles(self.h)
+
+    @property
     def workgroups(self) -> int:
         return self.lib.wn_engine_workgroups(self.h)
 

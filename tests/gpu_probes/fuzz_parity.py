@@ -21,12 +21,13 @@ GEOMETRIES = [(1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8), (4, 2), (
               (16, 4), (16, 8)]
 
 
-def random_case(rng, geometries=GEOMETRIES, mem_waves=(2, 4, 8, 16), chain_counts=(1, 2, 3, 7, 16, 33, 64)):
-    model = rng.choice(["std_normal", "diag_normal", "funnel", "rw1"])
-    streaming = rng.uniform() < 0.15   # every model has streaming kernels (funnel / rw1: the two-pass form)
+def random_case(rng, geometries=GEOMETRIES, mem_waves=(2, 4, 8, 16), chain_counts=(1, 2, 3, 7, 16, 33, 64),
+                streaming_share=0.15, streaming_dims=(3, 3000), models=("std_normal", "diag_normal", "funnel", "rw1")):
+    model = rng.choice(list(models))
+    streaming = rng.uniform() < streaming_share   # every model has streaming kernels (funnel / rw1: the two-pass form)
     if streaming:
         geometry = (int(rng.choice(list(mem_waves))), -1)
-        D = int(rng.integers(3, 3000))
+        D = int(rng.integers(*streaming_dims))
     else:
         geometry = geometries[int(rng.integers(len(geometries)))]
         cap = 64 * geometry[0] * geometry[1]
@@ -97,9 +98,16 @@ def main():
     ap.add_argument("--seed", type=int, default=2025)
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--verbose", action="store_true", help="print every case, not only failures / skips + the tally")
+    ap.add_argument("--held", action="store_true",
+                    help="the streaming kernels that hold the moving end in registers only: one-pass models, 8 wavefronts "
+                         "per chain, 1 000-16 384 dimensions (1-16 tiles per lane), few chains")
     a = ap.parse_args()
     t0 = time.time()
-    done, failed, tally = campaign(a.seed, a.seconds, a.cases, a.verbose)
+    case_kw = {}
+    if a.held:
+        case_kw = dict(mem_waves=(8,), streaming_share=1.0, streaming_dims=(1000, 16385), chain_counts=(1, 2, 3, 5),
+                       models=("std_normal", "diag_normal"))
+    done, failed, tally = campaign(a.seed, a.seconds, a.cases, a.verbose, **case_kw)
     bad = len(failed)
     print("# bit-exact cases by (model, waves x elements per lane): count, gradient evaluations compared, "
           "cases with a NaN-poisoned Adam state (identical on both sides)")

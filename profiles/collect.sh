@@ -13,7 +13,13 @@ $B --phase warmup --no-cpu-baseline --no-parity-gate > $OUT/bench_headline_warmu
 $B --no-cpu-baseline --model ill_normal --chains 4096 --dim 1024 --adapt-iters 300 > $OUT/bench_cfg2.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 128 --adapt-iters 300 > $OUT/bench_cfg3.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4.json 2>> $OUT/bench.err
-WALNUTS_AMD_NO_LDS_MASS=1 WALNUTS_AMD_NO_FAR_END_SUMS=1 $B --no-cpu-baseline --no-parity-gate --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4_round3_byte_budget.json 2>> $OUT/bench.err
+# config #4 on the kernels of the earlier rounds: sixteen wavefronts per chain streaming BOTH ends of every micro step
+# (round 4's kernel: what still runs beyond 16 384 dimensions), and the same without its two round-4 savings (round 3's)
+$B --no-cpu-baseline --no-parity-gate --waves-per-chain 16 --elems-per-lane -1 --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4_both_ends_streamed.json 2>> $OUT/bench.err
+WALNUTS_AMD_NO_LDS_MASS=1 WALNUTS_AMD_NO_FAR_END_SUMS=1 $B --no-cpu-baseline --no-parity-gate --waves-per-chain 16 --elems-per-lane -1 --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4_round3_byte_budget.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --phase warmup --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4_warmup.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --model diag_normal --chains 8192 --dim 12000 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_diag_12000.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --model std_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_std_16384.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --config 5 --steps 16 --warmup 8 > $OUT/bench_cfg5_one_gpu.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_funnel_1024.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model rw1 --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_rw1_1024.json 2>> $OUT/bench.err

@@ -390,7 +390,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.cfg = cfg;
   e.device = cfg.device;
   e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params, ops.preferred_epl,
-                              ops.hold_tiles(wn::kHeldWaves));
+                              ops.hold_tiles(wn::kHeldWaves), ops.one_pass);
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
@@ -1113,7 +1113,8 @@ int wn_engine_release_stream(wn_engine* e, void* stream, WalnutpyError** err) {
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {
   try {
     return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, wn::model_ops(model).uses_params,
-                                    wn::model_ops(model).preferred_epl, wn::model_ops(model).hold_tiles(wn::kHeldWaves)).nw;
+                                    wn::model_ops(model).preferred_epl, wn::model_ops(model).hold_tiles(wn::kHeldWaves),
+                                    wn::model_ops(model).one_pass).nw;
   } catch (...) {
     return -1;
   }

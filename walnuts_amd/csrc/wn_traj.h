@@ -1010,7 +1010,8 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   // 32 elements = 16 384 dimensions).  A micro step then reads NOTHING of its input from the memory system -- only the
   // new state goes out, because later U-turn tests, the selection and a turn-around name it as a pool buffer --, and
   // the steps of a multi-step leaf before the last one touch no memory at all.  `held`: the registers equal `cur`.
-  static constexpr bool kHold = HOLD > 0 && !kTwoPass;
+  // (two-pass models: those without halo reads -- a neighbour's value sits in another lane's registers)
+  static constexpr bool kHold = HOLD > 0 && !(kTwoPass && ST::kHalo);
   static constexpr int kHeld = kHold ? 2 * HOLD : 1;
   double hth[kHeld], hrh[kHeld];
   bool held;
@@ -1238,83 +1239,98 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   __device__ __forceinline__ void moving_end_replaced() {
     if constexpr (kTwoPass) aux_of(cur[0], auxs[0]);
   }
-  __device__ __forceinline__ void swap_sets(int ra, int rb) {  // role sets ra, rb (0 cur, 1 alt, 2 work, 3 tmp)
+  // (The role sets are named by TEMPLATE arguments from here on: with run-time set indices the slots are reached
+  // through selected member addresses, the optimiser cannot split the object into registers any more, and everything
+  // in it -- the held moving end included -- lives in scratch.)
+  template <int RA, int RB>
+  __device__ __forceinline__ void swap_sets() {  // role sets RA, RB (0 cur, 1 alt, 2 work, 3 tmp)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      double* t = slot_ptr(3 * ra + i);
-      slot_ptr(3 * ra + i) = slot_ptr(3 * rb + i);
-      slot_ptr(3 * rb + i) = t;
-      const int b = slot_buf[3 * ra + i];
-      slot_buf[3 * ra + i] = slot_buf[3 * rb + i];
-      slot_buf[3 * rb + i] = b;
+      double* t = slot_ptr(3 * RA + i);
+      slot_ptr(3 * RA + i) = slot_ptr(3 * RB + i);
+      slot_ptr(3 * RB + i) = t;
+      const int b = slot_buf[3 * RA + i];
+      slot_buf[3 * RA + i] = slot_buf[3 * RB + i];
+      slot_buf[3 * RB + i] = b;
     }
-    const unsigned ma = 7u << (3 * ra), mb = 7u << (3 * rb);
-    const unsigned oa = (own & ma) >> (3 * ra), ob = (own & mb) >> (3 * rb);
-    own = (own & ~(ma | mb)) | (ob << (3 * ra)) | (oa << (3 * rb));
-    const typename Model::Aux t = auxs[ra];
-    auxs[ra] = auxs[rb];
-    auxs[rb] = t;
+    constexpr unsigned ma = 7u << (3 * RA), mb = 7u << (3 * RB);
+    const unsigned oa = (own & ma) >> (3 * RA), ob = (own & mb) >> (3 * RB);
+    own = (own & ~(ma | mb)) | (ob << (3 * RA)) | (oa << (3 * RB));
+    const typename Model::Aux t = auxs[RA];
+    auxs[RA] = auxs[RB];
+    auxs[RB] = t;
   }
-  // n micro steps of a two-pass model from role set `rs` into role set `rd` (rd != rs; steps after the first
-  // ping-pong between rd and tmp, and the result ends in rd).  Pass A: kick with the gradient at the old position
-  // (its aux is known), drift, store, and take the model's sums of the NEW position; pass B: the gradient there,
-  // second kick, log-density terms, kinetic energy.
-  __device__ __forceinline__ double leapfrog_two_pass(int rs, int rd, bool negate, double h, int n) {
+  // One micro step of a two-pass model from role set FROM into role set TO.  Pass A: kick with the gradient at the old
+  // position (its aux is known), drift, store, and take the model's sums of the NEW position; pass B: the gradient
+  // there, second kick, log-density terms, kinetic energy.
+  template <int FROM, int TO>
+  __device__ __forceinline__ void two_pass_micro_step(bool neg, double h, double& part, double& ke) {
     const double half = 0.5 * h;
-    double part = 0.0, ke = 0.0;
-    int from = rs, to = rd;
-    for (int s = 0; s < n; ++s) {
-      ensure_writable(3 * to);
-      double* const* in = &slot_ptr(3 * from);
-      double* const* out = &slot_ptr(3 * to);
-      const bool neg = negate && s == 0;
-      const typename Model::Aux a_in = auxs[from];
-      double sums[ST::kSums];
-      for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
-      for (int k = 0; k < tiles; ++k) {
-        const int o = pair_offset(k);
-        const v2f64 t0 = ld(in[0] + o), r0 = ld(in[1] + o), m0 = mass_at(o);
-        double th2[2] = {t0[0], t0[1]}, rh2[2] = {neg ? -r0[0] : r0[0], neg ? -r0[1] : r0[1]};
-        double g2[2], mp2[2], prev[2], next[2];
-        load_mp(o, mp2);
-        halo(in[0], o, t0, prev, next);
-        TileCx cx{o, P.dim};
-        Model::stream_grad(cx, th2, prev, next, mp2, g2, a_in);
+    ensure_writable(3 * TO);
+    double* const in0 = slot_ptr(3 * FROM);
+    double* const in1 = slot_ptr(3 * FROM + 1);
+    double* const out0 = slot_ptr(3 * TO);
+    double* const out1 = slot_ptr(3 * TO + 1);
+    const typename Model::Aux a_in = auxs[FROM];
+    double sums[ST::kSums];
+    for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
+    for (int k = 0; k < tiles; ++k) {
+      const int o = pair_offset(k);
+      const v2f64 t0 = ld(in0 + o), r0 = ld(in1 + o), m0 = mass_at(o);
+      double th2[2] = {t0[0], t0[1]}, rh2[2] = {neg ? -r0[0] : r0[0], neg ? -r0[1] : r0[1]};
+      double g2[2], mp2[2], prev[2], next[2];
+      load_mp(o, mp2);
+      halo(in0, o, t0, prev, next);
+      TileCx cx{o, P.dim};
+      Model::stream_grad(cx, th2, prev, next, mp2, g2, a_in);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
+      for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) th2[j] = mad(h * m0[j], rh2[j], th2[j]);
-        if (ST::kHasSums) Model::stream_sums(cx, th2, mp2, sums);
-        st(out[0] + o, th2[0], th2[1]);
-        st(out[1] + o, rh2[0], rh2[1]);
-      }
-      finish_sums(sums, auxs[to]);
-      if (ST::kHalo) __syncthreads();  // the neighbours' new positions are in memory
-      const typename Model::Aux a_out = auxs[to];
-      part = 0.0;
-      ke = 0.0;
-      for (int k = 0; k < tiles; ++k) {
-        const int o = pair_offset(k);
-        const v2f64 t1 = ld(out[0] + o), r1 = ld(out[1] + o), m0 = mass_at(o);
-        const double th2[2] = {t1[0], t1[1]};
-        double rh2[2] = {r1[0], r1[1]}, g2[2], mp2[2], prev[2], next[2];
-        load_mp(o, mp2);
-        halo(out[0], o, t1, prev, next);
-        TileCx cx{o, P.dim};
-        Model::stream_grad(cx, th2, prev, next, mp2, g2, a_out);
-        Model::stream_logp(cx, th2, prev, next, mp2, a_out, part);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) ke = mad(m0[j], rh2[j] * rh2[j], ke);
-        st(out[1] + o, rh2[0], rh2[1]);
-      }
-      ++n_grad;
-      from = to;
-      to = (to == rd) ? 3 : rd;
+      for (int j = 0; j < 2; ++j) th2[j] = mad(h * m0[j], rh2[j], th2[j]);
+      if (ST::kHasSums) Model::stream_sums(cx, th2, mp2, sums);
+      st(out0 + o, th2[0], th2[1]);
+      st(out1 + o, rh2[0], rh2[1]);
     }
-    if (from != rd) swap_sets(rd, 3);  // an even number of steps ended in tmp
-    aux = auxs[rd];
+    finish_sums(sums, auxs[TO]);
+    if (ST::kHalo) __syncthreads();  // the neighbours' new positions are in memory
+    const typename Model::Aux a_out = auxs[TO];
+    part = 0.0;
+    ke = 0.0;
+    for (int k = 0; k < tiles; ++k) {
+      const int o = pair_offset(k);
+      const v2f64 t1 = ld(out0 + o), r1 = ld(out1 + o), m0 = mass_at(o);
+      const double th2[2] = {t1[0], t1[1]};
+      double rh2[2] = {r1[0], r1[1]}, g2[2], mp2[2], prev[2], next[2];
+      load_mp(o, mp2);
+      halo(out0, o, t1, prev, next);
+      TileCx cx{o, P.dim};
+      Model::stream_grad(cx, th2, prev, next, mp2, g2, a_out);
+      Model::stream_logp(cx, th2, prev, next, mp2, a_out, part);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ke = mad(m0[j], rh2[j] * rh2[j], ke);
+      st(out1 + o, rh2[0], rh2[1]);
+    }
+    ++n_grad;
+  }
+  // n micro steps of a two-pass model from role set RS into role set RD (RD != RS; steps after the first ping-pong
+  // between RD and tmp -- never in place: a neighbour's old value may still be wanted --, and the result ends in RD).
+  template <int RS, int RD>
+  __device__ __forceinline__ double leapfrog_two_pass(bool negate, double h, int n) {
+    double part = 0.0, ke = 0.0;
+    two_pass_micro_step<RS, RD>(negate, h, part, ke);
+    bool in_tmp = false;
+    for (int s = 1; s < n; ++s) {
+      if (!in_tmp) {
+        two_pass_micro_step<RD, 3>(false, h, part, ke);
+      } else {
+        two_pass_micro_step<3, RD>(false, h, part, ke);
+      }
+      in_tmp = !in_tmp;
+    }
+    if (in_tmp) swap_sets<RD, 3>();  // an even number of steps ended in tmp
+    aux = auxs[RD];
     ke_part = ke;
     if (!negate) ut_valid = false;
     return part;
@@ -1568,6 +1584,96 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
     }
     ++n_grad;
   }
+  // leapfrog_two_pass(cur -> alt, not negated) on the registers: both passes of every micro step read the state where
+  // it is, the model's sums are reduced between them, and the result goes out to `alt` once, after the last step --
+  // 16 bytes per element and macro step where the streamed form moves 72 per micro step.
+  __device__ __forceinline__ double leapfrog_two_pass_held(double h, int n) {
+    const double half = 0.5 * h;
+    const unsigned lb = lane_bytes();
+    double part = 0.0, ke = 0.0;
+    ensure_held();
+    held = false;  // (the candidate: `cur` again once macro_commit has swapped the sets)
+    typename Model::Aux a_in = auxs[0], a_out = auxs[0];
+    for (int s = 0; s < n; ++s) {
+      double sums[ST::kSums];
+#pragma unroll
+      for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
+      v2f64 mass[2];
+      mass[0] = mass_tile(0, lb);
+#pragma unroll
+      for (int k = 0; k < HOLD; ++k) {  // pass A: kick with the gradient at the old position, drift, the new position's sums
+        if (k + 1 < HOLD) {
+          if (k + 1 < tiles) mass[(k + 1) & 1] = mass_tile(k + 1, lb);
+        }
+        if (k < tiles) {
+          const v2f64 m0 = mass[k & 1];
+          double th2[2] = {hth[2 * k], hth[2 * k + 1]}, rh2[2] = {hrh[2 * k], hrh[2 * k + 1]};
+          double g2[2], mp2[2] = {1.0, 1.0};
+          const double none[2] = {0.0, 0.0};
+          if (Model::kUsesParams) {
+            const v2f64 p0 = ld_tile(P.model_params, k, lb);
+            mp2[0] = p0[0];
+            mp2[1] = p0[1];
+          }
+          TileCx cx{pair_offset(k), P.dim};
+          Model::stream_grad(cx, th2, none, none, mp2, g2, a_in);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) th2[j] = mad(h * m0[j], rh2[j], th2[j]);
+          if (ST::kHasSums) Model::stream_sums(cx, th2, mp2, sums);
+          hth[2 * k] = th2[0];
+          hth[2 * k + 1] = th2[1];
+          hrh[2 * k] = rh2[0];
+          hrh[2 * k + 1] = rh2[1];
+        }
+      }
+      finish_sums(sums, a_out);
+      part = 0.0;
+      ke = 0.0;
+      mass[0] = mass_tile(0, lb);
+#pragma unroll
+      for (int k = 0; k < HOLD; ++k) {  // pass B: the gradient there, second kick, log-density terms, kinetic energy
+        if (k + 1 < HOLD) {
+          if (k + 1 < tiles) mass[(k + 1) & 1] = mass_tile(k + 1, lb);
+        }
+        if (k < tiles) {
+          const v2f64 m0 = mass[k & 1];
+          const double th2[2] = {hth[2 * k], hth[2 * k + 1]};
+          double rh2[2] = {hrh[2 * k], hrh[2 * k + 1]}, g2[2], mp2[2] = {1.0, 1.0};
+          const double none[2] = {0.0, 0.0};
+          if (Model::kUsesParams) {
+            const v2f64 p0 = ld_tile(P.model_params, k, lb);
+            mp2[0] = p0[0];
+            mp2[1] = p0[1];
+          }
+          TileCx cx{pair_offset(k), P.dim};
+          Model::stream_grad(cx, th2, none, none, mp2, g2, a_out);
+          Model::stream_logp(cx, th2, none, none, mp2, a_out, part);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ke = mad(m0[j], rh2[j] * rh2[j], ke);
+          hrh[2 * k] = rh2[0];
+          hrh[2 * k + 1] = rh2[1];
+        }
+      }
+      ++n_grad;
+      a_in = a_out;
+    }
+#pragma unroll
+    for (int k = 0; k < HOLD; ++k) {
+      if (k < tiles) {
+        st_tile(alt[0], k, lb, hth[2 * k], hth[2 * k + 1]);
+        st_tile(alt[1], k, lb, hrh[2 * k], hrh[2 * k + 1]);
+      }
+    }
+    auxs[1] = a_out;
+    aux = a_out;
+    ke_part = ke;
+    ut_valid = false;
+    return part;
+  }
   // leapfrog_sets(cur, alt, false, h, n) with the input taken from -- and every intermediate state kept in -- the
   // registers: the same expressions in the same order, element by element
   __device__ __forceinline__ double leapfrog_held(double h, int n) {
@@ -1607,7 +1713,11 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   }
   __device__ __forceinline__ double leapfrog(double h, int n) {
     if constexpr (kTwoPass) {
-      return leapfrog_two_pass(0, 1, false, h, n);
+      if constexpr (kHold) {
+        ensure_writable(3);
+        return leapfrog_two_pass_held(h, n);
+      }
+      return leapfrog_two_pass<0, 1>(false, h, n);
     } else {
       ensure_writable(3);
       if constexpr (kHold) return leapfrog_held(h, n);
@@ -1648,7 +1758,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
       h *= 2;
       double part;
       if constexpr (kTwoPass) {
-        part = leapfrog_two_pass(1, 2, true, h, n);
+        part = leapfrog_two_pass<1, 2>(true, h, n);
       } else {
         ensure_writable(6);
         part = leapfrog_sets(alt, work, true, h, n);
@@ -1744,7 +1854,8 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   // is computed from) and the model's parameters of kAhead chunks are in flight while a chunk is worked on; each tile
   // takes its normals from its LDS slot and leaves the inverse mass there.
   template <bool WARM>
-  __device__ __forceinline__ void initial_state_sweep(long long row, unsigned lb, double& part, double& ke) {
+  __device__ __forceinline__ void initial_state_sweep(long long row, unsigned lb, double& part, double& ke,
+                                                      double (&sums)[ST::kSums]) {
     constexpr int kChunk = 4, kChunks = (HOLD + kChunk - 1) / kChunk;
     constexpr int kAhead = WARM ? 2 : 4;  // (three planes' loads per tile in warmup, two otherwise)
     const double wd = w_draw0, ws = w_score0;
@@ -1796,7 +1907,12 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
 #pragma unroll
           for (int j = 0; j < 2; ++j) rh2[j] = (o + j < P.dim) ? ch2[j] * z[j] : 0.0;
           TileCx cx{o, P.dim};
-          Model::eval(cx, th2, g2, mp2, aux, part);
+          if constexpr (kTwoPass) {
+            (void)g2;
+            Model::stream_sums(cx, th2, mp2, sums);  // (the position's aux first: the log-density terms follow it)
+          } else {
+            Model::eval(cx, th2, g2, mp2, aux, part);
+          }
 #pragma unroll
           for (int j = 0; j < 2; ++j) ke = mad(m0[j], rh2[j] * rh2[j], ke);
           hrh[2 * k] = rh2[0];
@@ -1839,10 +1955,31 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
       }
     }
     double part = 0.0, ke = 0.0;
+    double sums[ST::kSums];
+#pragma unroll
+    for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
     if (warm) {
-      initial_state_sweep<true>(row, lb, part, ke);
+      initial_state_sweep<true>(row, lb, part, ke, sums);
     } else {
-      initial_state_sweep<false>(row, lb, part, ke);
+      initial_state_sweep<false>(row, lb, part, ke, sums);
+    }
+    if constexpr (kTwoPass) {
+      finish_sums(sums, auxs[0]);
+      aux = auxs[0];
+#pragma unroll
+      for (int k = 0; k < HOLD; ++k) {
+        if (k < tiles) {
+          const double th2[2] = {hth[2 * k], hth[2 * k + 1]}, none[2] = {0.0, 0.0};
+          double mp2[2] = {1.0, 1.0};
+          if (Model::kUsesParams) {
+            const v2f64 p0 = ld_tile(P.model_params, k, lb);
+            mp2[0] = p0[0];
+            mp2[1] = p0[1];
+          }
+          TileCx cx{pair_offset(k), P.dim};
+          Model::stream_logp(cx, th2, none, none, mp2, auxs[0], part);
+        }
+      }
     }
     WN_MARK(kPhEvaluated);
 #pragma unroll
@@ -2113,10 +2250,11 @@ constexpr int mem_hold_tiles(int nw) {
   if constexpr (!(Model::kElementwise || is_streamable<Model>::value)) {
     return 0;  // (no streaming kernels at all)
   } else {
+    constexpr bool kCan = !(StreamTraits<Model>::kTwoPass && StreamTraits<Model>::kHalo);
 #if defined(WN_SIM_GEOMETRIES)
-    return StreamTraits<Model>::kTwoPass ? 0 : kMemHoldTiles;  // (tests/cpusim: every geometry it builds)
+    return kCan ? kMemHoldTiles : 0;  // (tests/cpusim: every geometry it builds)
 #else
-    return (nw == 8 && !StreamTraits<Model>::kTwoPass) ? kMemHoldTiles : 0;
+    return (nw == 8 && kCan) ? kMemHoldTiles : 0;
 #endif
   }
 }

@@ -46,7 +46,10 @@ HELD_WAVES = 8   # wn_launch.h, kHeldWaves
 
 def geometry_defines(nw: int, epl: int, streaming: bool, waves_requested: bool = True) -> Sequence[str]:
     if not streaming:
-        return [f"-DWN_ONLY_NW={nw}", f"-DWN_ONLY_EPL={epl}"]
+        chip = [f"-DWN_ONLY_NW={nw}", f"-DWN_ONLY_EPL={epl}"]
+        # where the register kernels would need sixteen wavefronts per chain (4 097-8 192 parameters) the engine runs
+        # a one-pass model on the held streaming kernels instead (wn_launch.h, kMaxRegisterDimHeld): both are built
+        return chip if (waves_requested or nw < 16) else chip + [f"-DWN_ONLY_MEM_NW={HELD_WAVES}"]
     # the engine's own streaming choice depends on the model (one-pass gradients up to 16 384 dimensions run the
     # kernels that hold the moving end in registers, HELD_WAVES wavefronts per chain): both candidates are built
     if waves_requested or nw == HELD_WAVES:
@@ -78,7 +81,9 @@ def build_device_model(header: str, type_name: str, tag: str, model_id: int, num
     geo = f"mem{nw}" if streaming else f"{nw}x{epl}"
     out = os.path.join(out_dir, f"libwn_model_{tag}_{geo}.so")
     cmd = list(compiler) if compiler is not None else ["hipcc"] + HIPCC_FLAGS
-    cmd += ["-DWN_MODEL_PLUGIN", *geometry_defines(nw, epl, streaming, waves_per_chain > 0), "-I", CSRC, "-I", os.path.dirname(header),
+    cmd += ["-DWN_MODEL_PLUGIN",
+            *geometry_defines(nw, epl, streaming, waves_per_chain > 0 or elems_per_lane != 0 or preferred_elems_per_lane > 0),
+            "-I", CSRC, "-I", os.path.dirname(header),
             *extra_flags, "-shared", src, "-o", out,
             # the registration call resolves against the library the engines come from
             "-L", os.path.dirname(lib_file), "-l:" + os.path.basename(lib_file),

@@ -628,7 +628,7 @@ def main():
                         # first, theta, rho in and rho out in the second = 72*D by design
                         "two_pass_floor": ({"per_grad_eval_per_dim": 72, "GBps": algorithmic_gbps * 72.0 / 56.0,
                                             "frac": algorithmic_gbps * 72.0 / 56.0 / HBM_PEAK_GBPS}
-                                           if args.model in ("funnel", "rw1") else None),
+                                           if args.model in ("funnel", "rw1") and eng.held_tiles == 0 else None),
                         "note": "achieved / frac price the launch at SURVEY.md section 8(d)'s 56*D bytes per grad-eval (theta, "
                                 "rho, gradient and inverse mass read; theta, rho, gradient written).  The one-pass streaming "
                                 "kernel never stores a gradient (element-wise: recomputed) and, when it fits, keeps the "

@@ -20,6 +20,13 @@ WALNUTS_AMD_NO_LDS_MASS=1 WALNUTS_AMD_NO_FAR_END_SUMS=1 $B --no-cpu-baseline --n
 $B --no-cpu-baseline --no-parity-gate --phase warmup --model diag_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_cfg4_warmup.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --model diag_normal --chains 8192 --dim 12000 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_diag_12000.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --no-parity-gate --model std_normal --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_std_16384.json 2>> $OUT/bench.err
+# 4 097-8 192 dimensions: the held streaming kernels (the default for one-pass gradients) beside the (16, 8) register kernels
+$B --no-cpu-baseline --no-parity-gate --model diag_normal --chains 8192 --dim 8192 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_diag_8192.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --waves-per-chain 16 --elems-per-lane 8 --model diag_normal --chains 8192 --dim 8192 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_diag_8192_register_kernels.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --model diag_normal --chains 8192 --dim 6000 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_diag_6000.json 2>> $OUT/bench.err
+$B --no-cpu-baseline --no-parity-gate --waves-per-chain 16 --elems-per-lane 8 --model diag_normal --chains 8192 --dim 6000 --steps 8 --warmup 8 --adapt-iters 100 > $OUT/bench_diag_6000_register_kernels.json 2>> $OUT/bench.err
+# the funnel's two passes on sixteen wavefronts streaming both ends (round 4's geometry) beside the held default
+$B --no-cpu-baseline --no-parity-gate --waves-per-chain 16 --elems-per-lane -1 --model funnel --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 60 > $OUT/bench_funnel_16384_both_ends_streamed.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --config 5 --steps 16 --warmup 8 > $OUT/bench_cfg5_one_gpu.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_funnel_1024.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model rw1 --chains 16384 --dim 1024 --adapt-iters 150 > $OUT/bench_rw1_1024.json 2>> $OUT/bench.err

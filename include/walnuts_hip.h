@@ -204,8 +204,9 @@ typedef struct wn_config {
   double step_stabilization;        /* 1e-4 */
   double step_learn_rate_decay;     /* 0.5 */
   int32_t waves_per_chain;          /* NW: wavefronts cooperating on one chain */
-  int32_t elems_per_lane;           /* EPL: vector elements held per lane; -1 = streaming kernels (vectors in HBM,
-                                       the default above 8192 parameters) */
+  int32_t elems_per_lane;           /* EPL: vector elements held per lane; -1 = streaming kernels (the span pool in
+                                       HBM: the default above 8192 parameters -- above 4096 for a model whose
+                                       gradient is element-wise, wn_engine_held_tiles) */
   int32_t workgroups_per_cu;        /* resident chains per compute unit */
   int32_t lds_vectors;              /* span-pool vectors kept in LDS (-1: as many as fit) */
   int32_t reserved_cus;             /* compute units the persistent grid leaves free (e.g. for RCCL kernels that

@@ -70,8 +70,8 @@ def test_library_stands_in_for_libwalnutpy_at_load_time_and_refuses_host_models(
 def test_default_launch_geometry_by_model_and_dimension():
     """The engine's own choice of kernel (wn_launch.h, choose_geometry), asked through the C ABI without a GPU: one
     wavefront per chain up to 1 024 parameters; the streaming kernels that hold the trajectory's moving end in registers
-    (8 wavefronts) from 4 097 to 16 384 parameters for one-pass gradients, from 8 193 for the funnel's two-pass form;
-    sixteen wavefronts streaming both ends beyond 16 384 and for rw1 (halo reads)."""
+    (8 wavefronts) from 4 097 to 16 384 parameters for one-pass gradients and rw1, from 8 193 for the funnel (two passes,
+    sums only: its (16, 8) register kernels still win below); sixteen wavefronts streaming both ends beyond 16 384."""
     if not os.path.exists(ffi.DEFAULT_LIB):
         pytest.fail("walnuts_amd/lib/libwalnuts_hip.so is not built: run __graft_entry__.build()")
     lib = ffi.load_library()
@@ -79,7 +79,7 @@ def test_default_launch_geometry_by_model_and_dimension():
     assert [lanes("std_normal", D) for D in (100, 1024, 4096, 4097, 8192, 16384, 16385)] == [64, 64, 512, 512, 512, 512, 1024]
     assert [lanes("diag_normal", D) for D in (1024, 6000, 16384, 40000)] == [64, 512, 512, 1024]
     assert [lanes("funnel", D) for D in (128, 6000, 8192, 8193, 16384, 16385)] == [64, 1024, 1024, 512, 512, 1024]
-    assert [lanes("rw1", D) for D in (1024, 8192, 8193, 16384)] == [256, 1024, 1024, 1024]
+    assert [lanes("rw1", D) for D in (1024, 4096, 4097, 16384, 16385)] == [256, 1024, 512, 512, 1024]
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -71,6 +71,8 @@ def _need_gpu(gpu):
     ("std_normal", 12100, 6, None),         # held moving end, 12 of the 16 tiles, the last one ragged
     ("diag_normal", 6000, 8, None),         # ... the default from 4 097 parameters for one-pass gradients
     ("funnel", 9000, 6, None),              # held moving end, two passes per micro step (no halo)
+    ("rw1", 9000, 6, None),                 # ... with halo reads: wavefront-edge elements through LDS, the rest by lane shuffles
+    ("rw1", 4500, 8, None),                 # ... the default for rw1 from 4 097 parameters
     ("std_normal", 20000, 8, (8, -1)),      # streaming, 8 wavefronts per chain, ragged last tile
     ("std_normal", 1000, 24, (2, -1)),      # streaming forced at a small dimension
     ("diag_normal", 5000, 12, (16, -1)),

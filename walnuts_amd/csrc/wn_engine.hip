@@ -390,7 +390,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.cfg = cfg;
   e.device = cfg.device;
   e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params, ops.preferred_epl,
-                              ops.hold_tiles(wn::kHeldWaves), ops.one_pass);
+                              ops.hold_tiles(wn::kHeldWaves), ops.register_dim_limit);
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
   hipDeviceProp_t prop;
@@ -431,7 +431,8 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
       e.smem += vec_bytes;
       // ... and, if the chain's vectors fit the registers the kernels set aside for it, the moving end (TrajMem, HOLD)
       const char* nh = std::getenv("WALNUTS_AMD_NO_HELD_STATE");
-      const size_t tables = sizeof(double) * wn::kLdsTableDoubles;  // (such a kernel keeps the exp / log tables in LDS too)
+      // (such a kernel keeps the exp / log tables in LDS too, and a halo model's wavefront-edge elements)
+      const size_t tables = sizeof(double) * (wn::kLdsTableDoubles + 2 * wn::kMemHoldTiles * e.geo.nw);
       e.hold_moving_end = hold_fits && e.smem + tables <= budget && !(nh != nullptr && nh[0] == '1');
       if (e.hold_moving_end) e.smem += tables;
     }
@@ -1114,7 +1115,7 @@ int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int e
   try {
     return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, wn::model_ops(model).uses_params,
                                     wn::model_ops(model).preferred_epl, wn::model_ops(model).hold_tiles(wn::kHeldWaves),
-                                    wn::model_ops(model).one_pass).nw;
+                                    wn::model_ops(model).register_dim_limit).nw;
   } catch (...) {
     return -1;
   }

@@ -60,8 +60,10 @@ constexpr int kHeldWaves = 8;
 // ... down to where the register kernels need sixteen wavefronts per chain ((16, 8): 4 097-8 192 dimensions at 128
 // registers per wavefront, 400-600 bytes of them spilled, every reduction a 16-wavefront barrier): measured at 8 192
 // chains of the diagonal normal, 8 192 dimensions 5.9 ms per step against 11.6, 6 000 dimensions 4.4 against 11.1 --
-// while (8, 8) at 4 096 dimensions runs 1.08 ms against 3.13 (profiles/r05/cfg4_held_moving_end.md).
-constexpr int kMaxRegisterDimHeld = 4096;
+// while (8, 8) at 4 096 dimensions runs 1.08 ms against 3.13; rw1 (two passes, halo reads) 8 192 dimensions 49.4
+// against 77.1, 5 000: 36.4 against 66.4; the funnel (two passes, sums) is the exception: 29.3 against (16, 8)'s 18.6
+// at 8 192 dimensions (profiles/r05/cfg4_held_moving_end.md).  The model's own limit: ModelOps::register_dim_limit
+// (mem_register_dim_limit<Model>(), wn_traj.h: 4 096, the funnel's kind 8 192).
 
 // X(NW, EPL) -- the register kernels (TrajChip, wn_chip.h)
 #if defined(WN_ONLY_NW)
@@ -88,14 +90,12 @@ inline bool geometry_exists(int nw, int epl) {
 
 // elems_per_lane == -1 requests the streaming backend explicitly (it is the default above kMaxRegisterDim)
 // held_tiles: the model's ModelOps::hold_tiles(kHeldWaves) -- 0 for a model without such kernels (or not known yet);
-// one_pass: its ModelOps::one_pass
+// register_dim_limit: its ModelOps::register_dim_limit
 inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool params_in_registers = false,
-                                int preferred_epl = 0, int held_tiles = 0, bool one_pass = false) {
+                                int preferred_epl = 0, int held_tiles = 0, int register_dim_limit = kMaxRegisterDim) {
   Geometry g{0, 0, false};
   const bool held = held_tiles > 0 && dim <= 2 * 64 * kHeldWaves * held_tiles && mem_geometry_exists(kHeldWaves);
-  // (a two-pass model on the held kernels still loses to (16, 8): funnel at 8 192 dimensions 29.3 ms against 18.6)
-  const int max_register_dim =
-      (held && one_pass && nw_req == 0 && preferred_epl == 0) ? kMaxRegisterDimHeld : kMaxRegisterDim;
+  const int max_register_dim = (held && nw_req == 0) ? std::min(register_dim_limit, kMaxRegisterDim) : kMaxRegisterDim;
   if (epl_req < 0 || (dim > max_register_dim && epl_req == 0)) {
     g.mem = true;
     g.nw = nw_req > 0 ? nw_req : held ? kHeldWaves : default_mem_waves();
@@ -175,7 +175,8 @@ struct ModelOps {
   void (*host_params)(double* params, int num_params);  // validate / transform the parameter vector before upload
   void (*validate)(int num_params);
   int (*hold_tiles)(int nw);  // streaming kernels of nw wavefronts: tiles of the moving end held in registers (0: none)
-  bool one_pass;              // the streaming kernels take ONE pass per micro step (an element-wise gradient)
+  int register_dim_limit;     // the largest num_params the register kernels serve by default when the held streaming
+                              // kernels exist (mem_register_dim_limit<Model>(), wn_traj.h)
 };
 constexpr int kMaxModels = 64;
 inline const ModelOps** model_table() {

@@ -9,8 +9,8 @@
 //   struct MyModel {
 //     static constexpr bool kUsesParams;      // a parameter vector of num_params doubles exists (arrives as `mp`,
 //                                             //   padded with 1.0); wn_engine_create requires it then
-//     static constexpr bool kElementwise;     // grad[i] depends on theta[i] (and mp[i]) only: the streaming kernels for
-//                                             //   num_params > 8192 then take ONE pass per micro step; needs grad()
+//     static constexpr bool kElementwise;     // grad[i] depends on theta[i] (and mp[i]) only: the streaming kernels (the
+//                                             //   default above 4 096 parameters) then take ONE pass per micro step; needs grad()
 //                                             //   below (other models: the optional streaming form further down)
 //     static constexpr bool kCheapGrad;       // grad_elem() is one or two operations: the kernels then store no
 //                                             //   gradient vector at all and call grad_elem() at each use
@@ -27,8 +27,9 @@
 //     static void grad(Cx& cx, const double (&theta)[EPL], double (&g)[EPL], const double (&mp)[EPL], Aux&);
 //     static double finish(double sum, const Aux&, int num_params);   // -> logp
 //
-//     // optional -- "Streaming a model whose gradient is not element-wise": above 8 192 parameters the vectors live in
-//     // HBM and are processed two coordinates at a time, so eval() (which sees the lane's whole share at once) cannot
+//     // optional -- "Streaming a model whose gradient is not element-wise": above 8 192 parameters (4 096 by default
+//     // where the kernels that hold the trajectory's moving end in registers apply) the span pool lives in HBM and
+//     // vectors are processed two coordinates at a time, so eval() (which sees the lane's whole share at once) cannot
 //     // run.  A model states what its gradient needs beyond the coordinate itself, and gets two passes per micro step:
 //     static constexpr bool kStreamable = true;
 //     static constexpr int kStreamSums;       // 0..2 sums over ALL coordinates (funnel: sum x_i^2 and x_0)

@@ -1010,13 +1010,50 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   // 32 elements = 16 384 dimensions).  A micro step then reads NOTHING of its input from the memory system -- only the
   // new state goes out, because later U-turn tests, the selection and a turn-around name it as a pool buffer --, and
   // the steps of a multi-step leaf before the last one touch no memory at all.  `held`: the registers equal `cur`.
-  // (two-pass models: those without halo reads -- a neighbour's value sits in another lane's registers)
-  static constexpr bool kHold = HOLD > 0 && !(kTwoPass && ST::kHalo);
+  static constexpr bool kHold = HOLD > 0;
   static constexpr int kHeld = kHold ? 2 * HOLD : 1;
   double hth[kHeld], hrh[kHeld];
   bool held;
   static constexpr bool kTablesInLds = kHold;  // (LdsTables above: behind the inverse mass)
   const WN_LDS double* tab_lds;
+  // Halo models with a held moving end: a coordinate's neighbours are the lane's own other element, the adjacent
+  // lane's (a lane shuffle) or -- for the first and last lane of a wavefront -- the adjacent wavefront's / tile's edge
+  // element, which every wavefront publishes here before a pass reads positions: [tile][wavefront][lane 0's first |
+  // lane 63's second element] (TrajChip::shift's scheme, tile by tile because a pass updates the position in place).
+  WN_LDS double* edge_lds;
+  static constexpr int kEdgeDoubles = (HOLD > 0 ? HOLD : 1) * NW * 2;
+  __device__ __forceinline__ void publish_edges() {
+    if constexpr (kHold && ST::kHalo) {
+      __syncthreads();  // (readers of the previous publication are done)
+#pragma unroll
+      for (int k = 0; k < HOLD; ++k) {
+        if (k < tiles) {
+          if (this->lane == 0) edge_lds[(k * NW + this->wave) * 2] = hth[2 * k];
+          if (this->lane == 63) edge_lds[(k * NW + this->wave) * 2 + 1] = hth[2 * k + 1];
+        }
+      }
+      __syncthreads();  // (also with one wavefront per chain: lane 0 reads what lane 63 wrote)
+    }
+  }
+  // values at the coordinates before / after tile k's two, from the registers (halo()'s values: 0.0 beyond either end
+  // of the padded vector); the tile's own elements must still be the ones that were published
+  __device__ __forceinline__ void halo_held(int k, double (&prev)[2], double (&next)[2]) const {
+    prev[0] = prev[1] = next[0] = next[1] = 0.0;
+    if constexpr (kHold && ST::kHalo) {
+      prev[1] = hth[2 * k];
+      next[0] = hth[2 * k + 1];
+      const double up = __shfl_up(hth[2 * k + 1], 1, 64);
+      const double dn = __shfl_down(hth[2 * k], 1, 64);
+      const int w = this->wave;
+      const bool first = w == 0, last = w == NW - 1;
+      const double left_edge = !first ? edge_lds[(k * NW + w - 1) * 2 + 1]
+                                      : (k > 0 ? edge_lds[((k > 0 ? k - 1 : 0) * NW + NW - 1) * 2 + 1] : 0.0);
+      const double right_edge = !last ? edge_lds[(k * NW + w + 1) * 2]
+                                      : (k + 1 < tiles ? edge_lds[((k + 1 < HOLD ? k + 1 : k) * NW) * 2] : 0.0);
+      prev[0] = this->lane == 0 ? left_edge : up;
+      next[1] = this->lane == 63 ? right_edge : dn;
+    }
+  }
   __device__ __forceinline__ auto make_uniform_tab() const {
     if constexpr (kTablesInLds) {
       return LdsTables{tab_lds};
@@ -1077,6 +1114,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
     ut_hot = ut_far = 0.0;
     im_lds = (p.im_in_lds & 1u) ? bc + 2 + kShiftDoubles(NW) : nullptr;
     tab_lds = nullptr;
+    edge_lds = nullptr;
     if constexpr (kTablesInLds) {
       // (a kernel with HOLD is launched only with the inverse mass in LDS: wn_kernels.inc, Params::im_in_lds bit 2)
       WN_LDS double* tl = bc + 2 + kShiftDoubles(NW) + p.dim_padded;
@@ -1088,6 +1126,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
         tl[128 + this->lane] = t.lc;
       }
       tab_lds = tl;
+      edge_lds = tl + kLdsTableDoubles;
       __syncthreads();
     }
     n_pend = 0;
@@ -1599,6 +1638,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
 #pragma unroll
       for (int i = 0; i < ST::kSums; ++i) sums[i] = 0.0;
       v2f64 mass[2];
+      publish_edges();
       mass[0] = mass_tile(0, lb);
 #pragma unroll
       for (int k = 0; k < HOLD; ++k) {  // pass A: kick with the gradient at the old position, drift, the new position's sums
@@ -1608,15 +1648,15 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
         if (k < tiles) {
           const v2f64 m0 = mass[k & 1];
           double th2[2] = {hth[2 * k], hth[2 * k + 1]}, rh2[2] = {hrh[2 * k], hrh[2 * k + 1]};
-          double g2[2], mp2[2] = {1.0, 1.0};
-          const double none[2] = {0.0, 0.0};
+          double g2[2], mp2[2] = {1.0, 1.0}, prev[2], next[2];
+          halo_held(k, prev, next);
           if (Model::kUsesParams) {
             const v2f64 p0 = ld_tile(P.model_params, k, lb);
             mp2[0] = p0[0];
             mp2[1] = p0[1];
           }
           TileCx cx{pair_offset(k), P.dim};
-          Model::stream_grad(cx, th2, none, none, mp2, g2, a_in);
+          Model::stream_grad(cx, th2, prev, next, mp2, g2, a_in);
 #pragma unroll
           for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
 #pragma unroll
@@ -1629,6 +1669,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
         }
       }
       finish_sums(sums, a_out);
+      publish_edges();  // (the new position's)
       part = 0.0;
       ke = 0.0;
       mass[0] = mass_tile(0, lb);
@@ -1640,16 +1681,16 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
         if (k < tiles) {
           const v2f64 m0 = mass[k & 1];
           const double th2[2] = {hth[2 * k], hth[2 * k + 1]};
-          double rh2[2] = {hrh[2 * k], hrh[2 * k + 1]}, g2[2], mp2[2] = {1.0, 1.0};
-          const double none[2] = {0.0, 0.0};
+          double rh2[2] = {hrh[2 * k], hrh[2 * k + 1]}, g2[2], mp2[2] = {1.0, 1.0}, prev[2], next[2];
+          halo_held(k, prev, next);
           if (Model::kUsesParams) {
             const v2f64 p0 = ld_tile(P.model_params, k, lb);
             mp2[0] = p0[0];
             mp2[1] = p0[1];
           }
           TileCx cx{pair_offset(k), P.dim};
-          Model::stream_grad(cx, th2, none, none, mp2, g2, a_out);
-          Model::stream_logp(cx, th2, none, none, mp2, a_out, part);
+          Model::stream_grad(cx, th2, prev, next, mp2, g2, a_out);
+          Model::stream_logp(cx, th2, prev, next, mp2, a_out, part);
 #pragma unroll
           for (int j = 0; j < 2; ++j) rh2[j] = mad(half, g2[j], rh2[j]);
 #pragma unroll
@@ -1909,7 +1950,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
           TileCx cx{o, P.dim};
           if constexpr (kTwoPass) {
             (void)g2;
-            Model::stream_sums(cx, th2, mp2, sums);  // (the position's aux first: the log-density terms follow it)
+            if (ST::kHasSums) Model::stream_sums(cx, th2, mp2, sums);  // (the position's aux first: the log-density terms follow it)
           } else {
             Model::eval(cx, th2, g2, mp2, aux, part);
           }
@@ -1966,18 +2007,20 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
     if constexpr (kTwoPass) {
       finish_sums(sums, auxs[0]);
       aux = auxs[0];
+      publish_edges();
 #pragma unroll
       for (int k = 0; k < HOLD; ++k) {
         if (k < tiles) {
-          const double th2[2] = {hth[2 * k], hth[2 * k + 1]}, none[2] = {0.0, 0.0};
-          double mp2[2] = {1.0, 1.0};
+          const double th2[2] = {hth[2 * k], hth[2 * k + 1]};
+          double mp2[2] = {1.0, 1.0}, prev[2], next[2];
+          halo_held(k, prev, next);
           if (Model::kUsesParams) {
             const v2f64 p0 = ld_tile(P.model_params, k, lb);
             mp2[0] = p0[0];
             mp2[1] = p0[1];
           }
           TileCx cx{pair_offset(k), P.dim};
-          Model::stream_logp(cx, th2, none, none, mp2, auxs[0], part);
+          Model::stream_logp(cx, th2, prev, next, mp2, auxs[0], part);
         }
       }
     }
@@ -2250,12 +2293,22 @@ constexpr int mem_hold_tiles(int nw) {
   if constexpr (!(Model::kElementwise || is_streamable<Model>::value)) {
     return 0;  // (no streaming kernels at all)
   } else {
-    constexpr bool kCan = !(StreamTraits<Model>::kTwoPass && StreamTraits<Model>::kHalo);
 #if defined(WN_SIM_GEOMETRIES)
-    return kCan ? kMemHoldTiles : 0;  // (tests/cpusim: every geometry it builds)
+    return kMemHoldTiles;  // (tests/cpusim: every geometry it builds)
 #else
-    return (nw == 8 && kCan) ? kMemHoldTiles : 0;
+    return nw == 8 ? kMemHoldTiles : 0;
 #endif
+  }
+}
+
+// num_params up to which the register kernels stay the default for a model that has held streaming kernels
+// (wn_launch.h, beside kHeldWaves: measured): two passes with sums only (the funnel) keep (16, 8)
+template <class Model>
+constexpr int mem_register_dim_limit() {
+  if constexpr (!(Model::kElementwise || is_streamable<Model>::value)) {
+    return 8192;
+  } else {
+    return (StreamTraits<Model>::kTwoPass && !StreamTraits<Model>::kHalo) ? 8192 : 4096;
   }
 }
 

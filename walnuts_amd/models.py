@@ -48,7 +48,7 @@ def geometry_defines(nw: int, epl: int, streaming: bool, waves_requested: bool =
     if not streaming:
         chip = [f"-DWN_ONLY_NW={nw}", f"-DWN_ONLY_EPL={epl}"]
         # where the register kernels would need sixteen wavefronts per chain (4 097-8 192 parameters) the engine runs
-        # a one-pass model on the held streaming kernels instead (wn_launch.h, kMaxRegisterDimHeld): both are built
+        # most models on the held streaming kernels instead (wn_launch.h, ModelOps::register_dim_limit): both are built
         return chip if (waves_requested or nw < 16) else chip + [f"-DWN_ONLY_MEM_NW={HELD_WAVES}"]
     # the engine's own streaming choice depends on the model (one-pass gradients up to 16 384 dimensions run the
     # kernels that hold the moving end in registers, HELD_WAVES wavefronts per chain): both candidates are built

@@ -19,3 +19,8 @@ gate cfg3 --model funnel --chains 16384 --dim 128 --adapt-iters 300
 gate funnel1024 --model funnel --chains 16384 --dim 1024 --adapt-iters 150
 gate rw1 --model rw1 --chains 16384 --dim 1024 --adapt-iters 150
 gate d256 --chains 65536 --dim 256
+# the streaming kernels that hold the trajectory's moving end in registers (fewer chains: the oracle pays per dimension)
+gate cfg4 --model diag_normal --chains 8192 --dim 16384 --adapt-iters 100 --gate-chains 96 --gate-transitions 16
+gate diag6000 --model diag_normal --chains 8192 --dim 6000 --adapt-iters 100 --gate-chains 128 --gate-transitions 16
+gate funnel16384 --model funnel --chains 8192 --dim 16384 --adapt-iters 60 --gate-chains 32 --gate-transitions 8
+gate rw1_16384 --model rw1 --chains 8192 --dim 16384 --adapt-iters 60 --gate-chains 32 --gate-transitions 8

@@ -164,6 +164,12 @@ def measured_traffic(args, D, chains_local, transitions_per_average_launch):
     switched = [v for v in ("WALNUTS_AMD_NO_LDS_MASS", "WALNUTS_AMD_NO_FAR_END_SUMS", "WALNUTS_AMD_LIB") if os.environ.get(v)]
     if switched:   # (the recorded passes ran the library as built, with its default switches)
         return None, "not recorded for this run's switches (" + ", ".join(switched) + ")"
+    # ... and the engine's own choice of kernel: a run that asks for a launch geometry runs another kernel
+    asked = [f"--{k.replace('_', '-')} {getattr(args, k)}" for k, default in
+             (("waves_per_chain", 0), ("elems_per_lane", 0), ("workgroups_per_cu", 0), ("lds_vectors", -1))
+             if getattr(args, k) != default]
+    if asked:
+        return None, "not recorded for this run's launch geometry (" + ", ".join(asked) + ")"
     try:
         entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except OSError:

@@ -101,12 +101,14 @@ def main():
     ap.add_argument("--held", action="store_true",
                     help="the streaming kernels that hold the moving end in registers only: one-pass models, 8 wavefronts "
                          "per chain, 1 000-16 384 dimensions (1-16 tiles per lane), few chains")
+    ap.add_argument("--held-two-pass", action="store_true",
+                    help="... the same for the two-pass models (funnel: sums; rw1: halo reads through lane shuffles and LDS)")
     a = ap.parse_args()
     t0 = time.time()
     case_kw = {}
-    if a.held:
+    if a.held or a.held_two_pass:
         case_kw = dict(mem_waves=(8,), streaming_share=1.0, streaming_dims=(1000, 16385), chain_counts=(1, 2, 3, 5),
-                       models=("std_normal", "diag_normal"))
+                       models=("funnel", "rw1") if a.held_two_pass else ("std_normal", "diag_normal"))
     done, failed, tally = campaign(a.seed, a.seconds, a.cases, a.verbose, **case_kw)
     bad = len(failed)
     print("# bit-exact cases by (model, waves x elements per lane): count, gradient evaluations compared, "

@@ -77,4 +77,12 @@ def test_fifth_model_without_rebuilding_the_library(gpu, oracle, tmp_path):
     so2 = models.build_device_model(HEADER, "user::MyDiagNormal", "user_diag_100", 21, 100, out_dir=str(tmp_path))
     mid2 = models.load_device_model(so2, "user_diag_100")
     check_against_oracle(mid2, None, [(100, 64, None, {})])
+    # 6 000 parameters: the register kernels' (16, 8) AND the streaming kernels that hold the moving end in registers
+    # are built (models.geometry_defines); the engine picks the latter for an element-wise gradient
+    so3 = models.build_device_model(HEADER, "user::MyDiagNormal", "user_diag_6000", 22, 6000, out_dir=str(tmp_path))
+    mid3 = models.load_device_model(so3, "user_diag_6000")
+    e = wa.DeviceEngine(mid3, 6000, 4, wa.default_config(), params=np.linspace(0.5, 2.0, 6000))
+    assert e.streaming and e.held_tiles == 16 and e.lanes == 512
+    del e
+    check_against_oracle(mid3, None, [(6000, 6, None, {}), (6000, 4, (16, 8), {})])
     assert os.path.getmtime(lib._name) == before   # the library itself was not touched

@@ -287,6 +287,8 @@ inline double wave_sum_packed(double a, double b) {  // a's total in lanes 0-31,
   return (wnsim::tidx.x & 63u) < 32u ? sa : sb;
 }
 inline int opaque_scalar_add(int a, int b) { return a + b; }
+inline double lane_below(double x) { return __shfl_up(x, 1u, 64); }
+inline double lane_above(double x) { return __shfl_down(x, 1u, 64); }
 inline double opaque_uniform(double v) { return v; }
 inline void launder(double&) {}
 using GlobalBytes = char*;

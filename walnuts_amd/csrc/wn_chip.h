@@ -143,8 +143,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       // pair m - 1's odd element / pair m + 1's even element, m = k * L + tid
-      const double up = __shfl_up(v[2 * k + 1], 1, 64);
-      const double dn = __shfl_down(v[2 * k], 1, 64);
+      const double up = lane_below(v[2 * k + 1]);
+      const double dn = lane_above(v[2 * k]);
       double left_edge, right_edge;  // what lane 0 / lane 63 of this wavefront take instead
       if (NW == 1) {
         left_edge = k > 0 ? __shfl(v[2 * (k > 0 ? k - 1 : 0) + 1], 63, 64) : 0.0;

@@ -432,7 +432,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
       // ... and, if the chain's vectors fit the registers the kernels set aside for it, the moving end (TrajMem, HOLD)
       const char* nh = std::getenv("WALNUTS_AMD_NO_HELD_STATE");
       // (such a kernel keeps the exp / log tables in LDS too, and a halo model's wavefront-edge elements)
-      const size_t tables = sizeof(double) * (wn::kLdsTableDoubles + 2 * wn::kMemHoldTiles * e.geo.nw);
+      const size_t tables = sizeof(double) * (wn::kLdsTableDoubles + 2 * 2 * wn::kMemHoldTiles * e.geo.nw);  // (two copies of the edges)
       e.hold_moving_end = hold_fits && e.smem + tables <= budget && !(nh != nullptr && nh[0] == '1');
       if (e.hold_moving_end) e.smem += tables;
     }

@@ -89,6 +89,23 @@ __device__ __forceinline__ double lane_value(double v, int src_lane) {
 }
 
 __device__ __forceinline__ int lane_value(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+// The value of the lane below / above (lane 0 / lane 63 keep their own): one DPP move per dword (wave_shr:1 /
+// wave_shl:1, a full-wavefront shift gfx9 still has) where __shfl_up / __shfl_down are two ds_bpermute round trips
+// through the LDS crossbar each.  For models whose gradient reads the neighbouring coordinates (rw1).
+__device__ __forceinline__ double lane_below(double x) {
+  const unsigned long long b = bits_of(x);
+  int lo = static_cast<int>(static_cast<unsigned>(b)), hi = static_cast<int>(static_cast<unsigned>(b >> 32));
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return double_of((static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) | static_cast<unsigned>(lo));
+}
+__device__ __forceinline__ double lane_above(double x) {
+  const unsigned long long b = bits_of(x);
+  int lo = static_cast<int>(static_cast<unsigned>(b)), hi = static_cast<int>(static_cast<unsigned>(b >> 32));
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return double_of((static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) | static_cast<unsigned>(lo));
+}
 // reg[dst_lane] = v for a wave-uniform value and index: a select on the lane id (v_writelane_b32 would do it in one
 // instruction per dword, but this compiler has no builtin for it and hands an inline-asm "s" operand a VECTOR
 // register whenever it knows the value uniform without having it in a scalar one)

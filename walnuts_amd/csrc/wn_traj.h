@@ -1020,11 +1020,16 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   // lane's (a lane shuffle) or -- for the first and last lane of a wavefront -- the adjacent wavefront's / tile's edge
   // element, which every wavefront publishes here before a pass reads positions: [tile][wavefront][lane 0's first |
   // lane 63's second element] (TrajChip::shift's scheme, tile by tile because a pass updates the position in place).
+  // (Two copies, written alternately: a wavefront that publishes again has passed the barrier of the publication in
+  // between, which every wavefront reaches only after its reads of the copy about to be overwritten.)
   WN_LDS double* edge_lds;
+  WN_LDS double* edge_base;
+  int edge_parity;
   static constexpr int kEdgeDoubles = (HOLD > 0 ? HOLD : 1) * NW * 2;
   __device__ __forceinline__ void publish_edges() {
     if constexpr (kHold && ST::kHalo) {
-      __syncthreads();  // (readers of the previous publication are done)
+      edge_parity ^= 1;
+      edge_lds = edge_base + edge_parity * kEdgeDoubles;
 #pragma unroll
       for (int k = 0; k < HOLD; ++k) {
         if (k < tiles) {
@@ -1042,8 +1047,8 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
     if constexpr (kHold && ST::kHalo) {
       prev[1] = hth[2 * k];
       next[0] = hth[2 * k + 1];
-      const double up = __shfl_up(hth[2 * k + 1], 1, 64);
-      const double dn = __shfl_down(hth[2 * k], 1, 64);
+      const double up = lane_below(hth[2 * k + 1]);
+      const double dn = lane_above(hth[2 * k]);
       const int w = this->wave;
       const bool first = w == 0, last = w == NW - 1;
       const double left_edge = !first ? edge_lds[(k * NW + w - 1) * 2 + 1]
@@ -1114,7 +1119,8 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
     ut_hot = ut_far = 0.0;
     im_lds = (p.im_in_lds & 1u) ? bc + 2 + kShiftDoubles(NW) : nullptr;
     tab_lds = nullptr;
-    edge_lds = nullptr;
+    edge_lds = edge_base = nullptr;
+    edge_parity = 0;
     if constexpr (kTablesInLds) {
       // (a kernel with HOLD is launched only with the inverse mass in LDS: wn_kernels.inc, Params::im_in_lds bit 2)
       WN_LDS double* tl = bc + 2 + kShiftDoubles(NW) + p.dim_padded;
@@ -1126,7 +1132,8 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
         tl[128 + this->lane] = t.lc;
       }
       tab_lds = tl;
-      edge_lds = tl + kLdsTableDoubles;
+      edge_base = tl + kLdsTableDoubles;
+      edge_lds = edge_base;
       __syncthreads();
     }
     n_pend = 0;

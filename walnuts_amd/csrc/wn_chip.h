@@ -95,6 +95,7 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
   static constexpr int kOther = -4;           // "this vector is the other end's theta" (kOtherRegs)
   Parked oth[EPL], orh[EPL];
   int n_lds;                                  // pool buffers [0, n_lds) live in LDS, the rest in the HBM arena
+  int shift_parity = 0;                       // which copy of the shift scratch the last exchange used
 #if defined(WN_COUNT_POOL)
   int pool_count[4];
 #endif
@@ -131,7 +132,11 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       prev[2 * k + 1] = v[2 * k];
       next[2 * k] = v[2 * k + 1];
     }
-    WN_LDS double* sh = this->bcast + 2;  // [pair slot][wavefront][first lane's even | last lane's odd]
+    // [pair slot][wavefront][first lane's even | last lane's odd], two copies used alternately: a wavefront that writes
+    // a copy again has passed the barrier of the exchange in between, which every wavefront reaches only after its
+    // reads of that copy -- one barrier per exchange instead of two
+    shift_parity ^= 1;
+    WN_LDS double* sh = this->bcast + 2 + shift_parity * (2 * 8 * NW);
     if (NW > 1) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
@@ -157,7 +162,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       prev[2 * k] = lane == 0 ? left_edge : up;
       next[2 * k + 1] = lane == 63 ? right_edge : dn;
     }
-    if (NW > 1) __syncthreads();  // the scratch is free again
   }
 
   // ---- vector buffers -----------------------------------------------------------------------------

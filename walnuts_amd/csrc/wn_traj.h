@@ -51,7 +51,8 @@ constexpr int kRedDoubles(int nw) { return 2 * kRedStride(nw); }
 // cx.shift() scratch: the edge lanes of every wavefront publish one value per pair slot (at most 8 pairs per lane)
 // (LDS tail of a workgroup: per-wave Meta | reduction scratch | broadcast word | next-chain words | shift scratch |
 // streaming kernels: the inverse mass vector, when the engine parks it there)
-constexpr int kShiftDoubles(int nw) { return 2 * 8 * nw; }
+// (two copies, used alternately: one barrier per exchange -- see TrajChip::shift)
+constexpr int kShiftDoubles(int nw) { return 2 * 2 * 8 * nw; }
 
 // The exp / log tables (wn_devmath.h) as one entry per lane of three VGPR pairs.  A wave-uniform argument looks its
 // entries up with v_readlane (a few cycles, no memory), per-lane arguments with a lane gather.
@@ -1025,6 +1026,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   WN_LDS double* edge_lds;
   WN_LDS double* edge_base;
   int edge_parity;
+  double edge_vec;  // (lane k: tile k's left neighbour; lane HOLD + k: its right neighbour -- of the last publication)
   static constexpr int kEdgeDoubles = (HOLD > 0 ? HOLD : 1) * NW * 2;
   __device__ __forceinline__ void publish_edges() {
     if constexpr (kHold && ST::kHalo) {
@@ -1038,6 +1040,24 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
         }
       }
       __syncthreads();  // (also with one wavefront per chain: lane 0 reads what lane 63 wrote)
+      // every edge value this wavefront's passes will want, fetched ONCE: lane k < HOLD takes tile k's left neighbour
+      // (the element before the wavefront's first), lane HOLD + k its right neighbour; halo_held hands them out with
+      // v_readlane -- a tile at a time they were two LDS round trips per tile and pass
+      static_assert(2 * (HOLD > 0 ? HOLD : 1) <= 64, "one lane per tile and side");
+      const int l = this->lane, w = this->wave;
+      const int k = l < HOLD ? l : l - HOLD;
+      const bool left = l < HOLD, first = w == 0, last = w == NW - 1;
+      int idx;
+      bool have;
+      if (left) {
+        have = !first || k > 0;
+        idx = !first ? (k * NW + w - 1) * 2 + 1 : ((k > 0 ? k - 1 : 0) * NW + NW - 1) * 2 + 1;
+      } else {
+        have = !last || k + 1 < tiles;
+        idx = !last ? (k * NW + w + 1) * 2 : ((k + 1 < HOLD ? k + 1 : k) * NW) * 2;
+      }
+      have = have && l < 2 * HOLD && k < tiles;
+      edge_vec = have ? edge_lds[have ? idx : 0] : 0.0;
     }
   }
   // values at the coordinates before / after tile k's two, from the registers (halo()'s values: 0.0 beyond either end
@@ -1049,12 +1069,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
       next[0] = hth[2 * k + 1];
       const double up = lane_below(hth[2 * k + 1]);
       const double dn = lane_above(hth[2 * k]);
-      const int w = this->wave;
-      const bool first = w == 0, last = w == NW - 1;
-      const double left_edge = !first ? edge_lds[(k * NW + w - 1) * 2 + 1]
-                                      : (k > 0 ? edge_lds[((k > 0 ? k - 1 : 0) * NW + NW - 1) * 2 + 1] : 0.0);
-      const double right_edge = !last ? edge_lds[(k * NW + w + 1) * 2]
-                                      : (k + 1 < tiles ? edge_lds[((k + 1 < HOLD ? k + 1 : k) * NW) * 2] : 0.0);
+      const double left_edge = lane_value(edge_vec, k), right_edge = lane_value(edge_vec, HOLD + k);
       prev[0] = this->lane == 0 ? left_edge : up;
       next[1] = this->lane == 63 ? right_edge : dn;
     }
@@ -1121,6 +1136,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
     tab_lds = nullptr;
     edge_lds = edge_base = nullptr;
     edge_parity = 0;
+    edge_vec = 0.0;
     if constexpr (kTablesInLds) {
       // (a kernel with HOLD is launched only with the inverse mass in LDS: wn_kernels.inc, Params::im_in_lds bit 2)
       WN_LDS double* tl = bc + 2 + kShiftDoubles(NW) + p.dim_padded;

@@ -1,5 +1,5 @@
 """GPU probe: the timeline of one workgroup of the STREAMING kernels (library built with
-`build_variant.sh tlm "-DWN_TIMELINE -DWN_TIMELINE_MARKS=256 -DWN_ONLY_MEM_NW=8"`): shader-clock intervals between the marks of the tree loop,
+`build_variant.sh tlm "-DWN_TIMELINE -DWN_TIMELINE_MARKS=192 -DWN_ONLY_MEM_NW=8"`): shader-clock intervals between the marks of the tree loop,
 per (mark -> next mark) edge.  usage: timeline_mem.py [model] [dim] [chains] [waves per chain]"""
 import ctypes as C, collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,9 +23,9 @@ for _ in range(3): e.sample_step()
 e.synchronize()
 e.timing_reset()
 e.sample_steps(1); e.synchronize()
-print("launch ms", e.kernel_times_ms().mean())
+print("launch ms", e.kernel_times_ms().mean(), "held tiles", e.held_tiles, "(0: the marks' LDS left no room for the inverse mass -- fewer WN_TIMELINE_MARKS)")
 get = getattr(e.lib, "wn_debug_timeline_" + model)
-N = 256
+N = 192
 buf = (C.c_ulonglong * N)()
 get(buf, N)
 rec = [(int(v) >> 6, int(v) & 63) for v in buf if v]

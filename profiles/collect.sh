@@ -47,6 +47,13 @@ rm -rf $OUT/headline_trace
 # the whole drop-in call, phase by phase (WALNUTS_AMD_TIMING), and a longer run of the randomised parity campaign
 (cd $ROOT && WALNUTS_AMD_TIMING=1 timeout 900 python3 tests/gpu_probes/sample_device_e2e.py > $OUT/sample_device_e2e.txt 2>&1)
 (cd $ROOT && timeout 600 python3 tests/gpu_probes/fuzz_parity.py --seconds 240 --seed 506 > $OUT/fuzz_parity.txt 2>&1; tail -3 $OUT/fuzz_parity.txt)
+# (set COLLECT_PARITY=1 for the wide reference-order gate and the campaigns on the held streaming kernels as well: ~12 min)
+if [ "${COLLECT_PARITY:-0}" = 1 ]; then
+  (cd $ROOT && { echo "# device (fused multiply-adds, the default) against the reference-order oracle"; bash tests/gpu_probes/exp/wide_gate.sh;
+     echo "# device with every product rounded (--fma 0)"; WIDE_GATE_ARGS="--fma 0" bash tests/gpu_probes/exp/wide_gate.sh; } > $OUT/parity_gate_wide.txt 2>&1)
+  (cd $ROOT && timeout 400 python3 tests/gpu_probes/fuzz_parity.py --held --seconds 240 --seed 514 > $OUT/fuzz_parity_held.txt 2>&1; tail -1 $OUT/fuzz_parity_held.txt)
+  (cd $ROOT && timeout 400 python3 tests/gpu_probes/fuzz_parity.py --held-two-pass --seconds 300 --seed 513 > $OUT/fuzz_parity_held_two_pass.txt 2>&1; tail -1 $OUT/fuzz_parity_held_two_pass.txt)
+fi
 for f in $OUT/bench_*.json; do python3 -c "
 import json,sys
 d=json.load(open('$f')); r=d['roofline']

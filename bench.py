@@ -114,6 +114,14 @@ def parse():
                          "one pair around the timed region")
     ap.add_argument("--phase", default="sampling", choices=["sampling", "warmup"],
                     help="which transition kind is timed")
+    ap.add_argument("--min-launches", type=int, default=12,
+                    help="the timed region holds at least this many whole launches (--steps is a minimum)")
+    ap.add_argument("--exact-steps", action="store_true",
+                    help="time exactly --steps transitions (the last launch short) instead of whole launches")
+    ap.add_argument("--legs", default="auto",
+                    help="auto: the default headline run on one GPU also measures BASELINE configs #2-#4 and the headline's "
+                         "warmup phase (short legs under \"configs\" of the same JSON line); none; or a comma list of "
+                         "cfg2,cfg3,cfg4,headline_warmup")
     return ap.parse_args()
 
 
@@ -255,6 +263,12 @@ def cpu_baseline(args, D):
 
 
 def parity_gate(args, D, cfg_kwargs):
+    return reference_order_gate(args.model, D, cfg_kwargs, chains=args.gate_chains, transitions=args.gate_transitions,
+                                adapt_iters=args.adapt_iters, seed=args.seed, phase=args.phase)
+
+
+def reference_order_gate(model, D, cfg_kwargs, *, chains=64, transitions=8, adapt_iters=100, seed=1234, phase="sampling",
+                         lib_path=None, model_id=None, params=None, oracle_model_id=None):
     """SURVEY.md section 8d "parity gate in the same run": a subset of chains replayed on the CPU restatement in the
     REFERENCE's arithmetic (libm exp/log, every product rounded) with the identical random stream, one transition at a
     time from the device's own state -- under BOTH summation orders the reference side can have: "eigen_sse2", the
@@ -263,50 +277,82 @@ def parity_gate(args, D, cfg_kwargs):
     left-to-right loops.  Per order: the max relative difference of the selected position per transition (north star:
     <= 1e-10), how many chains built the identical tree, and how many decisions sat within 1e-12 (relative) of their
     threshold -- |H0-H1| <= max_error (walnuts.hpp:339), the U-turn signs (:199-200), log u < delta (:379) -- i.e.
-    where a different summation order could have flipped the tree.  The top-level fields are the worst over both."""
+    where a different summation order could have flipped the tree.  The top-level fields are the worst over both.
+    phase "warmup": the gated transitions are ADAPTIVE ones (adaptive_walnuts.hpp:234-251) -- the oracle is handed the
+    device's Adam state, mass-estimator planes and min-micro-steps value before each, and Adam's six numbers and the
+    estimator's planes after the transition are compared as well (`max_rel_diff_adapt`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import walnuts_amd as wa
     import wno
 
-    Cg, T = args.gate_chains, args.gate_transitions
-    model_id, params = model_setup(args.model, D)
-    dev = wa.DeviceEngine(model_id, D, Cg, wa.default_config(**cfg_kwargs), params=params)
+    Cg, T = chains, transitions
+    if model_id is None:
+        model_id, params = model_setup(model, D)
+    dcfg = wa.default_config(lib_path, **cfg_kwargs)
+    dev = wa.DeviceEngine(model_id, D, Cg, dcfg, params=params, lib_path=lib_path)
     orders = {"eigen_sse2": wno.REDUCE_EIGEN_SSE2, "sequential": 0}
     orcs = {}
     for name, lanes in orders.items():
         ocfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=lanes)
-        orcs[name] = wno.Engine(oracle_model(args.model), D, Cg, ocfg, params=params)
+        orcs[name] = wno.Engine(oracle_model(model) if oracle_model_id is None else oracle_model_id, D, Cg, ocfg, params=params)
         orcs[name].set_tie_tolerance(1e-12)
-        orcs[name].seed_chains(args.seed + 1, 0)
-    dev.init_positions(args.seed, 0, 2.0)
+        orcs[name].seed_chains(seed + 1, 0)
+    dev.init_positions(seed, 0, 2.0)
     dev.init_masses_from_grad(1e-5)
     dev.set_step_sizes(1.0)
-    dev.adapt_step(args.seed, 0)
-    dev.seed_chains(args.seed + 1, 0)
-    adapt = min(args.adapt_iters, 40)
+    dev.adapt_step(seed, 0)
+    dev.seed_chains(seed + 1, 0)
+    adapt = min(adapt_iters, 40)
+    warm = phase == "warmup"
     for _ in range(adapt):
         dev.warmup_step()
-    dev.freeze()
+    if warm:
+        for orc in orcs.values():   # (the adapters must exist before their state is handed in)
+            orc.set_positions(dev.positions())
+            orc.init_masses_from_grad(1e-5)
+            orc.set_step_sizes(1.0)
+    else:
+        dev.freeze()
     dev.synchronize()
     inv_mass, steps, mm = dev.inv_mass(), dev.step_sizes(), dev.min_micro()
-    rec = {name: {"rel": [], "rel_lp": [], "same": []} for name in orders}
+    rec = {name: {"rel": [], "rel_lp": [], "same": [], "rel_adapt": []} for name in orders}
+
+    def plane_rel(x, y):
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        return float(np.max(np.abs(x - y) / np.maximum(np.abs(y), 1e-300))) if x.size else 0.0
+
     for t in range(T):
         pos = dev.positions()
         g_dev0 = dev.grad_evals().copy()
         g_orc0 = {}
+        if warm:
+            adam0, est0, mm0, it0 = dev.adam(), dev.estimator(), dev.min_micro(), dev.iteration
         for name, orc in orcs.items():
             orc.set_positions(pos)
-            orc.set_sampler_state(inv_mass, steps, mm)
+            if warm:
+                orc.set_adapt_state(adam0, est0, mm0, it0)
+            else:
+                orc.set_sampler_state(inv_mass, steps, mm)
             orc.set_transition_index(adapt + t)
             g_orc0[name] = orc.grad_evals().copy()
-        dev.sample_step()
+        dev.warmup_step() if warm else dev.sample_step()
         for orc in orcs.values():
-            orc.sample_step(host_cores())
+            orc.warmup_step(host_cores()) if warm else orc.sample_step(host_cores())
         dev.synchronize()
         a, la = dev.positions(), dev.logp()
         for name, orc in orcs.items():
             b, lb = orc.positions(), orc.logp()
             same = (dev.depths() == orc.depths()) & ((dev.grad_evals() - g_dev0) == (orc.grad_evals() - g_orc0[name]))
+            if warm:
+                de, oe = dev.estimator(), orc.estimator()
+                # Adam: theta, m, v, t, b1pow, b2pow (m passes through zero: relative to the row's largest magnitude)
+                da, oa = dev.adam()[same], orc.adam()[same]
+                ra = float(np.max(np.abs(da - oa) / np.maximum(np.max(np.abs(oa), axis=1, keepdims=True), 1e-300))) if same.any() else 0.0
+                # the estimator's means pass through zero as well: relative to each chain's largest entry of the plane
+                rp = max(float(np.max(np.max(np.abs(de[k][same] - oe[k][same]), axis=1)
+                                      / np.maximum(np.max(np.abs(oe[k][same]), axis=1), 1e-300))) if same.any() else 0.0
+                         for k in ("draw_mean", "draw_ssd", "score_mean", "score_ssd"))
+                rec[name]["rel_adapt"].append(max(ra, rp, plane_rel(de["weights"][same], oe["weights"][same])))
             r = np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-300)
             # the selected position is a leaf of element-wise leapfrog arithmetic; its log density is a sum over D
             # and shows the summation orders
@@ -324,10 +370,17 @@ def parity_gate(args, D, cfg_kwargs):
             "chains_with_identical_tree_per_transition": r["same"],
             "tree_mismatches": int(Cg * T - sum(r["same"])),
             "near_ties_1e-12": {k: {"near": v[0], "decisions": v[1]} for k, v in ties.items()}}
+        if warm:
+            out_orders[name]["max_rel_diff_adapt"] = float(np.max(r["rel_adapt"]))
     worst = max(o["max_rel_diff"] for o in out_orders.values())
     worst_lp = max(o["max_rel_diff_logp"] for o in out_orders.values())
-    return {"chains": Cg, "transitions": T,
-            "device_arithmetic": "fused multiply-adds" if wa.default_config(**cfg_kwargs).fused_multiply_add else "every product rounded",
+    lanes_per_chain, streaming = dev.lanes, bool(dev.streaming)
+    held_tiles = dev.held_tiles if streaming else 0
+    dev.close()
+    return {"chains": Cg, "transitions": T, "phase": phase,
+            **({"max_rel_diff_adapt": max(o["max_rel_diff_adapt"] for o in out_orders.values())} if warm else {}),
+            "device_arithmetic": "fused multiply-adds" if dcfg.fused_multiply_add else "every product rounded",
+            "kernel": {"lanes_per_chain": lanes_per_chain, "streaming": streaming, "held_tiles": held_tiles},
             "reference_side": "libm, every product rounded; summation orders: Eigen 3.4 SSE2 redux (restated) and sequential",
             "orders": out_orders,
             "max_rel_diff": worst, "max_rel_diff_logp": worst_lp,
@@ -436,9 +489,6 @@ def main():
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
     import torch
 
-    import walnuts_amd as wa
-    from walnuts_amd.distributed import DrawGather, shard_chains
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -462,6 +512,63 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    out = run_job(args, rank, local_rank, world, dist)
+    if rank == 0:
+        legs = config_legs(args, world)
+        if legs:
+            # the other single-GPU BASELINE configurations and the headline's warmup phase, measured in this same run
+            # (throughput for the sampling phase and separately for warmup)
+            out["configs"] = {}
+            for name, spec in legs.items():
+                t_leg = time.perf_counter()
+                leg_args = argparse.Namespace(**{**vars(args), **spec})
+                rec = run_job(leg_args, rank, local_rank, world, dist, cpu=False)
+                out["configs"][name] = {k: rec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config",
+                                                            "roofline", "parity_gate") if k in rec}
+                out["configs"][name]["leg_wall_s"] = time.perf_counter() - t_leg
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# BASELINE.json configs #2-#4 (definitions: SURVEY.md section 8d, examples/examples.cpp:20-31) and the headline's warmup
+# phase: short legs of the default single-GPU run, each with its own roofline and reference-order parity gate
+CONFIG_LEGS = {
+    "cfg2": dict(model="ill_normal", chains=4096, dim=1024, adapt_iters=300, phase="sampling",
+                 gate_chains=64, gate_transitions=4),
+    "cfg3": dict(model="funnel", chains=16384, dim=128, adapt_iters=300, phase="sampling",
+                 gate_chains=64, gate_transitions=4),
+    "cfg4": dict(model="diag_normal", chains=8192, dim=16384, adapt_iters=100, phase="sampling",
+                 gate_chains=64, gate_transitions=4),
+    "headline_warmup": dict(model="std_normal", chains=HEADLINE_CHAINS, dim=1024, adapt_iters=100, phase="warmup",
+                            gate_chains=64, gate_transitions=4),
+}
+
+
+def config_legs(args, world):
+    """Which extra legs this invocation runs: `--legs auto` (default) = all of CONFIG_LEGS when the line is the default
+    headline workload on one GPU (what the driver runs), none otherwise; `--legs none`; or a comma list."""
+    if world != 1 or args.legs == "none":
+        return {}
+    if args.legs == "auto":
+        headline = (args.model, args.chains, args.dim, args.phase, args.config, args.scaling) == (
+            "std_normal", HEADLINE_CHAINS, 1024, "sampling", 0, "strong")
+        geometry = (args.waves_per_chain, args.elems_per_lane, args.workgroups_per_cu, args.lds_vectors,
+                    args.chain_groups) != (0, 0, 0, -1, 0)
+        return dict(CONFIG_LEGS) if headline and not geometry and not args.no_parity_gate else {}
+    return {k: CONFIG_LEGS[k] for k in args.legs.split(",")}
+
+
+def run_job(args, rank, local_rank, world, dist, cpu=True):
+    """One workload on this process group: engine set-up, untimed adaptation and warm-up launches, the timed region,
+    roofline, and on one GPU the reference-order parity gate (and with `cpu` the CPU baseline).  Returns the record on
+    rank 0."""
+    import torch
+
+    import walnuts_amd as wa
+    from walnuts_amd.distributed import DrawGather, shard_chains
 
     D = args.dim
     if args.config == 5:
@@ -545,11 +652,21 @@ def main():
         eng.synchronize()
         torch.cuda.synchronize()
 
+    # --steps / --warmup are MINIMA: the timed region holds whole launches only (T transitions each), and at least
+    # --min-launches of them -- the first dispatches after a join run 10-50 % off steady state, and a region of 8+8+4
+    # transitions is a fragile sample.  `steps` / `warmup` in the line are the transitions actually run;
+    # `steps_requested` / `warmup_requested` what the command line asked for.  (--exact-steps: exactly K, last launch short.)
+    steps_requested, warmup_requested = args.steps, args.warmup
+    if args.exact_steps:
+        n_steps, n_warm = args.steps, args.warmup
+    else:
+        n_steps = max(-(-args.steps // T), args.min_launches) * T
+        n_warm = -(-args.warmup // T) * T
     for i in range(0, args.adapt_iters, T):
         eng.warmup_steps(min(T, args.adapt_iters - i))
     if args.phase == "sampling":
         eng.freeze()
-    run_steps(0, args.warmup, args.phase)
+    run_steps(0, n_warm, args.phase)
     fence()
     g_before = eng.total_grad_evals()
     # the dominant kernel's average launch duration: HIP events on the stream it is launched on, over the timed region
@@ -560,7 +677,7 @@ def main():
     else:
         eng.region_begin()
     t0 = time.perf_counter()
-    launches = run_steps(0, args.steps, args.phase)
+    launches = run_steps(0, n_steps, args.phase)
     if not per_launch:
         region_total_ms, region_launches = eng.region_ms()   # (waits for the last launch: part of the fence anyway)
     fence()
@@ -586,7 +703,7 @@ def main():
         def leg(**kw):
             fence()
             t1 = time.perf_counter()
-            run_steps(0, args.steps, args.phase, **kw)
+            run_steps(0, n_steps, args.phase, **kw)
             fence()
             dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -614,7 +731,7 @@ def main():
         algorithmic_bytes = 56.0 * D * evals_per_launch
         algorithmic_gbps = algorithmic_bytes / kernel_s / 1e9
         streaming = bool(eng.streaming)
-        traffic, traffic_source = measured_traffic(args, D, C, args.steps / max(launches, 1))
+        traffic, traffic_source = measured_traffic(args, D, C, n_steps / max(launches, 1))
         if streaming:
             design_b = 16.0 if eng.held_tiles > 0 else 40.0
             roofline = {"bound": "hbm", "achieved": algorithmic_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -664,9 +781,11 @@ def main():
             "value": total_grad_evals / elapsed,
             "unit": "grad-evals/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "steps": n_steps,
+            "warmup": n_warm,
+            "steps_requested": steps_requested,
+            "warmup_requested": warmup_requested,
+            "ms_per_step": elapsed / max(n_steps, 1) * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -683,23 +802,24 @@ def main():
                              "workgroups": eng.workgroups, "lds_pool_vectors": eng.lds_vectors,
                              "reserved_cus": reserved, "chain_groups": groups,
                              "held_tiles": eng.held_tiles if eng.streaming else 0},
-                "grad_evals_per_transition_per_chain": grad_evals / max(args.steps, 1) / C,
+                "grad_evals_per_transition_per_chain": grad_evals / max(n_steps, 1) / C,
                 "transitions_per_launch": T, "launches": launches,
                 "arithmetic": ("fused multiply-adds in the integrator (as an FMA-target build of the reference)"
                                if cfg.fused_multiply_add else
                                "every product rounded (the reference's x86-64 -O3 element-wise bits)"),
                 "csrc_sha": csrc_sha(),
+                "stream_version": wa.stream_version(),
             },
             "roofline": roofline,
         }
         if legs is not None:
-            full_ms = elapsed / max(args.steps, 1) * 1e3
-            comp_ms = legs["compute_s"] / max(args.steps, 1) * 1e3
+            full_ms = elapsed / max(n_steps, 1) * 1e3
+            comp_ms = legs["compute_s"] / max(n_steps, 1) * 1e3
             out["value_compute_only"] = legs["compute_grad_evals"] / legs["compute_s"]
             out["ms_per_step_compute_only"] = comp_ms
             out["exchange_ms_per_step"] = {
                 "exposed": full_ms - comp_ms,                                     # what the gathers add to a step
-                "alone": legs["exchange_s"] / max(args.steps, 1) * 1e3,           # the same collectives with nobody computing
+                "alone": legs["exchange_s"] / max(n_steps, 1) * 1e3,           # the same collectives with nobody computing
                 "bytes_per_step_per_rank_in": (world - 1) * gather.rows * D * 8 / max(args.gather_every, 1),
                 "method": args.gather_method if args.backend == "nccl" else "gloo (host staging)",
                 "library_algorithm": rccl_algorithm_seen() if args.backend == "nccl" else None,
@@ -707,12 +827,12 @@ def main():
                         "exchange only; DESIGN.md section 6 holds the prediction these are to confirm or refute"}
         if world == 1 and not args.no_parity_gate:
             out["parity_gate"] = parity_gate(args, D, cfg_kwargs)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cpu and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, D)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    eng.close()
+    del gather
+    torch.cuda.empty_cache()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

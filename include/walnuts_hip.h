@@ -234,6 +234,14 @@ WALNUTS_HIP_EXPORT void wn_default_config(wn_config* cfg);
  * (walnuts_amd/csrc/wn_model_api.h; INTEGRATION.md "Adding a device model").  -> the id registered under `name`
  * ("std_normal" 0, "diag_normal" 1, "funnel" 2, "rw1" 3, ...), or -1. */
 WALNUTS_HIP_EXPORT int wn_model_id(const char* name);
+/* Version of the counter-based random streams of this build (the map (seed, chain, transition, index) -> variate,
+ * csrc/wn_devmath.h): results at a fixed seed are reproducible within one version only.  A caller that stores draws
+ * or resumes a run records it beside the seed; walnuts_amd writes it into every result and bench line.
+ * (The reference's counterpart is implicit: mt19937_64 + libstdc++'s distributions, util.hpp:78-162.) */
+WALNUTS_HIP_EXPORT int wn_stream_version(void);
+/* The code-generation flags the library was compiled with (csrc/Makefile CODEGEN_FLAGS, a space-separated string):
+ * device models compiled at run time are built with exactly these, so that a plugin and the library cannot drift. */
+WALNUTS_HIP_EXPORT const char* wn_build_flags(void);
 /* Device models compiled at RUN time -- the device counterpart of handing the reference a host callable
  * (LOGP_CFUNC / a numba cfunc: python/src/walnutpie/walnutpy.cpp:131-132, pyfunc.py:216).  The model's five-line
  * translation unit is compiled against the installed headers (walnuts_amd/csrc) into a shared object of its own

@@ -1004,7 +1004,50 @@ static double chain_sum(const wno_engine* e, size_t M, F f) {
   return total;
 }
 
+// util.hpp:380-383 l2_rel_diff: norm((a - b) / b).  block_order: the device's monitor block (256 strided partials, then
+// a pairwise tree) instead of a left-to-right sum.
+static double l2_rel_diff(const double* a, const double* b, size_t n, bool block_order) {
+  auto rel_sq = [&](size_t d) {
+    const double r = (a[d] - b[d]) / b[d];
+    return r * r;
+  };
+  double ss = 0;
+  if (!block_order) {
+    for (size_t d = 0; d < n; ++d) ss += rel_sq(d);
+  } else {
+    double sh[256];
+    for (size_t t = 0; t < 256; ++t) {
+      double acc = 0.0;
+      for (size_t d = t; d < n; d += 256) acc += rel_sq(d);
+      sh[t] = acc;
+    }
+    for (size_t s = 128; s > 0; s >>= 1)
+      for (size_t t = 0; t < s; ++t) sh[t] += sh[t + s];
+    ss = sh[0];
+  }
+  return std::sqrt(ss);
+}
+
+// util.hpp:401-404 variance: sum((xs - mean(xs))^2) / (n - 1); `sum` is the order the caller's mode prescribes
+template <class Sum, class At>
+static double variance(size_t n, Sum sum, At at) {
+  const double mean = sum([&](size_t m) { return at(m); }) / static_cast<double>(n);
+  const double ss = sum([&](size_t m) { return (at(m) - mean) * (at(m) - mean); });
+  return ss / static_cast<double>(n - 1);
+}
+
 extern "C" {
+
+// the two controller helpers by themselves, in the reference's order (tests/util_test.cpp:316-381 hold their vectors)
+double wno_l2_rel_diff(size_t n, const double* a, const double* b) { return l2_rel_diff(a, b, n, false); }
+double wno_variance(size_t n, const double* xs) {
+  auto seq = [&](auto f) {
+    double s = 0.0;
+    for (size_t m = 0; m < n; ++m) s += f(m);
+    return s;
+  };
+  return variance(n, seq, [&](size_t m) { return xs[m]; });
+}
 
 void wno_default_config(wno_config* c) {
   c->max_trajectory_doublings = 5;
@@ -1200,6 +1243,31 @@ void wno_set_sampler_state(wno_engine* e, const double* inv_mass, const double* 
     ch.frozen = true;
   }
 }
+/* adaptation state handed in as it is (an AdaptiveWalnuts mid-warmup, adaptive_walnuts.hpp:205-251): Adam's six
+ * numbers per chain, the mass estimator's four planes and two weights, the min-micro-steps value in force, and the
+ * number of warmup transitions done (the estimator's discount depends on it, :74-80).  For gates that replay ONE warmup
+ * transition from another engine's state. */
+void wno_set_adapt_state(wno_engine* e, const double* adam, const double* dm, const double* ds, const double* sm,
+                         const double* ss, const double* w, const int64_t* min_micro, uint64_t iteration) {
+  e->ensure_adapters();
+  const size_t D = e->D;
+  for (size_t c = 0; c < e->C; ++c) {
+    Chain& ch = e->chains[c];
+    const double* a = adam + 6 * c;
+    ch.adam.theta = a[0]; ch.adam.m = a[1]; ch.adam.v = a[2]; ch.adam.t = a[3]; ch.adam.b1pow = a[4]; ch.adam.b2pow = a[5];
+    ch.est.draw_var.mean.assign(dm + c * D, dm + (c + 1) * D);
+    ch.est.draw_var.ssd.assign(ds + c * D, ds + (c + 1) * D);
+    ch.est.score_var.mean.assign(sm + c * D, sm + (c + 1) * D);
+    ch.est.score_var.ssd.assign(ss + c * D, ss + (c + 1) * D);
+    ch.est.draw_var.weight = w[2 * c];
+    ch.est.score_var.weight = w[2 * c + 1];
+    // MinMicroStepsAdaptHandler: total / count chosen so that value() is exactly the handed-in one
+    ch.mm.count = 1.0;
+    ch.mm.total = static_cast<double>(min_micro[c]) * ch.mm.target;
+    ch.iteration = static_cast<size_t>(iteration);
+    ch.frozen = false;
+  }
+}
 /* the counter-based streams are keyed by the transition index: make the next transition number `t` */
 void wno_set_transition_index(wno_engine* e, uint32_t t) {
   for (auto& ch : e->chains) ch.transitions = t;
@@ -1299,14 +1367,10 @@ int64_t wno_iteration(const wno_engine* e) { return e->iteration; }
 // sampler.hpp:132-145 with util.hpp:401-404 (variance) on the per-chain Welford statistics
 double wno_rhat(const wno_engine* e) {
   const size_t M = e->C;
-  double mean_of_means = chain_sum(e, M, [&](size_t m) { return e->chains[m].lp_mean; });
   double mean_of_vars = chain_sum(e, M, [&](size_t m) { return e->chains[m].lp_sample_variance(); });
-  mean_of_means /= static_cast<double>(M);
   mean_of_vars /= static_cast<double>(M);
-  const double ss = chain_sum(e, M, [&](size_t m) {
-    return (e->chains[m].lp_mean - mean_of_means) * (e->chains[m].lp_mean - mean_of_means);
-  });
-  const double variance_of_means = ss / static_cast<double>(M - 1);
+  const double variance_of_means = variance(M, [&](auto f) { return chain_sum(e, M, f); },
+                                            [&](size_t m) { return e->chains[m].lp_mean; });
   return std::sqrt(1 + variance_of_means / mean_of_vars);
 }
 
@@ -1335,25 +1399,7 @@ void wno_warmup_spread(wno_engine* e, double* max_rel_step, double* max_rel_mass
   const double gms = mo.exp(mean_log_step);
   double rm = 0, rs = 0;
   for (size_t m = 0; m < M; ++m) {
-    auto rel_sq = [&](size_t d) {
-      const double r = (mass[m][d] - mean_log_mass[d]) / mean_log_mass[d];
-      return r * r;
-    };
-    double ss = 0;
-    if (e->red.L <= 0) {
-      for (size_t d = 0; d < D; ++d) ss += rel_sq(d);
-    } else {
-      double sh[256];
-      for (size_t t = 0; t < 256; ++t) {
-        double acc = 0.0;
-        for (size_t d = t; d < D; d += 256) acc += rel_sq(d);
-        sh[t] = acc;
-      }
-      for (size_t s = 128; s > 0; s >>= 1)
-        for (size_t t = 0; t < s; ++t) sh[t] += sh[t + s];
-      ss = sh[0];
-    }
-    rm = std::fmax(rm, std::sqrt(ss));
+    rm = std::fmax(rm, l2_rel_diff(mass[m].data(), mean_log_mass.data(), D, e->red.L > 0));
     rs = std::fmax(rs, (mo.exp(log_step[m]) - gms) / gms);
   }
   *max_rel_step = rs;

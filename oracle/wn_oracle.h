@@ -102,6 +102,11 @@ void wno_sample_step(wno_engine* e, int num_threads); /* WalnutsSampler::operato
 
 /* frozen sampler parameters handed in as they are: inverse mass [C*D], step [C], min micro steps [C] */
 void wno_set_sampler_state(wno_engine* e, const double* inv_mass, const double* step, const int64_t* min_micro);
+/* adaptation state handed in as it is: Adam [C*6] (theta,m,v,t,b1pow,b2pow), the estimator's planes [C*D] and weights
+ * [C*2], the min-micro-steps value in force [C], warmup transitions done so far */
+void wno_set_adapt_state(wno_engine* e, const double* adam, const double* draw_mean, const double* draw_ssd,
+                         const double* score_mean, const double* score_ssd, const double* weights,
+                         const int64_t* min_micro, uint64_t iteration);
 /* counter-based streams are keyed by the transition index: make the next transition number `t` */
 void wno_set_transition_index(wno_engine* e, uint32_t t);
 /* near-tie audit: tolerance relative to the compared magnitudes (0 = off); totals over
@@ -131,6 +136,11 @@ int64_t wno_iteration(const wno_engine* e);
  * (sampler.hpp:132-145) and the warmup spread of step size / mass across chains (adapt.hpp:193-221) */
 double wno_rhat(const wno_engine* e);
 void wno_warmup_spread(wno_engine* e, double* max_rel_step, double* max_rel_mass);
+
+/* the controllers' two helpers by themselves, reference order: l2_rel_diff (util.hpp:380-383) and the bias-adjusted
+ * sample variance (util.hpp:401-404) -- the functions wno_warmup_spread / wno_rhat are built on */
+double wno_l2_rel_diff(size_t n, const double* a, const double* b);
+double wno_variance(size_t n, const double* xs);
 
 /* ---- per-macro-step trace of the LAST transition of one chain ------------ */
 /* record layout (doubles): [dir, level, n_micro, step, H_start, H_end, accepted,

@@ -121,6 +121,11 @@ def lib():
     L.wno_math_exp_weight.argtypes = [dbl]
     L.wno_set_sampler_state.argtypes = [vp, _dp, _dp, C.POINTER(C.c_int64)]
     L.wno_set_transition_index.argtypes = [vp, u32]
+    L.wno_set_adapt_state.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int64), u64]
+    L.wno_l2_rel_diff.restype = dbl
+    L.wno_l2_rel_diff.argtypes = [sz, _dp, _dp]
+    L.wno_variance.restype = dbl
+    L.wno_variance.argtypes = [sz, _dp]
     L.wno_set_tie_tolerance.argtypes = [vp, dbl]
     L.wno_get_near_ties.argtypes = [vp, C.POINTER(C.c_int64), i32]
     L.wno_get_weight_rebases.restype = C.c_int64
@@ -216,6 +221,15 @@ class Engine:
         self.L.wno_set_sampler_state(self.h, im.ctypes.data_as(_dp), st.ctypes.data_as(_dp),
                                      mm.ctypes.data_as(C.POINTER(C.c_int64)))
 
+    def set_adapt_state(self, adam, estimator, min_micro, iteration: int):
+        """Adam [C, 6], the estimator dict of Engine.estimator(), min micro steps [C], warmup transitions done."""
+        a = _f64(adam).reshape(self.C, 6)
+        planes = [_f64(estimator[k]).reshape(self.C, self.D) for k in ("draw_mean", "draw_ssd", "score_mean", "score_ssd")]
+        w = _f64(estimator["weights"]).reshape(self.C, 2)
+        mm = np.ascontiguousarray(np.asarray(min_micro, dtype=np.int64))
+        self.L.wno_set_adapt_state(self.h, _p(a), *(_p(x) for x in planes), _p(w),
+                                   mm.ctypes.data_as(C.POINTER(C.c_int64)), int(iteration))
+
     def set_transition_index(self, t: int):
         self.L.wno_set_transition_index(self.h, int(t))
 
@@ -306,6 +320,16 @@ REDUCE_EIGEN_SSE2 = -2   # reduce_lanes: Eigen 3.4's vectorised redux order, 2-l
 def reduce_sum(x, reduce_lanes: int = 0) -> float:
     v = _f64(x).reshape(-1)
     return lib().wno_reduce_sum(v.size, _p(v), reduce_lanes)
+
+
+def l2_rel_diff(a, b) -> float:
+    a, b = _f64(a), _f64(b)
+    return lib().wno_l2_rel_diff(a.size, _p(a), _p(b))
+
+
+def variance(xs) -> float:
+    xs = _f64(xs)
+    return lib().wno_variance(xs.size, _p(xs))
 
 
 def log_sum_exp(a: float, b: float, math_mode: int = MATH_LIBM) -> float:

@@ -8,7 +8,7 @@ CPU fallback: importing the binding without the built library raises.
 """
 from ._ffi import WalnutsHipError, load_library  # noqa: F401
 from .engine import (MODEL_DIAG_NORMAL, MODEL_FUNNEL, MODEL_RW1, MODEL_STD_NORMAL, DeviceEngine, model_id,  # noqa: F401
-                     default_config)
+                     default_config, stream_version)
 from .device import WalnutsOutputArray, WarmupInfo, walnuts_device  # noqa: F401
 from . import models, summary  # noqa: F401,E402
 from .summary import MarkovChains, Summarizer  # noqa: F401,E402

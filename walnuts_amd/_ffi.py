@@ -88,6 +88,8 @@ SYMBOLS = [
     ("walnutpie_mcse", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("wn_default_config", None, [C.POINTER(Config)]),
     ("wn_model_id", _i32, [C.c_char_p]),
+    ("wn_stream_version", _i32, []),
+    ("wn_build_flags", C.c_char_p, []),
     ("wn_plugin_register_model", _i32, [_vp, _vp]),
     ("wn_model_error", C.c_char_p, []),
     ("wn_model_clear_error", None, []),

@@ -556,6 +556,15 @@ const char* walnutpie_get_error_message(const WalnutpyError* err) {
 WalnutpyErrorType walnutpie_get_error_type(const WalnutpyError* err) { return err == nullptr ? generic : err->type; }
 void walnutpie_destroy_error(WalnutpyError* err) { delete err; }
 
+// which counter-based stream definition this build draws from (wn_devmath.h kStreamVersion: the map from
+// (seed, chain, transition, index) to variates; results at a fixed seed are comparable only within one version)
+int wn_stream_version(void) { return wnd::kStreamVersion; }
+// the code-generation flags this library was compiled with (Makefile CODEGEN_FLAGS): run-time models use the same
+#ifndef WN_CODEGEN_FLAGS
+#define WN_CODEGEN_FLAGS ""
+#endif
+const char* wn_build_flags(void) { return WN_CODEGEN_FLAGS; }
+
 int wn_model_id(const char* name) {
   if (name == nullptr) return -1;
   for (int i = 0; i < wn::kMaxModels; ++i) {

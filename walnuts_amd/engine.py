@@ -36,6 +36,11 @@ def model_id(name: str, lib_path: Optional[str] = None) -> int:
     return i
 
 
+def stream_version(lib_path: Optional[str] = None) -> int:
+    """Version of the library's counter-based random streams (wn_stream_version): same seed + same version = same run."""
+    return int(_ffi.load_library(lib_path).wn_stream_version())
+
+
 def _f64(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 

@@ -19,9 +19,17 @@ from typing import Optional, Sequence
 from . import _ffi
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-# the flags the library itself is built with (walnuts_amd/csrc/Makefile): same arithmetic (-ffp-contract=off), same code
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
-               "-mllvm", "-structurizecfg-skip-uniform-regions=1"]
+
+
+def hipcc_flags(lib_path: Optional[str] = None) -> Sequence[str]:
+    """The code-generation flags the library itself was built with (csrc/Makefile CODEGEN_FLAGS, kept in the library:
+    wn_build_flags): same arithmetic (-ffp-contract=off), same code -- read from the library, not repeated here."""
+    flags = _ffi.load_library(lib_path).wn_build_flags().decode().split()
+    if not flags:
+        raise _ffi.WalnutsHipError("this libwalnuts_hip.so does not state its build flags (built without csrc/Makefile?)")
+    return flags
+
+
 _loaded = {}   # path -> CDLL (kept alive: the registry holds pointers into the object)
 
 
@@ -68,7 +76,7 @@ def build_device_model(header: str, type_name: str, tag: str, model_id: int, num
     models).  ``waves_per_chain`` / ``elems_per_lane``: the same requests a ``wn_config`` can make (0 = the engine's
     choice); ``preferred_elems_per_lane``: the model's ``kPreferredElemsPerLane`` if it states one.  An engine created
     with other requests than the ones given here finds no kernel and says so.  ``compiler``: the command in front of
-    the flags (default ``["hipcc"] + HIPCC_FLAGS``; the CPU test tier passes g++ with the emulation's flags)."""
+    the flags (default ``["hipcc"] + hipcc_flags()``; the CPU test tier passes g++ with the emulation's flags)."""
     header = os.path.abspath(header)
     lib_file = os.path.abspath(lib_path or os.environ.get("WALNUTS_AMD_LIB") or _ffi.DEFAULT_LIB)
     nw, epl, streaming = geometry_for(num_params, waves_per_chain=waves_per_chain, elems_per_lane=elems_per_lane,
@@ -80,7 +88,7 @@ def build_device_model(header: str, type_name: str, tag: str, model_id: int, num
         f.write(translation_unit(header, type_name, tag, model_id))
     geo = f"mem{nw}" if streaming else f"{nw}x{epl}"
     out = os.path.join(out_dir, f"libwn_model_{tag}_{geo}.so")
-    cmd = list(compiler) if compiler is not None else ["hipcc"] + HIPCC_FLAGS
+    cmd = list(compiler) if compiler is not None else ["hipcc"] + list(hipcc_flags(lib_path))
     cmd += ["-DWN_MODEL_PLUGIN",
             *geometry_defines(nw, epl, streaming, waves_per_chain > 0 or elems_per_lane != 0 or preferred_elems_per_lane > 0),
             "-I", CSRC, "-I", os.path.dirname(header),

@@ -472,6 +472,94 @@ def test_full_size_config4_properties():
     assert np.array_equal(e2.positions(), e.positions()[100:164])
 
 
+def _full_size_run(model_id, D, chains, offset, s2, warm, samp, fused=1):
+    """InitConfigBuilder on the device keyed by GLOBAL chain ids -> `warm` adaptive + `samp` sampling transitions."""
+    e = wa.DeviceEngine(model_id, D, chains, params=s2)
+    e.init_positions(3, offset, 2.0)
+    e.init_masses_from_grad(1e-5)
+    e.set_step_sizes(1.0)
+    e.adapt_step(3, offset)
+    e.seed_chains(4, offset)
+    for i in range(0, warm, fused):
+        e.warmup_steps(min(fused, warm - i))
+    e.freeze()
+    for i in range(0, samp, fused):
+        e.sample_steps(min(fused, samp - i))
+    e.synchronize()
+    e.check()
+    return e
+
+
+def test_full_size_config2_properties(oracle):
+    """BASELINE config #2 at full size: 4 096 chains x 1 024-dim ill-conditioned diagonal Gaussian, sigma_d = d + 1
+    (examples/examples.cpp:20-31).  Size-independent properties: the reported log density is the model's at the reported
+    position; chain independence (a sub-batch with the same global chain ids reproduces its rows bit for bit, whatever
+    the batching and the chain groups); the warmup adapts the metric towards sigma^2 on every chain; and 64 of the 4 096
+    chains meet the device-order oracle bit for bit."""
+    D, C = 1024, 4096
+    s2 = np.array([(d + 1.0) ** 2 for d in range(D)])
+    e = _full_size_run(wa.MODEL_DIAG_NORMAL, D, C, 0, s2, warm=24, samp=8, fused=8)
+    x = e.positions()
+    assert np.allclose(e.logp(), np.sum(-0.5 * x * x / s2, axis=1), rtol=1e-11, atol=0)
+    assert np.all(np.isfinite(x)) and e.depths().min() >= 1 and e.depths().max() <= 6
+    assert np.all(e.step_sizes() > 0) and np.all(np.isfinite(e.inv_mass()))
+    sub = _full_size_run(wa.MODEL_DIAG_NORMAL, D, 64, 2000, s2, warm=24, samp=8, fused=8)
+    for a, b in ((sub.positions(), x[2000:2064]), (sub.logp(), e.logp()[2000:2064]),
+                 (sub.grad_evals(), e.grad_evals()[2000:2064]), (sub.inv_mass(), e.inv_mass()[2000:2064])):
+        assert np.array_equal(a, b)
+    # the same 64 chains on the oracle (device order): bit for bit
+    ocfg = oracle.default_config(rng_mode=oracle.RNG_PHILOX, math_mode=oracle.MATH_PORTABLE, reduce_lanes=sub.lanes,
+                                 fma=int(sub.cfg.fused_multiply_add))
+    o = oracle.Engine(oracle.MODEL_DIAG_NORMAL, D, 64, ocfg, params=s2)
+    o.init_positions(3, 2000, 2.0)
+    o.init_masses_from_grad(1e-5)
+    o.set_step_sizes(1.0)
+    o.adapt_step(3, 2000)
+    o.seed_chains(4, 2000)
+    for _ in range(24):
+        o.warmup_step(8)
+    o.freeze()
+    for _ in range(8):
+        o.sample_step(8)
+    assert np.array_equal(o.positions(), sub.positions()) and np.array_equal(o.logp(), sub.logp())
+    assert np.array_equal(o.grad_evals(), sub.grad_evals())
+
+
+def test_full_size_config3_properties(oracle):
+    """BASELINE config #3 at full size: Neal's funnel D = 128, 16 384 chains (adaptive step size / divergence stress).
+    Properties: reported log density = the funnel's at the reported position; chain independence; every chain's
+    failed-extension flag is 0 or 1; step sizes adapt downwards from 1; 128 of the chains meet the device-order oracle
+    bit for bit through the adaptive and the sampling transitions."""
+    D, C = 128, 16384
+    e = _full_size_run(wa.MODEL_FUNNEL, D, C, 0, None, warm=40, samp=8, fused=8)
+    x = e.positions()
+    lp = -0.5 * x[:, 0] ** 2 / 9.0 - 0.5 * np.exp(-x[:, 0]) * np.sum(x[:, 1:] ** 2, axis=1) - 0.5 * (D - 1) * x[:, 0]
+    assert np.allclose(e.logp(), lp, rtol=1e-10, atol=1e-9)
+    assert np.all(np.isfinite(x)) and e.depths().min() >= 1
+    st = e.step_sizes()
+    assert np.all(st > 0) and np.median(st) < 1.0
+    assert set(np.unique(e.failed_extensions()).tolist()) <= {0, 1}
+    sub = _full_size_run(wa.MODEL_FUNNEL, D, 128, 9000, None, warm=40, samp=8, fused=8)
+    for a, b in ((sub.positions(), x[9000:9128]), (sub.logp(), e.logp()[9000:9128]),
+                 (sub.grad_evals(), e.grad_evals()[9000:9128]), (sub.step_sizes(), st[9000:9128])):
+        assert np.array_equal(a, b)
+    ocfg = oracle.default_config(rng_mode=oracle.RNG_PHILOX, math_mode=oracle.MATH_PORTABLE, reduce_lanes=sub.lanes,
+                                 fma=int(sub.cfg.fused_multiply_add))
+    o = oracle.Engine(oracle.MODEL_FUNNEL, D, 128, ocfg)
+    o.init_positions(3, 9000, 2.0)
+    o.init_masses_from_grad(1e-5)
+    o.set_step_sizes(1.0)
+    o.adapt_step(3, 9000)
+    o.seed_chains(4, 9000)
+    for _ in range(40):
+        o.warmup_step(8)
+    o.freeze()
+    for _ in range(8):
+        o.sample_step(8)
+    assert np.array_equal(o.positions(), sub.positions()) and np.array_equal(o.logp(), sub.logp())
+    assert np.array_equal(o.grad_evals(), sub.grad_evals()) and np.array_equal(o.step_sizes(), sub.step_sizes())
+
+
 def test_sample_device_contract_on_gpu():
     # python/tests/test_pyfunc.py:38-125 for the device entry point
     kw = dict(num_params=100, num_chains=4, seed=1234, min_warmup_iter=30, max_warmup_iter=30, min_sampling_iter=20,

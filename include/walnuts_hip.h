@@ -170,8 +170,28 @@ WALNUTS_HIP_EXPORT int walnutpie_sample_device_multi(
 /* ... with the sampling draws kept on the devices (walnutpie_sample_device_resident's contract for `out`, `thin` and
  * `chains_out`): every shard keeps its draws on its own device while it samples; at the end the shards' blocks --
  * contiguous slabs of the chain-major [C][S][D] layout -- are gathered on devices[0] with one peer-to-peer copy per
- * shard (hipMemcpyPeerAsync: each over its own xGMI link, all at once) and handed back as ONE wn_chains there. */
+ * shard (hipMemcpyPeerAsync, each on a stream of its own so that the inbound copies run side by side, each over the
+ * xGMI link of its source; peer access is enabled per pair first, and a pair without a peer path is a `generic` error
+ * that names it) and handed back as ONE wn_chains there.  Unmeasured on more than one physical device. */
 WALNUTS_HIP_EXPORT int walnutpie_sample_device_multi_resident(
+    int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
+    unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
+    int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,
+    int max_step_halvings, int min_micro_steps, double max_hamiltonian_error, double step_size_converge_tol,
+    double mass_converge_tol, double rhat_converge_tol, double mass_init_count, double mass_additive_smoothing,
+    double max_macro_steps_target, double step_size_init, double step_accept_rate_target,
+    double step_learning_rate, double step_gradient_decay, double step_sq_gradient_decay,
+    double step_stabilization, double step_learn_rate_decay, bool save_warmup, double* out, size_t out_size,
+    int* final_lengths, double* stepsize_out, double* inv_metric_out, int refresh, PRINT_CALLBACK print,
+    const int* devices, int num_devices, int thin, wn_chains** chains_out, WalnutpyError** err);
+
+/* ... the ALL-GATHER of the draws (BASELINE.json's north star: "only an ... all-gather of draws over xGMI"), for a C/C++
+ * caller (the reference's callers: examples/walnutpie_api.cpp:78-79, walnutpy.cpp:82) without Python or RCCL: as
+ * _multi_resident, but EVERY listed device ends with the whole [C][S][D] block -- chains_out is an array of
+ * num_devices handles, chains_out[d] living on devices[d].  All-pairs direct copies: each device pulls every other
+ * shard's slab over the link of that pair (xGMI is point-to-point: N-1 inbound copies per device side by side, no
+ * ring), its own shard by a local copy.  Unmeasured on more than one physical device. */
+WALNUTS_HIP_EXPORT int walnutpie_sample_device_multi_allgather(
     int model, const double* model_params, int num_params, const double* inits, size_t num_chains,
     unsigned int seed, unsigned int id, double init_radius, const double* init_inv_metric, int min_warmup_iter,
     int max_warmup_iter, int min_sampling_iter, int max_sampling_iter, int max_trajectory_doublings,

@@ -380,8 +380,18 @@ struct Adam {
 // ---------------------------------------------------------------------------
 // discounted Welford (online_moments.hpp:125-247)
 // ---------------------------------------------------------------------------
+// Device arithmetic (WNO_MATH_PORTABLE) divides a plane's elements by the estimator's weight the way the kernels do
+// (walnuts_amd/csrc/wn_devmath.h, SharedDivisor): r = 1 / w once, then q0 = a r, q = fma(fma(-q0, w, a), r, q0) -- the
+// correctly rounded quotient for every finite numerator in the normal range (the all-ones significand aside), restated
+// here operation for operation so that the comparison is exact in the corner cases too.  Reference arithmetic: `/`.
+static inline double div_shared(double a, double w, double r) {
+  const double q0 = a * r;
+  return std::fma(std::fma(-q0, w, a), r, q0);
+}
+
 struct OnlineMoments {
   double weight = 0;
+  bool shared_div = false;
   Vec mean, ssd;
   void init(double w, const double* mean0, const double* var0, size_t n) {  // :151-159
     weight = w;
@@ -394,18 +404,27 @@ struct OnlineMoments {
   void observe(double discount, const double* y) {
     weight = discount * weight + 1;
     const size_t n = mean.size();
-    for (size_t i = 0; i < n; ++i) mean[i] += (y[i] - mean[i]) / weight;
+    if (shared_div) {
+      const double r = 1.0 / weight;
+      for (size_t i = 0; i < n; ++i) mean[i] += div_shared(y[i] - mean[i], weight, r);
+    } else {
+      for (size_t i = 0; i < n; ++i) mean[i] += (y[i] - mean[i]) / weight;
+    }
     for (size_t i = 0; i < n; ++i) ssd[i] = discount * ssd[i] + (y[i] - mean[i]) * (y[i] - mean[i]);
   }
-  double variance(size_t i) const { return weight > 0 ? ssd[i] / weight : 1.0; }  // :225-230
+  double variance(size_t i) const {  // :225-230
+    if (!(weight > 0)) return 1.0;
+    return shared_div ? div_shared(ssd[i], weight, 1.0 / weight) : ssd[i] / weight;
+  }
 };
 
 // adaptive_walnuts.hpp:25-105
 struct MassEstimator {
   double init_count = 4;
   OnlineMoments draw_var, score_var;
-  void init(double count, const double* mass, size_t n) {  // :54-62
+  void init(double count, const double* mass, size_t n, bool shared_div = false) {  // :54-62
     init_count = count;
+    draw_var.shared_div = score_var.shared_div = shared_div;
     Vec zero(n, 0.0), inv(n);
     for (size_t i = 0; i < n; ++i) inv[i] = 1.0 / mass[i];
     score_var.init(count, zero.data(), mass, n);
@@ -816,7 +835,7 @@ struct wno_engine {
     for (auto& ch : chains) {
       // adaptive_walnuts.hpp:205-223
       ch.adam.init(ch.step_init, cfg, mo);
-      ch.est.init(cfg.mass_init_count, ch.mass.data(), D);
+      ch.est.init(cfg.mass_init_count, ch.mass.data(), D, cfg.math_mode == WNO_MATH_PORTABLE);
       ch.mm.target = cfg.max_macro_steps_target;
       ch.mm.floor_ = static_cast<size_t>(cfg.min_micro_steps);
       ch.mm.total = 2.0;
@@ -1037,6 +1056,9 @@ static double variance(size_t n, Sum sum, At at) {
 }
 
 extern "C" {
+
+// the device's shared-divisor quotient by itself (tests/test_portable_math.py compares it with `/`)
+double wno_div_shared(double a, double w) { return div_shared(a, w, 1.0 / w); }
 
 // the two controller helpers by themselves, in the reference's order (tests/util_test.cpp:316-381 hold their vectors)
 double wno_l2_rel_diff(size_t n, const double* a, const double* b) { return l2_rel_diff(a, b, n, false); }

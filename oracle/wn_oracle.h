@@ -140,6 +140,8 @@ void wno_warmup_spread(wno_engine* e, double* max_rel_step, double* max_rel_mass
 /* the controllers' two helpers by themselves, reference order: l2_rel_diff (util.hpp:380-383) and the bias-adjusted
  * sample variance (util.hpp:401-404) -- the functions wno_warmup_spread / wno_rhat are built on */
 double wno_l2_rel_diff(size_t n, const double* a, const double* b);
+/* device arithmetic: a / w the way the kernels divide a plane by the estimator's weight (wn_devmath.h SharedDivisor) */
+double wno_div_shared(double a, double w);
 double wno_variance(size_t n, const double* xs);
 
 /* ---- per-macro-step trace of the LAST transition of one chain ------------ */

@@ -124,6 +124,8 @@ def lib():
     L.wno_set_adapt_state.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int64), u64]
     L.wno_l2_rel_diff.restype = dbl
     L.wno_l2_rel_diff.argtypes = [sz, _dp, _dp]
+    L.wno_div_shared.restype = dbl
+    L.wno_div_shared.argtypes = [dbl, dbl]
     L.wno_variance.restype = dbl
     L.wno_variance.argtypes = [sz, _dp]
     L.wno_set_tie_tolerance.argtypes = [vp, dbl]
@@ -325,6 +327,10 @@ def reduce_sum(x, reduce_lanes: int = 0) -> float:
 def l2_rel_diff(a, b) -> float:
     a, b = _f64(a), _f64(b)
     return lib().wno_l2_rel_diff(a.size, _p(a), _p(b))
+
+
+def div_shared(a: float, w: float) -> float:
+    return lib().wno_div_shared(a, w)
 
 
 def variance(xs) -> float:

@@ -23,6 +23,10 @@ void p_philox(const unsigned* c, const unsigned* k, unsigned* o) {
 void p_philox10(const unsigned* c, const unsigned* k, unsigned* o) {
   wnd::U4 r = wnd::philox<10>(c[0], c[1], c[2], c[3], k[0], k[1]); o[0]=r.x; o[1]=r.y; o[2]=r.z; o[3]=r.w; }
 int p_rounds() { return wnd::kPhiloxRounds; }
+void p_div_shared(const double* a, double w, double* out, long n) {
+  const wnd::SharedDivisor d(w);
+  for (long i = 0; i < n; ++i) out[i] = a[i] / d;
+}
 double p_uniform(unsigned long long seed, unsigned chain, unsigned t, unsigned stream, unsigned idx) {
   return wnd::stream_uniform(seed, chain, t, stream, idx); }
 void p_normal_pair(unsigned long long seed, unsigned chain, unsigned t, unsigned stream, unsigned pair, double* z) {
@@ -127,3 +131,34 @@ def test_stream_moments(oracle):
     assert abs(z.mean()) < 0.01 and abs(z.var() - 1) < 0.01 and abs((z**4).mean() - 3) < 0.08
     u = np.array([oracle.stream_uniform(9, 1, 2, 1, i) for i in range(20000)])
     assert 0 < u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+
+
+def test_shared_divisor_quotients_are_the_correctly_rounded_ones(shim, oracle):
+    """wnd::SharedDivisor (the mass estimator's divisions by its weight: online_moments.hpp:184-191,
+    adaptive_walnuts.hpp:89-94) against IEEE division: equal bit for bit on 6e6 numerators over the weights the
+    estimator's recurrence w <- (1 - 1/(count + i)) w + 1 actually takes (adaptive_walnuts.hpp:74-80) and over random
+    divisors, numerators from subnormal-free 1e-300 to 1e300 in both signs plus exact zeros -- and equal to the oracle's
+    restatement (the comparison the parity tests rest on)."""
+    dp = C.POINTER(C.c_double)
+    shim.p_div_shared.argtypes = [dp, C.c_double, dp, C.c_long]
+    rng = np.random.default_rng(17)
+    weights = []
+    for count in (4.0, 1.0, 10.0, 0.5):
+        w = count
+        for i in range(400):
+            weights.append(w)
+            w = (1.0 - 1.0 / (count + i)) * w + 1.0
+    weights += list(np.exp(rng.uniform(-50, 50, size=1200)))
+    n = 2500
+    bad = 0
+    for w in weights:
+        a = np.concatenate([rng.normal(size=n // 2) * np.exp(rng.uniform(-600, 600, size=n // 2)),
+                            rng.normal(size=n // 2 - 2), [0.0, -0.0]])
+        out = np.empty_like(a)
+        shim.p_div_shared(a.ctypes.data_as(dp), float(w), out.ctypes.data_as(dp), a.size)
+        want = a / w
+        normal = (np.abs(want) > 2.3e-308) | (want == 0)   # (a subnormal quotient may differ in its last bit)
+        bad += int(np.sum((out != want) & normal))
+        for k in (0, 1, n // 2, n - 1):
+            assert oracle.div_shared(float(a[k]), float(w)) == out[k]
+    assert bad == 0

@@ -153,7 +153,19 @@ def test_multi_device_resident_on_one_gpu_gathers_the_shards_draws():
     assert np.array_equal(chains.mean(), chains_one.mean())
     assert np.array_equal(chains.r_hat(), chains_one.r_hat())
     assert np.array_equal(chains.quantiles([0.1, 0.5]), chains_one.quantiles([0.1, 0.5]))
-    chains.close(), chains_one.close()
+    chains.close()
+    # walnutpie_sample_device_multi_allgather: every listed device ends with the whole block (all-pairs copies on their
+    # own streams) -- three handles, each equal to the one-engine call's
+    many, every = wa.walnuts_device(wa.MODEL_STD_NORMAL, devices=[0, 0, 0], all_gather=True, **kw)
+    assert len(every) == 3
+    for c in (0, 999, 1000, 1999, 2000, C - 1):
+        assert np.array_equal(np.asarray(many[c]), np.asarray(one[c])), c
+    for ch in every:
+        assert ch.num_chains() == C and ch.num_draws() == C * S
+        assert np.array_equal(ch.mean(), chains_one.mean())
+        assert np.array_equal(ch.quantiles([0.1, 0.5]), chains_one.quantiles([0.1, 0.5]))
+        ch.close()
+    chains_one.close()
 
 
 def test_multi_device_call_on_one_gpu_equals_the_single_engine_call():

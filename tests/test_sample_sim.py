@@ -184,6 +184,19 @@ def test_multi_device_resident_gathers_the_shards_draws(sim, oracle):
         assert np.array_equal(chains.r_hat(), chains_one.r_hat())
         assert np.array_equal(chains.effective_sample_size(), chains_one.effective_sample_size())
         chains.close()
+    # the all-gather (walnutpie_sample_device_multi_allgather): one handle per listed device, every one the whole block
+    many, every = _run(sim, devices=[0, 0, 0], all_gather=True, **kw)
+    assert len(every) == 3
+    for a, b in zip(one, many):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    for chains in every:
+        assert chains.num_chains() == 5 and chains.num_draws() == 5 * 4
+        assert np.array_equal(chains.mean(), chains_one.mean())
+        assert np.array_equal(chains.sample_variance(), chains_one.sample_variance())
+        assert np.array_equal(chains.r_hat(), chains_one.r_hat())
+        chains.close()
+    with pytest.raises(ValueError, match="all_gather"):
+        _run(sim, num_chains=5, all_gather=True)
     streamed = _run(sim, num_chains=5, min_sampling_iter=4, max_sampling_iter=9, rhat_converge_tol=1e6)
     assert np.array_equal(chains_one.mean(), sp.wnso.mean([np.asarray(s) for s in streamed]))
     with pytest.raises(ValueError, match="max_sampling_iter"):

@@ -82,6 +82,10 @@ SYMBOLS = [
      [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
       _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
       _dp, _dp, _i32, PRINT_CALLBACK, C.POINTER(C.c_int), _i32, _i32, C.POINTER(_vp), _errpp]),
+    ("walnutpie_sample_device_multi_allgather", _i32,
+     [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
+      _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
+      _dp, _dp, _i32, PRINT_CALLBACK, C.POINTER(C.c_int), _i32, _i32, C.POINTER(_vp), _errpp]),
     ("wn_internal_reference_normals", None, [C.c_uint, C.c_uint, _sz, _sz, _i32, _dbl, _dp]),
     ("walnutpie_ess", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("walnutpie_r_hat", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),

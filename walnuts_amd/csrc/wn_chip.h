@@ -909,12 +909,13 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     this->finish_tuning(warm);
     WN_MARK(kPhTuned);
     // rho = cholesky_mass * z (walnuts.hpp:528-529), padding slots zero
+    const wnd::SharedDivisor wd0(warm ? w_draw0 : 1.0), ws0(warm ? w_score0 : 1.0);  // (wnd::SharedDivisor: same quotients)
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       double chol;
       if (warm) {
         // adaptive_walnuts.hpp:235-236 with MassEstimator::inv_mass_estimate :89-94
-        im[j] = __builtin_sqrt((ds[j] / w_draw0) / (ss[j] / w_score0));
+        im[j] = __builtin_sqrt((ds[j] / wd0) / (ss[j] / ws0));
         chol = __builtin_sqrt(1.0 / im[j]);
       } else {
         // Streaming the plane costs 8 KB of the 48 KB a 1024-dimensional chain moves per transition; re-evaluating
@@ -974,8 +975,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
         n_grad = keep_grad;
       }
       const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(this->warmup_iter_now()));
-      const double wd = discount * w_draw0 + 1;
-      const double ws = discount * w_score0 + 1;
+      const wnd::SharedDivisor wd(discount * w_draw0 + 1);
+      const wnd::SharedDivisor ws(discount * w_score0 + 1);
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {  // online_moments.hpp:184-191 (lazy delta => (y - mean_new)^2)
         mean[j] += (th[kI][j] - mean[j]) / wd;

@@ -53,6 +53,24 @@ WND_HD double as_f64(uint64_t u) {
 // a * b + c with one rounding (IEEE fusedMultiplyAdd on the device and on the host alike)
 WND_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// a / b for MANY numerators and ONE divisor (the mass estimator's weights: online_moments.hpp:184-191 divides every
+// element of a plane by the same weight, adaptive_walnuts.hpp:89-94 every sum of squared deviations): with r = RN(1/b)
+// from ONE true division, q0 = RN(a r), the exact remainder a - b q0 in one fused multiply-add and q = RN(q0 + rem r)
+// is the correctly rounded quotient (Markstein, "Computation of elementary functions on the IBM RISC System/6000",
+// 1990; Cornea, Harrison, Tang 2002, thm. 1) -- three instructions where v_div_scale / v_rcp / v_div_fmas / v_div_fixup
+// take eleven.  It equals IEEE division for every finite numerator with a quotient in the normal range, unless b's
+// significand is all ones (RN(1/b) then sits on a rounding boundary; a weight `discount * w + 1` never has been);
+// a non-finite numerator gives NaN where division gives +-inf.  The oracle's device-order mode restates exactly these
+// three operations, so parity with it is bit for bit in every case; tests/test_portable_math.py compares with `/`.
+struct SharedDivisor {
+  double b, r;
+  WND_HD explicit SharedDivisor(double d) : b(d), r(1.0 / d) {}
+};
+WND_HD double operator/(double a, const SharedDivisor& d) {
+  const double q0 = a * d.r;
+  return __builtin_fma(__builtin_fma(-q0, d.b, a), d.r, q0);
+}
+
 WND_HD double two_to(int k) { return as_f64(static_cast<uint64_t>(k + 1023) << 52); }
 
 // ---------------------------------------------------------------------------

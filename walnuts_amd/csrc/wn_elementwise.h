@@ -43,7 +43,7 @@ static __global__ void freeze_kernel(int C, int Dp, const double* draw_ssd, cons
   for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
     const long long c = i / Dp;
-    const double wd = est_weight[2 * c], ws = est_weight[2 * c + 1];
+    const wnd::SharedDivisor wd(est_weight[2 * c]), ws(est_weight[2 * c + 1]);  // (as the warmup transitions divide)
     const double im = __builtin_sqrt((draw_ssd[i] / wd) / (score_ssd[i] / ws));
     inv_mass[i] = im;
     chol_mass[i] = 1.0 / __builtin_sqrt(im);  // walnuts.hpp:647
@@ -64,7 +64,7 @@ static __global__ void inv_mass_estimate_kernel(int C, int Dp, const double* dra
   for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
     const long long c = i / Dp;
-    inv_mass[i] = __builtin_sqrt((draw_ssd[i] / est_weight[2 * c]) / (score_ssd[i] / est_weight[2 * c + 1]));
+    inv_mass[i] = __builtin_sqrt((draw_ssd[i] / wnd::SharedDivisor(est_weight[2 * c])) / (score_ssd[i] / wnd::SharedDivisor(est_weight[2 * c + 1])));
   }
 }
 
@@ -123,7 +123,7 @@ static __global__ void log_mass_colsum_kernel(int C, int D, int Dp, const double
   double s = 0.0;
   for (int c = 0; c < C; ++c) {
     const long long i = static_cast<long long>(c) * Dp + d;
-    const double im = __builtin_sqrt((draw_ssd[i] / est_weight[2 * c]) / (score_ssd[i] / est_weight[2 * c + 1]));
+    const double im = __builtin_sqrt((draw_ssd[i] / wnd::SharedDivisor(est_weight[2 * c])) / (score_ssd[i] / wnd::SharedDivisor(est_weight[2 * c + 1])));
     s += -wnd::dlog(im);
   }
   colsum[d] = s;
@@ -155,7 +155,7 @@ static __global__ void warmup_spread_kernel(int C, int D, int Dp, const double* 
   double acc = 0.0;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
     const long long i = static_cast<long long>(c) * Dp + d;
-    const double im = __builtin_sqrt((draw_ssd[i] / est_weight[2 * c]) / (score_ssd[i] / est_weight[2 * c + 1]));
+    const double im = __builtin_sqrt((draw_ssd[i] / wnd::SharedDivisor(est_weight[2 * c])) / (score_ssd[i] / wnd::SharedDivisor(est_weight[2 * c + 1])));
     const double mass = wnd::dexp(-wnd::dlog(im));                       // snap.mass, adapt.hpp:141
     const double gm = wnd::dexp(colsum[d] / n_chains);                   // geom_mean_mass, adapt.hpp:203-205
     const double r = (mass - gm) / gm;

@@ -779,6 +779,7 @@ struct ShardCtx {
 struct ResidentRequest {  // walnutpie_sample_device_resident
   int thin;
   wn_chains** chains_out;
+  bool all_gather = false;  // multi-device: chains_out is an array of num_devices handles, every device gets the whole block
 };
 
 static int sample_device_impl(
@@ -1248,7 +1249,7 @@ static int sample_multi_impl(const ResidentRequest* resident, WN_SAMPLE_PARAMS_N
       if (resident->chains_out == nullptr) throw std::invalid_argument("chains_out must not be null");
       if (resident->thin < 0) throw std::invalid_argument("thin must be >= 0");
       if (max_sampling_iter < 1) throw std::invalid_argument("resident draws need max_sampling_iter >= 1");
-      *resident->chains_out = nullptr;
+      for (int d = 0; d < (resident->all_gather ? std::max(num_devices, 1) : 1); ++d) resident->chains_out[d] = nullptr;
     }
     if (num_chains < static_cast<size_t>(num_devices)) throw std::invalid_argument("fewer chains than devices");
     if (num_params < 1) throw std::invalid_argument("num_params must be in {1, 2, ... }");
@@ -1323,36 +1324,69 @@ static int sample_multi_impl(const ResidentRequest* resident, WN_SAMPLE_PARAMS_N
       for (int s = 0; s < num_devices; ++s)
         if (rcs[s] != 0) throw std::runtime_error("a shard ended without reporting its error");
     if (rc == 0 && resident != nullptr) {
-      // gather: shard s's [count_s][S][D] block is rows [begin_s, begin_s + count_s) of the whole [C][S][D] block
+      // gather: shard s's [count_s][S][D] block is rows [begin_s, begin_s + count_s) of the whole [C][S][D] block.
+      // One destination: devices[0] (gather), or every listed device (all_gather: the north star's exchange -- every
+      // device ends with every shard's draws).  Every (destination, source) pair is its own hipMemcpyPeerAsync on its
+      // own stream of the destination, so the inbound copies of a device run side by side, each over the xGMI link of
+      // its source -- not one after the other on one in-order stream.  Peer access is switched on per pair first: without
+      // it the runtime stages a peer copy through host memory.  (Unmeasured on more than one physical device: this pool
+      // has one GPU per box; the one-device tests list a device several times, where a "peer" copy is a local copy.)
       const size_t S = static_cast<size_t>(max_sampling_iter);
-      const int dev0 = devices[0];
-      struct RestoreDevice {  // the gather selects devices[0]: the calling thread gets its current device back
+      struct RestoreDevice {  // the gather selects the destinations: the calling thread gets its current device back
         int before = -1;
         RestoreDevice() { if (hipGetDevice(&before) != hipSuccess) before = -1; }
         ~RestoreDevice() { if (before >= 0) (void)hipSetDevice(before); }
       } restore_device;
-      if (hipSetDevice(dev0) != hipSuccess) throw std::runtime_error("cannot select the device");
-      DevBlock whole;
-      if (!whole.alloc(num_chains * S * D)) throw std::runtime_error("cannot allocate the gathered draw block");
-      Stream gather;
-      gather.create();
-      size_t first = 0;
-      for (int s = 0; s < num_devices; ++s) {
-        const size_t count = wn_chains_num_chains(shard_chains[static_cast<size_t>(s)]);
-        if (hipMemcpyPeerAsync(whole.p + first * S * D, dev0, wn_chains_device_draws(shard_chains[static_cast<size_t>(s)]),
-                               devices[s], count * S * D * sizeof(double), gather.s) != hipSuccess)
-          throw std::runtime_error("gathering the shards' draws failed");
-        first += count;
+      const int destinations = resident->all_gather ? num_devices : 1;
+      std::vector<size_t> first(static_cast<size_t>(num_devices) + 1, 0);
+      for (int s = 0; s < num_devices; ++s)
+        first[static_cast<size_t>(s) + 1] = first[static_cast<size_t>(s)] + wn_chains_num_chains(shard_chains[static_cast<size_t>(s)]);
+      std::vector<DevBlock> whole(static_cast<size_t>(destinations));
+      std::vector<std::unique_ptr<Stream>> copies;
+      for (int d = 0; d < destinations; ++d) {
+        const int dst = devices[d];
+        if (hipSetDevice(dst) != hipSuccess) throw std::runtime_error("cannot select the device");
+        if (!whole[static_cast<size_t>(d)].alloc(num_chains * S * D)) throw std::runtime_error("cannot allocate the gathered draw block");
+        for (int s = 0; s < num_devices; ++s) {
+          const int src = devices[s];
+          if (src != dst) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, dst, src) != hipSuccess || can == 0) {
+              std::stringstream ss;
+              ss << "device " << dst << " has no peer-to-peer path to device " << src
+                 << ": the shards' draws cannot be gathered on it (list devices of one xGMI hive)";
+              throw std::runtime_error(ss.str());
+            }
+            const hipError_t en = hipDeviceEnablePeerAccess(src, 0);
+            if (en != hipSuccess && en != hipErrorPeerAccessAlreadyEnabled) throw std::runtime_error("cannot enable peer access");
+            (void)hipGetLastError();  // (an "already enabled" is not an error to carry along)
+          }
+          copies.push_back(std::make_unique<Stream>());
+          copies.back()->create();
+          const size_t count = first[static_cast<size_t>(s) + 1] - first[static_cast<size_t>(s)];
+          if (hipMemcpyPeerAsync(whole[static_cast<size_t>(d)].p + first[static_cast<size_t>(s)] * S * D, dst,
+                                 wn_chains_device_draws(shard_chains[static_cast<size_t>(s)]), src,
+                                 count * S * D * sizeof(double), copies.back()->s) != hipSuccess)
+            throw std::runtime_error("gathering the shards' draws failed");
+        }
       }
-      if (hipStreamSynchronize(gather.s) != hipSuccess) throw std::runtime_error("gathering the shards' draws failed");
+      for (auto& c : copies)
+        if (hipStreamSynchronize(c->s) != hipSuccess) throw std::runtime_error("gathering the shards' draws failed");
       std::vector<int64_t> lengths(num_chains);
       for (size_t c = 0; c < num_chains; ++c) lengths[c] = final_lengths[num_chains + c];
-      double* block = whole.release();
-      WalnutpyError* adopt_err = nullptr;
-      if (wn_chains_adopt(resident->chains_out, block, num_chains, S, D, static_cast<int64_t>(S * D), lengths.data(), dev0,
-                          &adopt_err) != 0) {
-        (void)hipFree(block);
-        rethrow(adopt_err);
+      for (int d = 0; d < destinations; ++d) resident->chains_out[d] = nullptr;
+      for (int d = 0; d < destinations; ++d) {
+        double* block = whole[static_cast<size_t>(d)].release();
+        WalnutpyError* adopt_err = nullptr;
+        if (wn_chains_adopt(&resident->chains_out[d], block, num_chains, S, D, static_cast<int64_t>(S * D), lengths.data(),
+                            devices[d], &adopt_err) != 0) {
+          (void)hipFree(block);
+          for (int k = 0; k < d; ++k) {  // (nothing half-built is handed back)
+            wn_chains_destroy(resident->chains_out[k]);
+            resident->chains_out[k] = nullptr;
+          }
+          rethrow(adopt_err);
+        }
       }
     }
     return rc;
@@ -1378,7 +1412,12 @@ extern "C" int walnutpie_sample_device_multi(WN_SAMPLE_PARAMS_NOERR, const int* 
 }
 extern "C" int walnutpie_sample_device_multi_resident(WN_SAMPLE_PARAMS_NOERR, const int* devices, int num_devices, int thin,
                                                       wn_chains** chains_out, WalnutpyError** err) {
-  const ResidentRequest req{thin, chains_out};
+  const ResidentRequest req{thin, chains_out, false};
+  return sample_multi_impl(&req, WN_SAMPLE_ARGS_NOERR, devices, num_devices, err);
+}
+extern "C" int walnutpie_sample_device_multi_allgather(WN_SAMPLE_PARAMS_NOERR, const int* devices, int num_devices, int thin,
+                                                       wn_chains** chains_out, WalnutpyError** err) {
+  const ResidentRequest req{thin, chains_out, true};
   return sample_multi_impl(&req, WN_SAMPLE_ARGS_NOERR, devices, num_devices, err);
 }
 

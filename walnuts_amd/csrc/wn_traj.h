@@ -1922,7 +1922,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
                                                       double (&sums)[ST::kSums]) {
     constexpr int kChunk = 4, kChunks = (HOLD + kChunk - 1) / kChunk;
     constexpr int kAhead = WARM ? 2 : 4;  // (three planes' loads per tile in warmup, two otherwise)
-    const double wd = w_draw0, ws = w_score0;
+    const wnd::SharedDivisor wd(w_draw0), ws(w_score0);  // (wn_devmath.h: the same quotients as `/`)
     const double* plane_a = WARM ? P.est_draw_ssd + row : P.inv_mass + row;
     struct Chunk {
       v2f64 pa[kChunk], pb[kChunk], mp[kChunk];
@@ -2063,7 +2063,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   }
 
   __device__ __forceinline__ double begin_transition(long long row, bool warm) {
-    const double wd = w_draw0, ws = w_score0;
+    const wnd::SharedDivisor wd(w_draw0), ws(w_score0);  // (wn_devmath.h: the same quotients as `/`)
     im = warm ? im_buf : P.inv_mass + row;
     n_pend = 0;
     pend_mask = 0;
@@ -2166,7 +2166,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
       if (warm) aux_of(sel, aux_sel);  // the estimator wants the gradient at the selected position
     }
     const double discount = 1.0 - 1.0 / (P.mass_init_count + static_cast<double>(this->warmup_iter_now()));
-    const double wd = discount * w_draw0 + 1, ws = discount * w_score0 + 1;
+    const wnd::SharedDivisor wd(discount * w_draw0 + 1), ws(discount * w_score0 + 1);
     double* const out = P.draws_out != nullptr ? this->draw_row() : nullptr;
     // a draw row on a 16-byte boundary takes whole pairs (streamed: written once, read by nobody here); the pair that
     // straddles the end of an odd-length row, or a row at an odd offset, goes element by element

@@ -130,6 +130,7 @@ def walnuts_device(
     thin: int = 0,
     devices=None,
     lazy_results: bool = False,
+    all_gather: bool = False,
     lib_path: Optional[str] = None,
     print_callback=None,
 ):
@@ -147,7 +148,9 @@ def walnuts_device(
     one-device call (random streams keyed by global chain id, controllers reduced over all shards).  An ordinal may
     repeat: ``devices=[0, 0]`` runs two half-size engines on one device, each filling the other's launch tail.  With
     ``keep_on_device=True`` (walnutpie_sample_device_multi_resident) every shard keeps its draws on its own device and
-    the blocks are gathered on ``devices[0]`` by peer-to-peer copies at the end: one ``MarkovChains`` handle there."""
+    the blocks are gathered on ``devices[0]`` by peer-to-peer copies at the end: one ``MarkovChains`` handle there;
+    with ``all_gather=True`` as well (walnutpie_sample_device_multi_allgather) EVERY listed device ends with the whole
+    block -- the call returns ``(results, [chains on devices[0], chains on devices[1], ...])``."""
     lib = _ffi.load_library(lib_path)
     if devices is not None and reference_streams:
         raise ValueError("devices is not available with reference_streams")
@@ -155,6 +158,8 @@ def walnuts_device(
         raise ValueError("keep_on_device is not available with reference_streams")
     if thin < 0:
         raise ValueError("thin must be non-negative")
+    if all_gather and not (keep_on_device and devices is not None):
+        raise ValueError("all_gather needs devices=[...] and keep_on_device=True")
     if inits is not None:
         inits = np.asarray(inits, dtype=np.float64)
         if inits.ndim == 1:
@@ -209,6 +214,10 @@ def walnuts_device(
         if keep_on_device:   # every shard's draws stay on its device, gathered on devices[0] at the end
             entry = lib.walnutpie_sample_device_multi_resident
             tail = (refresh, cb, dev, len(devices), thin, C.byref(chains_handle), C.byref(err))
+            if all_gather:   # ... and every device gets every shard's draws
+                entry = lib.walnutpie_sample_device_multi_allgather
+                handles = (C.c_void_p * len(devices))()
+                tail = (refresh, cb, dev, len(devices), thin, handles, C.byref(err))
     import os
     import sys
     import time
@@ -247,5 +256,7 @@ def walnuts_device(
     if keep_on_device:
         from .summary import MarkovChains
 
+        if all_gather and devices is not None:
+            return results, [MarkovChains(C.c_void_p(h), lib) for h in handles]
         return results, MarkovChains(chains_handle, lib)
     return results

@@ -268,7 +268,8 @@ def parity_gate(args, D, cfg_kwargs):
 
 
 def reference_order_gate(model, D, cfg_kwargs, *, chains=64, transitions=8, adapt_iters=100, seed=1234, phase="sampling",
-                         lib_path=None, model_id=None, params=None, oracle_model_id=None):
+                         lib_path=None, model_id=None, params=None, oracle_model_id=None, init_scale=2.0,
+                         step_size=None):
     """SURVEY.md section 8d "parity gate in the same run": a subset of chains replayed on the CPU restatement in the
     REFERENCE's arithmetic (libm exp/log, every product rounded) with the identical random stream, one transition at a
     time from the device's own state -- under BOTH summation orders the reference side can have: "eigen_sse2", the
@@ -292,15 +293,18 @@ def reference_order_gate(model, D, cfg_kwargs, *, chains=64, transitions=8, adap
     dev = wa.DeviceEngine(model_id, D, Cg, dcfg, params=params, lib_path=lib_path)
     orders = {"eigen_sse2": wno.REDUCE_EIGEN_SSE2, "sequential": 0}
     orcs = {}
+    # (SamplingConfig / WarmupConfig fields among cfg_kwargs go to both sides; launch geometry etc. to the device only)
+    shared = {k: v for k, v in cfg_kwargs.items() if hasattr(wno.Config(), k) and k not in ("math_mode", "reduce_lanes", "rng_mode", "fma")}
     for name, lanes in orders.items():
-        ocfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=lanes)
+        ocfg = wno.default_config(rng_mode=wno.RNG_PHILOX, math_mode=wno.MATH_LIBM, reduce_lanes=lanes, **shared)
         orcs[name] = wno.Engine(oracle_model(model) if oracle_model_id is None else oracle_model_id, D, Cg, ocfg, params=params)
         orcs[name].set_tie_tolerance(1e-12)
         orcs[name].seed_chains(seed + 1, 0)
-    dev.init_positions(seed, 0, 2.0)
+    dev.init_positions(seed, 0, init_scale)
     dev.init_masses_from_grad(1e-5)
-    dev.set_step_sizes(1.0)
-    dev.adapt_step(seed, 0)
+    dev.set_step_sizes(1.0 if step_size is None else step_size)
+    if step_size is None:
+        dev.adapt_step(seed, 0)   # (step_size: that step as it is, no search)
     dev.seed_chains(seed + 1, 0)
     adapt = min(adapt_iters, 40)
     warm = phase == "warmup"

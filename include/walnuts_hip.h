@@ -276,6 +276,17 @@ WALNUTS_HIP_EXPORT void wn_model_clear_error(void);
 WALNUTS_HIP_EXPORT int wn_geometry_for(int num_params, int waves_per_chain, int elems_per_lane,
                                        int preferred_elems_per_lane, int* waves_out, int* elems_per_lane_out,
                                        int* streaming_out, WalnutpyError** err);
+/* wn_geometry_for answers for a model WITHOUT held streaming kernels.  The engine's choice also depends on the model
+ * (one-pass gradients stream from 4 097 parameters on the kernels that hold the moving end in registers, the funnel's
+ * kind from 8 193): wn_geometry_for_model is the ONE geometry wn_engine_create picks for a REGISTERED model;
+ * wn_geometry_candidates lists every geometry it may pick over all model traits, as triples (waves per chain, elements
+ * per lane, streaming) -- what a model compiled at run time, not registered yet, instantiates (at most 3). */
+WALNUTS_HIP_EXPORT int wn_geometry_for_model(int model, int num_params, int waves_per_chain, int elems_per_lane,
+                                             int* waves_out, int* elems_per_lane_out, int* streaming_out,
+                                             WalnutpyError** err);
+WALNUTS_HIP_EXPORT int wn_geometry_candidates(int num_params, int waves_per_chain, int elems_per_lane,
+                                              int preferred_elems_per_lane, int* out_triples, int max_triples,
+                                              int* count, WalnutpyError** err);
 
 /* model_params: host pointer (copied). */
 WALNUTS_HIP_EXPORT int wn_engine_create(wn_engine** out, int model, int num_params, const double* model_params,

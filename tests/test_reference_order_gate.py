@@ -75,6 +75,37 @@ GPU_CASES = [
 ]
 
 
+def _deep_low_density_gate(lib_path, chains, D, geometry):
+    """Plain NUTS (no energy-error bound) from far-out starting points, trees up to 2^8 leaves: the device's span
+    weights are LINEAR-domain values relative to a moving reference energy, clamped at e^-700 of it (wn_traj.h "span
+    weights", wn_devmath.h dexp_weight) where the reference keeps log-domain weights of any size (walnuts.hpp:368-387,
+    util.hpp:174-183).  The gate replays every transition on the reference-order oracle -- log_sum_exp, no clamp --: the
+    Barker / Metropolis decisions must agree (identical trees, no acceptance within 1e-12 of its threshold)."""
+    import bench
+
+    kw = dict(max_hamiltonian_error=1e9, max_trajectory_doublings=8)
+    if geometry is not None:
+        kw.update(waves_per_chain=geometry[0], elems_per_lane=geometry[1])
+    g = bench.reference_order_gate("std_normal", D, kw, chains=chains, transitions=4, adapt_iters=0, init_scale=30.0,
+                                   step_size=0.04, lib_path=lib_path)
+    assert_gate_clean(g, "deep trees far out")
+    acc = g["orders"]["sequential"]["near_ties_1e-12"]["acceptance"]
+    assert acc["decisions"] >= 4 * 40 * chains and acc["near"] == 0, acc   # (trees of ~2^6 leaves were built)
+
+
+@pytest.mark.timeout(900)
+def test_span_weight_clamp_against_log_domain_weights_on_the_emulation(oracle):
+    import build as simbuild
+
+    _deep_low_density_gate(simbuild.build(), 3, 40, (1, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_span_weight_clamp_against_log_domain_weights_on_gpu(gpu):
+    _deep_low_density_gate(None, 256, 1024, None)
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("fma", [1, 0])

@@ -98,6 +98,8 @@ SYMBOLS = [
     ("wn_model_error", C.c_char_p, []),
     ("wn_model_clear_error", None, []),
     ("wn_geometry_for", _i32, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _errpp]),
+    ("wn_geometry_for_model", _i32, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _errpp]),
+    ("wn_geometry_candidates", _i32, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int), _i32, C.POINTER(C.c_int), _errpp]),
     ("wn_engine_create", _i32, [C.POINTER(_vp), _i32, _i32, _dp, _sz, C.POINTER(Config), _errpp]),
     ("wn_engine_destroy", None, [_vp]),
     ("wn_engine_set_positions", _i32, [_vp, _dp, _errpp]),

@@ -67,6 +67,9 @@ struct SharedDivisor {
   WND_HD explicit SharedDivisor(double d) : b(d), r(1.0 / d) {}
 };
 WND_HD double operator/(double a, const SharedDivisor& d) {
+#if defined(WN_PLAIN_ESTIMATOR_DIVISION)  // (A/B probe builds only: tests/gpu_probes/build_variant.sh)
+  return a / d.b;
+#endif
   const double q0 = a * d.r;
   return __builtin_fma(__builtin_fma(-q0, d.b, a), d.r, q0);
 }

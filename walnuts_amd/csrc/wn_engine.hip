@@ -304,6 +304,7 @@ struct wn_engine {
         // and then failed leaves the device in an error state anyway; the memset then fails too and is ignored)
         (void)hipMemsetAsync(counter.p + g, 0, sizeof(uint32_t), s);
         work_base[g] = 0;
+        if (timed != nullptr) --events_used;  // (the pair taken for this launch has no end event: hand it back)
         throw;
       }
       work_base[g] += count;  // (only once the launch is known to be queued)
@@ -404,38 +405,52 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   if (e.pool_total > wn::kMaxPool)
     throw std::invalid_argument("max_trajectory_doublings needs more span-pool vectors than the device free mask holds");
   const int wps = wn::waves_per_simd(model, e.geo);
-  int wg_per_cu = cfg.workgroups_per_cu > 0 ? cfg.workgroups_per_cu : wn::default_workgroups_per_cu(e.geo, wps);
-  // a streaming kernel that can hold the moving end in registers wants the CU -- its LDS for the inverse mass, a
-  // wavefront's full register budget -- for ONE chain
   const int hold_tiles = e.geo.mem ? ops.hold_tiles(e.geo.nw) : 0;
   const bool hold_fits = hold_tiles > 0 && num_params <= 2 * 64 * e.geo.nw * hold_tiles;
-  if (hold_fits && cfg.workgroups_per_cu <= 0) wg_per_cu = 1;
-  wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
-  if (!e.geo.mem) wg_per_cu = std::min(wg_per_cu, std::max(1, 4 * wps / e.geo.nw));
-  const size_t fixed = wn::transition_smem_bytes(e.geo.nw, 0, e.Dp);
-  const size_t budget = lds_per_cu / wg_per_cu;
   const size_t vec_bytes = sizeof(double) * e.Dp;
-  if (fixed > budget) throw std::invalid_argument("workgroups_per_cu too high for the LDS-resident state");
-  int lds_vecs = budget > fixed + 256 ? static_cast<int>((budget - fixed - 256) / vec_bytes) : 0;
-  if (cfg.lds_vectors >= 0 && cfg.lds_vectors < lds_vecs) lds_vecs = cfg.lds_vectors;
-  if (e.geo.mem) lds_vecs = 0;  // streaming backend: vectors are far larger than LDS
-  e.pool_lds = std::min(lds_vecs, e.pool_total);
-  e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds, e.Dp);
-  if (e.geo.mem) {
-    // one more vector per workgroup, if the CU's LDS holds it for every resident workgroup: the inverse mass
-    const char* off = std::getenv("WALNUTS_AMD_NO_LDS_MASS");
-    const char* nf = std::getenv("WALNUTS_AMD_NO_FAR_END_SUMS");
-    e.no_far_end_sums = nf != nullptr && nf[0] == '1';
-    if (e.smem + vec_bytes <= budget && !(off != nullptr && off[0] == '1')) {
-      e.im_in_lds = true;
-      e.smem += vec_bytes;
-      // ... and, if the chain's vectors fit the registers the kernels set aside for it, the moving end (TrajMem, HOLD)
-      const char* nh = std::getenv("WALNUTS_AMD_NO_HELD_STATE");
-      // (such a kernel keeps the exp / log tables in LDS too, and a halo model's wavefront-edge elements)
-      const size_t tables = sizeof(double) * (wn::kLdsTableDoubles + 2 * 2 * wn::kMemHoldTiles * e.geo.nw);  // (two copies of the edges)
-      e.hold_moving_end = hold_fits && e.smem + tables <= budget && !(nh != nullptr && nh[0] == '1');
-      if (e.hold_moving_end) e.smem += tables;
+  int wg_per_cu = 0;
+  // residency for `want` workgroups per CU (0: the default for this geometry) -> whether the moving end is held
+  auto residency = [&](int want) {
+    wg_per_cu = want > 0 ? want : wn::default_workgroups_per_cu(e.geo, wps);
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 32 / e.geo.nw));
+    if (!e.geo.mem) wg_per_cu = std::min(wg_per_cu, std::max(1, 4 * wps / e.geo.nw));
+    const size_t fixed = wn::transition_smem_bytes(e.geo.nw, 0, e.Dp);
+    const size_t budget = lds_per_cu / wg_per_cu;
+    if (fixed > budget) throw std::invalid_argument("workgroups_per_cu too high for the LDS-resident state");
+    int lds_vecs = budget > fixed + 256 ? static_cast<int>((budget - fixed - 256) / vec_bytes) : 0;
+    if (cfg.lds_vectors >= 0 && cfg.lds_vectors < lds_vecs) lds_vecs = cfg.lds_vectors;
+    if (e.geo.mem) lds_vecs = 0;  // streaming backend: vectors are far larger than LDS
+    e.pool_lds = std::min(lds_vecs, e.pool_total);
+    e.smem = wn::transition_smem_bytes(e.geo.nw, e.pool_lds, e.Dp);
+    e.im_in_lds = false;
+    e.hold_moving_end = false;
+    if (e.geo.mem) {
+      // one more vector per workgroup, if the CU's LDS holds it for every resident workgroup: the inverse mass
+      const char* off = std::getenv("WALNUTS_AMD_NO_LDS_MASS");
+      const char* nf = std::getenv("WALNUTS_AMD_NO_FAR_END_SUMS");
+      e.no_far_end_sums = nf != nullptr && nf[0] == '1';
+      if (e.smem + vec_bytes <= budget && !(off != nullptr && off[0] == '1')) {
+        e.im_in_lds = true;
+        e.smem += vec_bytes;
+        // ... and, if the chain's vectors fit the registers the kernels set aside for it, the moving end (TrajMem, HOLD)
+        const char* nh = std::getenv("WALNUTS_AMD_NO_HELD_STATE");
+        // (such a kernel keeps the exp / log tables in LDS too, and a halo model's wavefront-edge elements)
+        const size_t tables = sizeof(double) * (wn::kLdsTableDoubles + 2 * 2 * wn::kMemHoldTiles * e.geo.nw);  // (two copies of the edges)
+        e.hold_moving_end = hold_fits && e.smem + tables <= budget && !(nh != nullptr && nh[0] == '1');
+        if (e.hold_moving_end) e.smem += tables;
+      }
     }
+    return e.hold_moving_end;
+  };
+  if (cfg.workgroups_per_cu > 0) {
+    residency(cfg.workgroups_per_cu);
+  } else if (hold_fits) {
+    // a streaming kernel that can hold the moving end in registers wants the CU -- its LDS for the inverse mass, a
+    // wavefront's full register budget -- for ONE chain; if the hold is then refused (no room for the inverse mass
+    // and the tables, or switched off), the kernel that streams both ends gets its usual residency back
+    if (!residency(1)) residency(0);
+  } else {
+    residency(0);
   }
   const int usable_cus = std::max(1, e.num_cus - std::max(0, cfg.reserved_cus));
   e.grid = static_cast<int>(std::min<size_t>(num_chains, static_cast<size_t>(usable_cus) * wg_per_cu));
@@ -592,9 +607,51 @@ int wn_plugin_register_model(const void* ops, const void* abi) {
 const char* wn_model_error(void) { return wn::registry_error().c_str(); }
 // forget a failed registration (a run-time model whose id was taken is reported once, not by every later engine)
 void wn_model_clear_error(void) { wn::registry_error().clear(); }
-// The launch geometry an engine for `num_params` parameters would use (waves_per_chain / elems_per_lane: a wn_config's
-// requests, 0 = the engine's choice; preferred_elems_per_lane: the model's kPreferredElemsPerLane, 0 = none) -- a
-// model built at run time instantiates exactly this one.  *streaming: the vectors live in HBM (elems_per_lane is 0).
+// Launch geometries.  The engine's choice depends on the MODEL as well as on num_params and the wn_config's requests:
+// a model with held streaming kernels (ModelOps::hold_tiles) leaves the register kernels at its register_dim_limit.
+// wn_geometry_for_model: the ONE geometry build_engine picks for a REGISTERED model (the same choose_geometry call).
+int wn_geometry_for_model(int model, int num_params, int waves_per_chain, int elems_per_lane, int* nw, int* epl,
+                          int* streaming, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (num_params < 1) throw std::invalid_argument("num_params must be positive");
+    const wn::ModelOps& ops = wn::model_ops(model);
+    const wn::Geometry g = wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, ops.uses_params, ops.preferred_epl,
+                                               ops.hold_tiles(wn::kHeldWaves), ops.register_dim_limit);
+    if (nw != nullptr) *nw = g.nw;
+    if (epl != nullptr) *epl = g.epl;
+    if (streaming != nullptr) *streaming = g.mem ? 1 : 0;
+  });
+}
+// wn_geometry_candidates: EVERY geometry build_engine may pick for these requests, over all traits a model can have
+// (no held streaming kernels; held kernels with the register kernels up to 4 096 or up to 8 192 parameters) -- what a
+// model that is compiled at run time, and therefore not registered yet, has to instantiate.  out: triples
+// (waves per chain, elements per lane, streaming), at most `max` of them; *count = how many there are.
+int wn_geometry_candidates(int num_params, int waves_per_chain, int elems_per_lane, int preferred_elems_per_lane,
+                           int* out, int max, int* count, WalnutpyError** err) {
+  return guarded(err, [&] {
+    if (num_params < 1) throw std::invalid_argument("num_params must be positive");
+    if (count == nullptr) throw std::invalid_argument("null argument");
+    const int traits[3][2] = {{0, wn::kMaxRegisterDim}, {wn::kMemHoldTiles, 4096}, {wn::kMemHoldTiles, 8192}};
+    int n = 0;
+    wn::Geometry seen[3];
+    for (const auto& t : traits) {
+      const wn::Geometry g = wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, false,
+                                                 preferred_elems_per_lane, t[0], t[1]);
+      bool dup = false;
+      for (int i = 0; i < n; ++i) dup = dup || (seen[i].nw == g.nw && seen[i].epl == g.epl && seen[i].mem == g.mem);
+      if (dup) continue;
+      seen[n] = g;
+      if (out != nullptr && n < max) {
+        out[3 * n] = g.nw;
+        out[3 * n + 1] = g.epl;
+        out[3 * n + 2] = g.mem ? 1 : 0;
+      }
+      ++n;
+    }
+    *count = n;
+  });
+}
+// (kept: the choice for a model WITHOUT held streaming kernels and with the default register limit)
 int wn_geometry_for(int num_params, int waves_per_chain, int elems_per_lane, int preferred_elems_per_lane, int* nw,
                     int* epl, int* streaming, WalnutpyError** err) {
   return guarded(err, [&] {

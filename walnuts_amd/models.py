@@ -5,8 +5,9 @@ The reference takes any host function as a model: a ``LOGP_CFUNC`` pointer, a nu
 GPU-resident trajectory, so here a model is a header of static device functions (``walnuts_amd/csrc/wn_model_api.h``)
 that is compiled INTO the transition kernels.  ``build_device_model`` does that at call time, without touching
 ``libwalnuts_hip.so``: it writes the model's five-line translation unit, compiles it against the installed headers
-(``walnuts_amd/csrc``) with one ``hipcc -shared`` -- instantiating only the ONE launch geometry the engine will use
-for ``num_params`` parameters (``wn_geometry_for``), which takes seconds where the whole table takes minutes -- and
+(``walnuts_amd/csrc``) with one ``hipcc -shared`` -- instantiating only the launch geometries the engine may use
+for ``num_params`` parameters (``wn_geometry_candidates``: one, or up to three where the choice depends on the model's
+traits), which takes seconds where the whole table takes minutes -- and
 ``load_device_model`` loads the result; the shared object's static initialiser enters the model into the library's
 registry (``wn_plugin_register_model``).  From then on ``model_id(name)`` resolves it and every entry point takes it.
 """
@@ -39,30 +40,52 @@ def translation_unit(header: str, type_name: str, tag: str, model_id: int) -> st
             f"#define WN_MODEL_TYPE {type_name}\n" '#include "wn_kernels.inc"\n')
 
 
-def geometry_for(num_params: int, *, waves_per_chain: int = 0, elems_per_lane: int = 0,
+def geometry_for(num_params: int, *, model: Optional[int] = None, waves_per_chain: int = 0, elems_per_lane: int = 0,
                  preferred_elems_per_lane: int = 0, lib_path: Optional[str] = None):
-    """-> (waves per chain, elements per lane, streaming?) of the engine's kernel for ``num_params`` parameters."""
+    """-> (waves per chain, elements per lane, streaming?) of the engine's kernel for ``num_params`` parameters.
+
+    ``model``: the id of a REGISTERED model -- the answer is then the one geometry ``wn_engine_create`` picks for it
+    (``wn_geometry_for_model``).  Without it: the choice for a model that has no held streaming kernels
+    (``wn_geometry_for``); for 4 097-16 384 parameters a model with such kernels runs them instead --
+    :func:`geometry_candidates` lists every possibility."""
     lib = _ffi.load_library(lib_path)
     nw, epl, mem, err = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
-    _ffi.check(lib, lib.wn_geometry_for(num_params, waves_per_chain, elems_per_lane, preferred_elems_per_lane,
-                                        C.byref(nw), C.byref(epl), C.byref(mem), C.byref(err)), err)
+    if model is not None:
+        rc = lib.wn_geometry_for_model(int(model), num_params, waves_per_chain, elems_per_lane, C.byref(nw), C.byref(epl),
+                                       C.byref(mem), C.byref(err))
+    else:
+        rc = lib.wn_geometry_for(num_params, waves_per_chain, elems_per_lane, preferred_elems_per_lane,
+                                 C.byref(nw), C.byref(epl), C.byref(mem), C.byref(err))
+    _ffi.check(lib, rc, err)
     return nw.value, epl.value, bool(mem.value)
 
 
-HELD_WAVES = 8   # wn_launch.h, kHeldWaves
+def geometry_candidates(num_params: int, *, waves_per_chain: int = 0, elems_per_lane: int = 0,
+                        preferred_elems_per_lane: int = 0, lib_path: Optional[str] = None):
+    """Every (waves per chain, elements per lane, streaming?) the engine may pick for these requests, over all traits a
+    model can have (``wn_geometry_candidates``): what a model compiled at run time has to instantiate."""
+    lib = _ffi.load_library(lib_path)
+    out, n, err = (C.c_int * 9)(), C.c_int(), C.c_void_p()
+    _ffi.check(lib, lib.wn_geometry_candidates(num_params, waves_per_chain, elems_per_lane, preferred_elems_per_lane,
+                                               out, 3, C.byref(n), C.byref(err)), err)
+    return [(out[3 * i], out[3 * i + 1], bool(out[3 * i + 2])) for i in range(n.value)]
 
 
-def geometry_defines(nw: int, epl: int, streaming: bool, waves_requested: bool = True) -> Sequence[str]:
-    if not streaming:
-        chip = [f"-DWN_ONLY_NW={nw}", f"-DWN_ONLY_EPL={epl}"]
-        # where the register kernels would need sixteen wavefronts per chain (4 097-8 192 parameters) the engine runs
-        # most models on the held streaming kernels instead (wn_launch.h, ModelOps::register_dim_limit): both are built
-        return chip if (waves_requested or nw < 16) else chip + [f"-DWN_ONLY_MEM_NW={HELD_WAVES}"]
-    # the engine's own streaming choice depends on the model (one-pass gradients up to 16 384 dimensions run the
-    # kernels that hold the moving end in registers, HELD_WAVES wavefronts per chain): both candidates are built
-    if waves_requested or nw == HELD_WAVES:
-        return [f"-DWN_ONLY_MEM_NW={nw}"]
-    return [f"-DWN_ONLY_MEM_NW={nw}", f"-DWN_ONLY_MEM_NW_ALSO={HELD_WAVES}"]
+def geometry_defines(candidates) -> Sequence[str]:
+    """-DWN_ONLY_* switches (wn_launch.h) that instantiate exactly the candidate geometries: at most one register
+    geometry and two streaming ones -- the library decides (geometry_candidates), nothing about the rule lives here."""
+    chip = [(nw, epl) for nw, epl, mem in candidates if not mem]
+    mem = [nw for nw, epl, m in candidates if m]
+    if len(chip) > 1 or len(mem) > 2:
+        raise _ffi.WalnutsHipError(f"more candidate geometries than a model object holds: {candidates}")
+    flags = []
+    if chip:
+        flags += [f"-DWN_ONLY_NW={chip[0][0]}", f"-DWN_ONLY_EPL={chip[0][1]}"]
+    if mem:
+        flags.append(f"-DWN_ONLY_MEM_NW={mem[0]}")
+    if len(mem) > 1:
+        flags.append(f"-DWN_ONLY_MEM_NW_ALSO={mem[1]}")
+    return flags
 
 
 def build_device_model(header: str, type_name: str, tag: str, model_id: int, num_params: int, *,
@@ -79,18 +102,18 @@ def build_device_model(header: str, type_name: str, tag: str, model_id: int, num
     the flags (default ``["hipcc"] + hipcc_flags()``; the CPU test tier passes g++ with the emulation's flags)."""
     header = os.path.abspath(header)
     lib_file = os.path.abspath(lib_path or os.environ.get("WALNUTS_AMD_LIB") or _ffi.DEFAULT_LIB)
-    nw, epl, streaming = geometry_for(num_params, waves_per_chain=waves_per_chain, elems_per_lane=elems_per_lane,
-                                      preferred_elems_per_lane=preferred_elems_per_lane, lib_path=lib_path)
+    candidates = geometry_candidates(num_params, waves_per_chain=waves_per_chain, elems_per_lane=elems_per_lane,
+                                     preferred_elems_per_lane=preferred_elems_per_lane, lib_path=lib_path)
     out_dir = out_dir or tempfile.mkdtemp(prefix="wn_model_")
     os.makedirs(out_dir, exist_ok=True)
     src = os.path.join(out_dir, f"wn_kernels_{tag}.hip")
     with open(src, "w") as f:
         f.write(translation_unit(header, type_name, tag, model_id))
-    geo = f"mem{nw}" if streaming else f"{nw}x{epl}"
+    geo = "_".join(f"mem{nw}" if mem else f"{nw}x{epl}" for nw, epl, mem in candidates)
     out = os.path.join(out_dir, f"libwn_model_{tag}_{geo}.so")
     cmd = list(compiler) if compiler is not None else ["hipcc"] + list(hipcc_flags(lib_path))
     cmd += ["-DWN_MODEL_PLUGIN",
-            *geometry_defines(nw, epl, streaming, waves_per_chain > 0 or elems_per_lane != 0 or preferred_elems_per_lane > 0),
+            *geometry_defines(candidates),
             "-I", CSRC, "-I", os.path.dirname(header),
             *extra_flags, "-shared", src, "-o", out,
             # the registration call resolves against the library the engines come from

@@ -1,14 +1,16 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): the round's bench lines of every BASELINE configuration + the rocprofv3
-# kernel trace of the headline.  Outputs land in gpurun_out/$PROFILE_ROUND/ (default r05); PMC passes are profiles/pmc.sh's.
+# kernel trace of the headline.  Outputs land in gpurun_out/$PROFILE_ROUND/ (default r06); PMC passes are profiles/pmc.sh's.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-R=${PROFILE_ROUND:-r05}
+R=${PROFILE_ROUND:-r06}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py"
-$B > $OUT/bench_headline.json 2> $OUT/bench.err
+# the line the driver runs, as the driver runs it: headline + the legs for configs #2-#4 and the warmup phase
+python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2> $OUT/bench.err
+B="python3 $ROOT/bench.py --legs none"
+$B > $OUT/bench_headline.json 2>> $OUT/bench.err
 $B --phase warmup --no-cpu-baseline --no-parity-gate > $OUT/bench_headline_warmup.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model ill_normal --chains 4096 --dim 1024 --adapt-iters 300 > $OUT/bench_cfg2.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model funnel --chains 16384 --dim 128 --adapt-iters 300 > $OUT/bench_cfg3.json 2>> $OUT/bench.err
@@ -41,9 +43,13 @@ $B --no-cpu-baseline --no-parity-gate --chains 32768 --steps 40 > $OUT/bench_sha
 $B --no-cpu-baseline --model funnel --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_funnel_16384_streaming.json 2>> $OUT/bench.err
 $B --no-cpu-baseline --model rw1 --chains 8192 --dim 16384 --steps 8 --warmup 8 --adapt-iters 60 --gate-chains 16 --gate-transitions 4 > $OUT/bench_rw1_16384_streaming.json 2>> $OUT/bench.err
 $B --gpus 2 --backend gloo --no-cpu-baseline --steps 16 --warmup 8 > $OUT/bench_gloo2_one_gpu.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate > $OUT/bench_headline_under_trace.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $OUT/headline_trace -o t -- python3 $ROOT/bench.py --legs none --no-cpu-baseline --no-parity-gate > $OUT/bench_headline_under_trace.json 2>/dev/null
 python3 $ROOT/profiles/summarize.py $R $(find $OUT/headline_trace -name "*results.db" | head -1) > $OUT/kernel_trace_headline.txt 2>&1
 rm -rf $OUT/headline_trace
+# ... and of the DRIVER's command with its legs: per kernel, the launch durations bench.py's avg_launch_ms must agree with
+rocprofv3 --kernel-trace --stats -d $OUT/driver_trace -o t -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_line_under_trace.json 2>/dev/null
+python3 $ROOT/profiles/summarize.py $R $(find $OUT/driver_trace -name "*results.db" | head -1) --per-kernel > $OUT/kernel_trace_driver_line.txt 2>&1
+rm -rf $OUT/driver_trace
 # the whole drop-in call, phase by phase (WALNUTS_AMD_TIMING), and a longer run of the randomised parity campaign
 (cd $ROOT && WALNUTS_AMD_TIMING=1 timeout 900 python3 tests/gpu_probes/sample_device_e2e.py > $OUT/sample_device_e2e.txt 2>&1)
 (cd $ROOT && timeout 600 python3 tests/gpu_probes/fuzz_parity.py --seconds 240 --seed 506 > $OUT/fuzz_parity.txt 2>&1; tail -3 $OUT/fuzz_parity.txt)

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export WALNUTS_AMD_CHAIN_GROUPS=1   # (one dispatch per launch: the per-launch counter values below are one kernel's)
 # (steps and warmup are multiples of the transitions per launch: every profiled dispatch is a full launch)
-ARGS="--no-cpu-baseline --no-parity-gate --steps 16 --warmup 8 --adapt-iters 100 $*"
+ARGS="--no-cpu-baseline --no-parity-gate --legs none --min-launches 2 --steps 16 --warmup 8 --adapt-iters 100 $*"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
@@ -46,7 +46,7 @@ known, _ = ap.parse_known_args("$ARGS".split())
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     json.dump({"model": known.model, "chains": known.chains, "dim": known.dim, "phase": known.phase,
                "transitions_per_launch": max(1, known.transitions_per_launch), "csrc_sha": bench.csrc_sha(), "chain_groups": 1, "bytes_per_launch": (2 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024,
-               "source": "profiles/${PROFILE_ROUND:-r05}/pmc_$TAG.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, last "
+               "source": "profiles/${PROFILE_ROUND:-r06}/pmc_$TAG.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, last "
                          "(steady-state) dispatch, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 note in MI355X_MICROARCH.md"},
               open("$OUT/traffic.json", "w"))
 if "SQ_WAVE_CYCLES" in vals:

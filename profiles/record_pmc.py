@@ -16,8 +16,8 @@ def main():
     entries = json.load(open(path)) if os.path.exists(path) else []
     for tag in sys.argv[1:]:
         src = os.path.join(ROOT, "gpurun_out", "pmc_" + tag)
-        os.makedirs(os.path.join(ROOT, "profiles", os.environ.get("PROFILE_ROUND", "r05")), exist_ok=True)
-        shutil.copy(os.path.join(src, "summary.txt"), os.path.join(ROOT, "profiles", os.environ.get("PROFILE_ROUND", "r05"), f"pmc_{tag}.txt"))
+        os.makedirs(os.path.join(ROOT, "profiles", os.environ.get("PROFILE_ROUND", "r06")), exist_ok=True)
+        shutil.copy(os.path.join(src, "summary.txt"), os.path.join(ROOT, "profiles", os.environ.get("PROFILE_ROUND", "r06"), f"pmc_{tag}.txt"))
         e = json.load(open(os.path.join(src, "traffic.json")))
         key = lambda x: (x["model"], x["chains"], x["dim"], x["phase"], x.get("transitions_per_launch", 1))
         entries = [x for x in entries if key(x) != key(e)] + [e]

@@ -30,6 +30,30 @@ def kernel_stats(db):
     return lines, rows
 
 
+def per_kernel(db):
+    """The driver's command runs several workloads (bench.py's legs): one block per transition kernel, in the order of
+    first dispatch.  A leg's TIMED launches are its last ones (after its adaptation and warm-up launches); with two
+    chain groups a launch is two overlapping dispatches of the same kernel, each lasting about the launch period, so
+    the mean over the last dispatches is what bench.py reports as avg_launch_ms of that leg."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name,(end-start)/1e3,grid_x,workgroup_x from kernels where name like '%transition_kernel%' "
+                       "order by start").fetchall()
+    order, by = [], {}
+    for name, us, grid, block in rows:
+        if name not in by:
+            order.append(name)
+            by[name] = []
+        by[name].append((us, grid, block))
+    lines = ["", "per transition kernel (a bench leg = adaptation launches of the WARM instantiation, then its timed launches):"]
+    for name in order:
+        d = [x[0] for x in by[name]]
+        tail = d[-16:] if len(d) >= 24 else d[len(d) // 2:]
+        lines.append(f"  {name[:150]}")
+        lines.append(f"    {len(d)} dispatches, grid={by[name][-1][1]} block={by[name][-1][2]}; last {len(tail)}: mean {sum(tail) / len(tail):.1f} us, "
+                     f"min {min(tail):.1f}, max {max(tail):.1f}")
+    return lines
+
+
 def counter(db, kernel_like="%transition_kernel%"):
     cur = sqlite3.connect(db).cursor()
     return cur.execute("select counter_name,value,duration from counters_collection where kernel_name like ? order by start",
@@ -41,6 +65,9 @@ def main():
     out = [f"# rocprofv3 summary {tag}", "", "## --kernel-trace --stats", ""]
     lines, rows = kernel_stats(trace)
     out += lines
+    if "--per-kernel" in sys.argv:
+        sys.argv.remove("--per-kernel")
+        out += per_kernel(trace)
     if len(sys.argv) >= 5:
         f, w = counter(sys.argv[3]), counter(sys.argv[4])
         out += ["", "## PMC (separate passes; KB per dispatch of transition_kernel; kernels run serialised and slower under PMC)", ""]

@@ -165,6 +165,15 @@ def test_multi_device_controllers_look_at_all_chains(sim):
 
 
 @pytest.mark.timeout(900)
+def test_results_carry_the_stream_version(sim):
+    """every result says which definition of the counter-based streams produced it (wn_stream_version)."""
+    out = _run(sim, num_chains=2)
+    import walnuts_amd as wa
+
+    assert wa.stream_version(sim) == 2 and all(a.warmup.stream_version == 2 for a in out)
+
+
+@pytest.mark.timeout(900)
 def test_multi_device_resident_gathers_the_shards_draws(sim, oracle):
     """walnutpie_sample_device_multi_resident with devices = {0, 0} / {0, 0, 0}: every shard keeps its sampling draws
     on its device, the blocks are gathered into ONE wn_chains (peer copies) -- the thinned rows, the warmup rows and the

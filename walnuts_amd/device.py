@@ -20,6 +20,9 @@ class WarmupInfo(Generic[T]):  # python/src/walnutpie/util.py:47-66
     stepsize: float
     inv_metric: Optional[np.ndarray]
     warmup_draws: Optional[T]
+    # not in the reference: which definition of the library's counter-based random streams produced this run
+    # (wn_stream_version()): a stored result is reproducible from its seed only under the same version
+    stream_version: Optional[int] = None
 
 
 class WalnutsOutputArray(np.ndarray):  # python/src/walnutpie/pyfunc.py (ndarray with a .warmup attribute)
@@ -198,6 +201,7 @@ def walnuts_device(
         else:
             print(text, end="", flush=True)
 
+    stream_version = int(lib.wn_stream_version())
     cb = _ffi.PRINT_CALLBACK(_print)
     dp = _ffi._dp
     err = C.c_void_p()
@@ -242,7 +246,8 @@ def walnuts_device(
         n_warm, n_samp = int(final_lengths[c]), int(final_lengths[num_chains + c])
         warm = out[c, :n_warm] if save_warmup else None
         info = WarmupInfo(stepsize=float(stepsize_out[c]),
-                          inv_metric=None if inv_metric_out is None else inv_metric_out[c], warmup_draws=warm)
+                          inv_metric=None if inv_metric_out is None else inv_metric_out[c], warmup_draws=warm,
+                          stream_version=None if reference_streams else stream_version)
         if keep_on_device:   # rows 0, thin, 2 thin, ... of the n_samp draws the device holds
             n_samp = 0 if thin == 0 else -(-n_samp // thin)
         return WalnutsOutputArray(out[c, n_warm:n_warm + n_samp], info)

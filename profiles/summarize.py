@@ -31,26 +31,30 @@ def kernel_stats(db):
 
 
 def per_kernel(db):
-    """The driver's command runs several workloads (bench.py's legs): one block per transition kernel, in the order of
-    first dispatch.  A leg's TIMED launches are its last ones (after its adaptation and warm-up launches); with two
-    chain groups a launch is two overlapping dispatches of the same kernel, each lasting about the launch period, so
-    the mean over the last dispatches is what bench.py reports as avg_launch_ms of that leg."""
+    """The driver's command runs several workloads (bench.py's legs), each followed by its parity gate on a small
+    engine: one block per (transition kernel, grid), in the order of first dispatch.  A leg's launches have the
+    workload's grid (resident workgroups x block), its gate's a grid of 64 chains.  Within a leg the WARM instantiation
+    runs the adaptation launches (and the warmup leg's timed ones), the other one the timed sampling launches; with two
+    chain groups a launch is two overlapping dispatches of the same kernel, each lasting about the launch period --
+    their mean over the later dispatches is what bench.py reports as that leg's avg_launch_ms."""
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name,(end-start)/1e3,grid_x,workgroup_x from kernels where name like '%transition_kernel%' "
                        "order by start").fetchall()
     order, by = [], {}
     for name, us, grid, block in rows:
-        if name not in by:
-            order.append(name)
-            by[name] = []
-        by[name].append((us, grid, block))
-    lines = ["", "per transition kernel (a bench leg = adaptation launches of the WARM instantiation, then its timed launches):"]
-    for name in order:
-        d = [x[0] for x in by[name]]
-        tail = d[-16:] if len(d) >= 24 else d[len(d) // 2:]
-        lines.append(f"  {name[:150]}")
-        lines.append(f"    {len(d)} dispatches, grid={by[name][-1][1]} block={by[name][-1][2]}; last {len(tail)}: mean {sum(tail) / len(tail):.1f} us, "
-                     f"min {min(tail):.1f}, max {max(tail):.1f}")
+        key = (name, grid, block)
+        if key not in by:
+            order.append(key)
+            by[key] = []
+        by[key].append(us)
+    lines = ["", "per (transition kernel, grid) in order of first dispatch -- durations in us:"]
+    for key in order:
+        d = by[key]
+        name, grid, block = key
+        tail = d[len(d) // 3:] if len(d) >= 6 else d   # (past the ramp: the first dispatches after a join run alone)
+        lines.append(f"  {name[:130]}  grid={grid} block={block}")
+        lines.append(f"    {len(d)} dispatches; last {len(tail)}: mean {sum(tail) / len(tail):.1f}, min {min(tail):.1f}, "
+                     f"max {max(tail):.1f}")
     return lines
 
 

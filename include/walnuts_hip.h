@@ -262,6 +262,8 @@ WALNUTS_HIP_EXPORT int wn_stream_version(void);
 /* The code-generation flags the library was compiled with (csrc/Makefile CODEGEN_FLAGS, a space-separated string):
  * device models compiled at run time are built with exactly these, so that a plugin and the library cannot drift. */
 WALNUTS_HIP_EXPORT const char* wn_build_flags(void);
+/* ... and the compiler it was built with (the "HIP version:" line of `hipcc --version`; "" if the build did not say) */
+WALNUTS_HIP_EXPORT const char* wn_build_compiler(void);
 /* Device models compiled at RUN time -- the device counterpart of handing the reference a host callable
  * (LOGP_CFUNC / a numba cfunc: python/src/walnutpie/walnutpy.cpp:131-132, pyfunc.py:216).  The model's five-line
  * translation unit is compiled against the installed headers (walnuts_amd/csrc) into a shared object of its own
@@ -451,6 +453,9 @@ WALNUTS_HIP_EXPORT int wn_lanes_for_model_dim(int model, int num_params, int wav
  * count_per_chain normals x scale per chain from mt19937_64(seed_seq{seed, stream}) through libstdc++'s
  * normal_distribution -- one distribution for all chains (initial positions, config.hpp:259-268) or a fresh one per
  * chain (step-size search, util.hpp:288) */
+/* (internal, for the tests) the kernels' range-free square root (csrc/wn_devmath.h sqrt_normal) evaluated on the device
+ * for n host arguments; checked != 0: the variant that patches 0 / inf back in.  -> 0, or -1 */
+WALNUTS_HIP_EXPORT int wn_internal_sqrt_probe(const double* x, double* y, size_t n, int checked);
 WALNUTS_HIP_EXPORT void wn_internal_reference_normals(unsigned int seed, unsigned int stream, size_t num_chains,
                                                       size_t count_per_chain, int fresh_per_chain, double scale,
                                                       double* out);

@@ -378,6 +378,41 @@ def test_host_supplied_variates_path():
 
 
 # ---- size-independent properties at full BASELINE sizes --------------------------------------------------
+def test_range_free_square_root_equals_sqrt_on_the_device():
+    """wnd::sqrt_normal (wn_devmath.h): the compiler's fp64 sqrt refinement without its range scaling and special-case
+    patches -- the Box-Muller radius and the warmup prologue's inverse mass / Cholesky factor use it.  Bit for bit equal
+    to the correctly rounded square root on 2.4e7 arguments: dense around the radicand's range [2^-52, 73], every
+    binade from 2^-760 to 2^1023, values one ulp either side of perfect squares (the hard cases of a last-bit
+    correction); the checked variant also on 0, -0, inf, NaN and negative arguments."""
+    import ctypes as C
+    lib = wa.load_library()
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(8)
+
+    def device_sqrt(x, checked):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        assert lib.wn_internal_sqrt_probe(x.ctypes.data_as(dp), y.ctypes.data_as(dp), x.size, checked) == 0
+        return y
+
+    squares = rng.uniform(1.0, 2.0, size=1 << 20) ** 2
+    args = np.concatenate([
+        -2.0 * np.log(rng.uniform(size=1 << 23)),                                     # the radicand's own law
+        np.exp(rng.uniform(np.log(2.0 ** -52), np.log(73.0), size=1 << 22)),
+        rng.uniform(1.0, 4.0, size=1 << 22) * 2.0 ** rng.integers(-760, 1022, size=1 << 22),
+        squares, np.nextafter(squares, 0.0), np.nextafter(squares, 10.0),
+    ])
+    want = np.sqrt(args)
+    for checked in (0, 1):
+        got = device_sqrt(args, checked)
+        assert np.array_equal(got, want), int(np.sum(got != want))
+    special = np.array([0.0, -0.0, np.inf, np.nan, -1.0, -np.inf, 4.0])
+    with np.errstate(invalid="ignore"):
+        want = np.sqrt(special)
+    got = device_sqrt(special, 1)
+    assert np.array_equal(got, want, equal_nan=True) and np.signbit(got[1])
+
+
 def _logp_std_normal(x):
     return -0.5 * np.einsum("ij,ij->i", x, x)
 

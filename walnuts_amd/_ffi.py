@@ -86,6 +86,7 @@ SYMBOLS = [
      [_i32, _dp, _i32, _dp, _sz, C.c_uint, C.c_uint, _dbl, _dp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl,
       _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_bool, _dp, _sz, C.POINTER(C.c_int),
       _dp, _dp, _i32, PRINT_CALLBACK, C.POINTER(C.c_int), _i32, _i32, C.POINTER(_vp), _errpp]),
+    ("wn_internal_sqrt_probe", _i32, [_dp, _dp, _sz, _i32]),
     ("wn_internal_reference_normals", None, [C.c_uint, C.c_uint, _sz, _sz, _i32, _dbl, _dp]),
     ("walnutpie_ess", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
     ("walnutpie_r_hat", _i32, [_dp, _i32, _i32, C.POINTER(C.c_int), _i32, _dp, _errpp]),
@@ -94,6 +95,7 @@ SYMBOLS = [
     ("wn_model_id", _i32, [C.c_char_p]),
     ("wn_stream_version", _i32, []),
     ("wn_build_flags", C.c_char_p, []),
+    ("wn_build_compiler", C.c_char_p, []),
     ("wn_plugin_register_model", _i32, [_vp, _vp]),
     ("wn_model_error", C.c_char_p, []),
     ("wn_model_clear_error", None, []),

@@ -599,6 +599,12 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     free_mask = (P.pool_total >= 64) ? ~0ull : ((1ull << P.pool_total) - 1ull);
     const long long row = static_cast<long long>(chain) * kDp;
     const bool warm = is_warmup();
+    if constexpr (WARM) {
+      if (WN_UNLIKELY(this->cold().est_mode == 2)) {
+        observe_only(row);
+        return;
+      }
+    }
 
     // momentum refresh + initial point (walnuts.hpp:528-535), into set 0
     double lp_pos, lj;
@@ -871,11 +877,42 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
 #endif
   }
 
+  // The mass estimator's observation of a warmup transition's result (adaptive_walnuts.hpp:247-248) is applied by the
+  // NEXT transition's prologue (kDeferObservation), not by its own epilogue: what it observes -- the selected position
+  // and the gradient there -- is the next transition's initial point, which the prologue holds and evaluates anyway;
+  // the four estimator planes it reads arrive behind the momentum generator like every other prologue load (in the
+  // epilogue they stood in the open: ~4 700 of a warmup transition's 63 000 cycles, tests/gpu_probes/timeline.py),
+  // the two sums of squared deviations are read once per transition instead of twice, and a model whose gradient is
+  // carried (not recomputed) saves its re-evaluation.  Same operations in the same order, so the same bits.  Between
+  // two launches the engine remembers that an observation is pending (Params::est_mode) and applies it before anything
+  // else looks at the estimator (wn_engine: flush_pending_observation -> est_mode 2 -> observe_only()).
+  static constexpr bool kDeferObservation = true;
+  // online_moments.hpp:184-191 (the lazy delta: (y - mean_new)^2) for both moments, in place; -> the new weights
+  __device__ __forceinline__ void observe(double (&mean)[EPL], double (&ssd)[EPL], double (&smean)[EPL], double (&sssd)[EPL],
+                                          long long iteration) {
+    const auto& Q = this->cold();
+    const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(iteration));
+    const wnd::SharedDivisor wd(discount * w_draw0 + 1);
+    const wnd::SharedDivisor ws(discount * w_score0 + 1);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      mean[j] += (th[kI][j] - mean[j]) / wd;
+      ssd[j] = discount * ssd[j] + (th[kI][j] - mean[j]) * (th[kI][j] - mean[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      smean[j] += (G<kI>(j) - smean[j]) / ws;
+      sssd[j] = discount * sssd[j] + (G<kI>(j) - smean[j]) * (G<kI>(j) - smean[j]);
+    }
+    w_draw0 = wd.b;
+    w_score0 = ws.b;
+  }
+
   // load the chain, refresh the momentum (walnuts.hpp:528-529), evaluate the initial point (:532)
   __device__ __forceinline__ double begin_transition(long long row, bool warm) {
     const auto& Q = this->cold();
     // Order matters: the chain's scalars and planes are REQUESTED first, then the momentum's standard normals are
-    // generated (pure arithmetic: Philox + Box-Muller, ~2 000 VALU instructions per wavefront at 16 elements per
+    // generated (pure arithmetic: Philox + Box-Muller, ~1 000 VALU instructions per wavefront at 16 elements per
     // lane), and only then is anything loaded looked at -- the round trips to HBM hide behind the generator.
     this->request_tuning(warm);
     // (a launch runs Params::fused transitions of the chain back to back: after the first one the position is the
@@ -884,9 +921,15 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     if (first_of_launch) vload_stream(Q.theta + row, th[kI]);
     if (Model::kUsesParams) vload(Q.model_params, mp);
     double ds[EPL], ss[EPL];  // warmup: the estimator's two sums of squared deviations; sampling: ds = cholesky_mass
+    double dm[EPL], sm[EPL];  // warmup with an observation pending: the two means
+    const bool pending = warm && (!first_of_launch || Q.est_mode == 1);
     if (warm) {
       vload_stream(Q.est_draw_ssd + row, ds);
       vload_stream(Q.est_score_ssd + row, ss);
+      if (pending) {
+        vload_stream(Q.est_draw_mean + row, dm);
+        vload_stream(Q.est_score_mean + row, sm);
+      }
     } else {
       if (first_of_launch) vload_stream(Q.inv_mass + row, im);
       vload_stream(Q.chol_mass + row, ds);  // 1/sqrt(inv_mass), walnuts.hpp:647, stored once by freeze_kernel
@@ -908,6 +951,15 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
     WN_MARK(kPhMomentum);
     this->finish_tuning(warm);
     WN_MARK(kPhTuned);
+    // the initial point (walnuts.hpp:532): its gradient is also what a pending observation observes
+    const double part = model_eval<kI>();
+    if (pending) {
+      observe(dm, ds, sm, ss, this->warmup_iter_now() - 1);
+      vstore_stream(Q.est_draw_mean + row, dm);
+      vstore_stream(Q.est_draw_ssd + row, ds);
+      vstore_stream(Q.est_score_mean + row, sm);
+      vstore_stream(Q.est_score_ssd + row, ss);
+    }
     // rho = cholesky_mass * z (walnuts.hpp:528-529), padding slots zero
     const wnd::SharedDivisor wd0(warm ? w_draw0 : 1.0), ws0(warm ? w_score0 : 1.0);  // (wnd::SharedDivisor: same quotients)
 #pragma unroll
@@ -915,8 +967,9 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       double chol;
       if (warm) {
         // adaptive_walnuts.hpp:235-236 with MassEstimator::inv_mass_estimate :89-94
-        im[j] = __builtin_sqrt((ds[j] / wd0) / (ss[j] / ws0));
-        chol = __builtin_sqrt(1.0 / im[j]);
+        // (wnd::sqrt_normal<true>: sqrt's bits for every operand that is normal when it is finite and positive)
+        im[j] = wnd::sqrt_normal<true>((ds[j] / wd0) / (ss[j] / ws0));
+        chol = wnd::sqrt_normal<true>(1.0 / im[j]);
       } else {
         // Streaming the plane costs 8 KB of the 48 KB a 1024-dimensional chain moves per transition; re-evaluating
         // 1 / sqrt(im) (a division and a square root per element) costs ~2 000 cycles of the ~85 000 a transition took
@@ -926,24 +979,41 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       const double r = chol * rh[kI][j];
       rh[kI][j] = (fed || valid(j)) ? r : 0.0;
     }
-    return model_eval<kI>();
+    return part;
+  }
+
+  // Params::est_mode == 2: nothing but the pending observation of this chain (the engine's flush before a read of the
+  // estimator, a freeze, or anything that replaces the positions).  The observed state is the position plane's row.
+  __device__ __forceinline__ void observe_only(long long row) {
+    const auto& Q = this->cold();
+    this->request_tuning(true);
+    vload_stream(Q.theta + row, th[kI]);
+    if (Model::kUsesParams) vload(Q.model_params, mp);
+    double ds[EPL], ss[EPL], dm[EPL], sm[EPL];
+    vload_stream(Q.est_draw_ssd + row, ds);
+    vload_stream(Q.est_score_ssd + row, ss);
+    vload_stream(Q.est_draw_mean + row, dm);
+    vload_stream(Q.est_score_mean + row, sm);
+    this->finish_tuning(true);
+    (void)model_eval<kI>();
+    observe(dm, ds, sm, ss, Q.warmup_iter - 1);
+    vstore_stream(Q.est_draw_mean + row, dm);
+    vstore_stream(Q.est_draw_ssd + row, ds);
+    vstore_stream(Q.est_score_mean + row, sm);
+    vstore_stream(Q.est_score_ssd + row, ss);
+    if (NW > 1) __syncthreads();  // (every wavefront has read the old weights before thread 0 replaces them)
+    if (tid == 0) {
+      Q.est_weight[2 * chain] = w_draw0;
+      Q.est_weight[2 * chain + 1] = w_score0;
+    }
+    this->prefetch_next_chain();
   }
 
   __device__ __forceinline__ void finish_transition(int a_sel, long long row, bool warm) {
     const auto& Q = this->cold();
-    // warmup: the estimator's four planes are requested before anything else -- they come from HBM (last touched a
-    // launch ago), and requested where they are used, one pair after the other, their two round trips (~2 x 2 000
-    // cycles) stood in the open at the end of every transition
-    double mean[EPL], ssd[EPL], smean[EPL], sssd[EPL];
-    if (warm) {
-      vload_stream(Q.est_draw_mean + row, mean);
-      vload_stream(Q.est_draw_ssd + row, ssd);
-      vload_stream(Q.est_score_mean + row, smean);
-      vload_stream(Q.est_score_ssd + row, sssd);
-      // ... and the batched Adam update (adam.hpp:70-86 for every macro step of this transition: ~4 000 cycles of
-      // wave-uniform arithmetic that touches none of the planes) runs while they are on their way
-      if (wave == 0) this->adam_flush();
-    }
+    // warmup: the batched Adam update (adam.hpp:70-86 for every macro step of this transition, wave-uniform arithmetic);
+    // the estimator's observation of the selected state waits for the next prologue (kDeferObservation)
+    if (warm && wave == 0) this->adam_flush();
     if (kOtherRegs && a_sel == kOther) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) th[kI][j] = fetch(oth[j]);
@@ -951,7 +1021,8 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
       pool_load(a_sel, th[kI]);
     }
     WN_MARK(kPhSelLoaded);
-    // the position plane is read again by the NEXT launch only: the launch's last transition of the chain writes it
+    // the position plane is read again by the NEXT launch only (its first prologue, or the engine's flush of the pending
+    // observation): the launch's last transition of the chain writes it
     if (this->fuse_t + 1 >= Q.fused) vstore_stream(Q.theta + row, th[kI]);
     double* draws = Q.draws_out;
     if (WN_LIKELY(draws != nullptr)) {
@@ -965,32 +1036,6 @@ struct TrajChip : TrajBase<TrajChip<Model, NW, EPL, WARM, FMA>, Model, NW> {
           if (valid(j)) stream_store(th[kI][j], &out[index(j)]);
         }
       }
-    }
-    if (warm) {
-      // adaptive_walnuts.hpp:247-248: observe (theta_sel, grad_sel).  grad_sel is a pure
-      // function of theta_sel, so it is re-evaluated instead of being carried through the tree.
-      if constexpr (!kNoGrad) {
-        const long long keep_grad = n_grad;
-        (void)model_eval<kI>();
-        n_grad = keep_grad;
-      }
-      const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(this->warmup_iter_now()));
-      const wnd::SharedDivisor wd(discount * w_draw0 + 1);
-      const wnd::SharedDivisor ws(discount * w_score0 + 1);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {  // online_moments.hpp:184-191 (lazy delta => (y - mean_new)^2)
-        mean[j] += (th[kI][j] - mean[j]) / wd;
-        ssd[j] = discount * ssd[j] + (th[kI][j] - mean[j]) * (th[kI][j] - mean[j]);
-      }
-      vstore_stream(Q.est_draw_mean + row, mean);
-      vstore_stream(Q.est_draw_ssd + row, ssd);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        smean[j] += (G<kI>(j) - smean[j]) / ws;
-        sssd[j] = discount * sssd[j] + (G<kI>(j) - smean[j]) * (G<kI>(j) - smean[j]);
-      }
-      vstore_stream(Q.est_score_mean + row, smean);
-      vstore_stream(Q.est_score_ssd + row, sssd);
     }
   }
 };

@@ -74,6 +74,36 @@ WND_HD double operator/(double a, const SharedDivisor& d) {
   return __builtin_fma(__builtin_fma(-q0, d.b, a), d.r, q0);
 }
 
+// sqrt(x) for x known to be a NORMAL positive number >= 2^-767 (the Box-Muller radicand -2 log u of an open-interval
+// uniform lies in [2^-52, 73]): the refinement the compiler emits for fp64 sqrt on this target -- v_rsq_f64, one
+// Goldschmidt step, two residual corrections -- without what it wraps around it for the rest of the domain (a compare, a
+// select and a v_ldexp_f64 to scale tiny arguments up, another v_ldexp_f64 to scale back, a class test and two selects
+// for 0 / inf / NaN): 10 instructions for 18, the same correctly rounded result (an exact power-of-two scaling does not
+// change a rounding).  The host evaluates sqrt(); tests/test_gpu_parity.py compares the two on 2^24 arguments per binade
+// sample through wn_internal_sqrt_probe, and every bit-exact trajectory test depends on it.
+// `checked`: the same with the special operands patched back in (0, inf, NaN and negative arguments give what sqrt
+// gives) for arguments that are normal when they are finite and positive -- the mass estimator's variance ratios.
+template <bool checked = false>
+WND_HD double sqrt_normal(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WN_PLAIN_SQRT)
+  const double y = __builtin_amdgcn_rsq(x);
+  const double g0 = x * y, h0 = 0.5 * y;
+  const double r0 = __builtin_fma(-h0, g0, 0.5);
+  const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+  const double g2 = __builtin_fma(__builtin_fma(-g1, g1, x), h1, g1);
+  const double g3 = __builtin_fma(__builtin_fma(-g2, g2, x), h1, g2);
+  if constexpr (checked) {
+    // +-0 -> itself, +inf -> itself (class mask 0x260 = -0 | +0 | +inf); NaN and negative arguments: the sequence
+    // already ends in NaN (rsq of a negative number / of NaN is NaN)
+    return __builtin_amdgcn_class(x, 0x260) ? x : g3;
+  } else {
+    return g3;
+  }
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+
 WND_HD double two_to(int k) { return as_f64(static_cast<uint64_t>(k + 1023) << 52); }
 
 // ---------------------------------------------------------------------------
@@ -329,7 +359,7 @@ WND_HD void stream_normal_pair(uint64_t seed, uint32_t chain, uint32_t transitio
   const U4 o = philox(pair, transition, chain, stream, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
   const double u1 = open01(o.x, o.y);
   const double u2 = open01(o.z, o.w);
-  const double rad = __builtin_sqrt(-2.0 * dlog_normal(u1, tab));
+  const double rad = sqrt_normal(-2.0 * dlog_normal(u1, tab));
   double sn, cs;
   dsincospi(2.0 * u2, sn, cs);
   z0 = rad * cs;

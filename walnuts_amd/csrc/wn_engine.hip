@@ -36,6 +36,13 @@ struct ReferenceStreams {
   int pool = 0;
 };
 
+// (internal, for the tests) wnd::sqrt_normal on the device for arguments handed in from the host
+static __global__ void sqrt_probe_kernel(const double* x, double* y, long long n, int checked) {
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x)
+    y[i] = checked ? wnd::sqrt_normal<true>(x[i]) : wnd::sqrt_normal<false>(x[i]);
+}
+
 struct wn_engine {
   int model = 0, D = 0, Dp = 0;
   size_t C = 0;
@@ -96,6 +103,12 @@ struct wn_engine {
   hipEvent_t gdone[kMaxGroups] = {}, main_point = nullptr;
   hipEvent_t ext_point = nullptr, rel_point = nullptr;  // wn_engine_wait_stream / _release_stream
   uint32_t work_base[kMaxGroups] = {};  // value of each group's device-side chain counter at its next launch
+  // register kernels, warmup: the mass estimator's observation of a launch's last transition is applied by the next
+  // launch's first prologue (wn_chip.h kDeferObservation).  Until then it is PENDING: the planes and weights hold the
+  // state before it, the position plane what it will observe.  Everything but a warmup launch applies it first
+  // (flush_pending_observation(), reached through use_device()), so nothing outside the kernels ever sees the difference.
+  bool est_pending = false;
+  bool in_flush = false;
   bool groups_ahead = false;  // a group stream holds launches `stream` has not waited for
   bool main_moved = true;     // `stream` has done something since the groups last waited for it
   bool in_step = false;
@@ -135,11 +148,13 @@ struct wn_engine {
 
   void use_device() {
     HIP_OK(hipSetDevice(device));
+    if (est_pending && !in_step && !in_flush) flush_pending_observation();
     if (groups > 1 && !in_step) {  // anything but a transition launch: ordered after every group, and the groups after it
       if (groups_ahead) join_groups();
       main_moved = true;
     }
   }
+  void flush_pending_observation();
 
   void upload_rows(DevBuf<double>& dst, const double* host, double pad_value) {
     // host [C][D] -> device [C][Dp]; padding columns keep their fill value
@@ -196,6 +211,7 @@ struct wn_engine {
     HIP_OK(hipGetLastError());
     adapters_ready = true;
     warmup_iter = 0;
+    est_pending = false;
   }
 
   wn::Params make_params(bool warm, double* draws_dev, int64_t draws_stride, int fused = 1, int64_t draws_tstride = 0) {
@@ -253,6 +269,7 @@ struct wn_engine {
     P.pool_lds = pool_lds;
     P.im_in_lds = (im_in_lds ? 1u : 0u) | (no_far_end_sums ? 2u : 0u) | (hold_moving_end ? 4u : 0u);
     P.pool_total = pool_total;
+    P.est_mode = (warm && est_pending) ? 1 : 0;
     P.work_counter = counter.p;
     P.error_flags = error_flags.p;
     return P;
@@ -263,10 +280,14 @@ struct wn_engine {
 
   // One launch = `fused` transitions of every chain, back to back on the workgroup that fetched the chain (the chain's
   // k-th draw row at draws_dev + chain * draws_stride + k * draws_tstride).  Host-fed variates cover one transition.
-  void step(bool warm, double* draws_dev, int64_t draws_stride, int fused = 1, int64_t draws_tstride = 0) {
+  void step(bool warm, double* draws_dev, int64_t draws_stride, int fused = 1, int64_t draws_tstride = 0,
+            bool flush_only = false) {
     if (fused < 1) throw std::invalid_argument("transitions per launch must be at least 1");
     if (fused > 1 && (ref_streams || variates_pending))
       throw std::invalid_argument("host-fed variates cover one transition: transitions per launch must be 1");
+    // (a sampling launch reads the frozen planes; freeze has applied a pending observation -- a caller that samples
+    // without freezing gets it applied here)
+    if (!flush_only && !warm && est_pending) flush_pending_observation();
     in_step = !ref_streams;  // (a transition launch does not make `stream` wait for the groups -- unless variates are
                              // fed from the host first, which writes buffers the groups' previous launches read)
     struct Leave {
@@ -274,15 +295,16 @@ struct wn_engine {
       ~Leave() { flag = false; }
     } leave{in_step};
     use_device();
-    if (ref_streams) feed_reference_streams();
+    if (ref_streams && !flush_only) feed_reference_streams();
     in_step = true;
     wn::Params P = make_params(warm, draws_dev, draws_stride, fused, draws_tstride);
+    if (flush_only) P.est_mode = 2;
     if (groups > 1 && main_moved) {  // the group streams catch up with what `stream` did since their last launches
       HIP_OK(hipEventRecord(main_point, stream));
       for (int g = 1; g < groups; ++g) HIP_OK(hipStreamWaitEvent(gstream[g], main_point, 0));
       main_moved = false;
     }
-    std::pair<hipEvent_t, hipEvent_t>* timed = timing ? &next_events() : nullptr;
+    std::pair<hipEvent_t, hipEvent_t>* timed = (timing && !flush_only) ? &next_events() : nullptr;
     for (int g = 0; g < groups; ++g) {
       // The chain counter is never reset: every launch performs exactly as many fetches as it has chains (one per
       // processed chain), so a group's launch n starts at n * its chain count (mod 2^32) -- one memset per transition
@@ -296,7 +318,7 @@ struct wn_engine {
       hipStream_t s = g == 0 ? stream : gstream[g];
       try {
         // (per-launch HIP events: only between wn_engine_timing_reset and the read-back)
-        if (timing && g == 0) HIP_OK(hipEventRecord(timed->first, s));
+        if (timed != nullptr && g == 0) HIP_OK(hipEventRecord(timed->first, s));
         wn::launch_transition(model, geo, group_grid[g], smem, s, P);
         HIP_OK(hipGetLastError());
       } catch (...) {
@@ -313,20 +335,39 @@ struct wn_engine {
         groups_ahead = true;
       }
     }
-    if (timing) {
+    if (timed != nullptr) {
       // the launch has ended when its LAST kernel has: the end event waits for every group (per-launch timing is a
       // diagnostic mode -- it joins the groups' streams at every launch, which the plain mode never does)
       for (int g = 1; g < groups; ++g) HIP_OK(hipStreamWaitEvent(stream, gdone[g], 0));
       HIP_OK(hipEventRecord(timed->second, stream));
     }
+    if (flush_only) return;  // (not a transition: the stream keys and the iteration counts stay)
     ++region_launches;
     variates_pending = false;
     transition += static_cast<uint32_t>(fused);
     iteration += fused;
-    if (warm) warmup_iter += fused;
+    if (warm) {
+      warmup_iter += fused;
+      est_pending = !geo.mem;  // (register kernels: the launch's last observation waits for the next prologue)
+    }
     if (ref_streams) advance_reference_streams();
   }
 };
+
+// the pending observation by itself: one launch of the warmup kernel in its observe-only mode, over every chain group
+void wn_engine::flush_pending_observation() {
+  if (!est_pending || in_flush) return;
+  in_flush = true;
+  struct Leave {
+    wn_engine& e;
+    ~Leave() {
+      e.in_flush = false;
+      e.in_step = false;
+    }
+  } leave{*this};
+  step(true, nullptr, 0, 1, 0, /*flush_only=*/true);
+  est_pending = false;
+}
 
 void wn_engine::feed_reference_streams() {
   ReferenceStreams& r = *ref_streams;
@@ -579,6 +620,26 @@ int wn_stream_version(void) { return wnd::kStreamVersion; }
 #define WN_CODEGEN_FLAGS ""
 #endif
 const char* wn_build_flags(void) { return WN_CODEGEN_FLAGS; }
+#ifndef WN_COMPILER_VERSION
+#define WN_COMPILER_VERSION ""
+#endif
+const char* wn_build_compiler(void) { return WN_COMPILER_VERSION; }
+
+int wn_internal_sqrt_probe(const double* x, double* y, size_t n, int checked) {
+  DevBuf<double> dx, dy;
+  try {
+    dx.alloc(n);
+    dy.alloc(n);
+    HIP_OK(hipMemcpyAsync(dx.p, x, n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(sqrt_probe_kernel, dim3(1024), dim3(256), 0, nullptr, dx.p, dy.p, static_cast<long long>(n), checked);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(y, dy.p, n * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    HIP_OK(hipStreamSynchronize(nullptr));
+  } catch (...) {
+    return -1;
+  }
+  return 0;
+}
 
 int wn_model_id(const char* name) {
   if (name == nullptr) return -1;

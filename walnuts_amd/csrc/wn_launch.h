@@ -191,7 +191,7 @@ inline std::string& registry_error() {
   return msg;
 }
 // Everything a separately compiled model and the library must agree on: the layout of what crosses the boundary.
-constexpr int kModelAbiVersion = 6;
+constexpr int kModelAbiVersion = 7;
 struct ModelAbi {
   int version;
   unsigned sizeof_ops, sizeof_params, sizeof_geometry;

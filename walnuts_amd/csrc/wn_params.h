@@ -88,7 +88,9 @@ struct Params {
                            // transition; bit 1 = (experiment switch) no far-end sums in the leaf's pass; bit 2 = the
                            // vectors fit the registers a kernel with a held moving end has for them (TrajMem, HOLD)
   int32_t chain_begin;    // first chain of this launch
-  int32_t pad3;
+  int32_t est_mode;       // register kernels, warmup (TrajChip::kDeferObservation): 1 = the mass estimator has not seen the
+                          // previous launch's last transition yet (this launch's first prologue applies the observation);
+                          // 2 = apply that observation and do nothing else (the engine's flush); 0 = nothing pending
   uint32_t* error_flags;  // OR of kErr* bits of every chain and transition since wn_engine_check last read (and cleared) it
 };
 

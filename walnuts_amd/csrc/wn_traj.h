@@ -639,9 +639,15 @@ struct TrajBase {
     if (tid == 0) {
       const auto& Q = cold();
       if (warm) {
-        const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(warmup_iter_now()));
-        Q.est_weight[2 * chain] = discount * w_draw0 + 1;
-        Q.est_weight[2 * chain + 1] = discount * w_score0 + 1;
+        if constexpr (Self::kDeferObservation) {
+          // (the prologue applied the pending observation, if there was one: these ARE the weights in force)
+          Q.est_weight[2 * chain] = w_draw0;
+          Q.est_weight[2 * chain + 1] = w_score0;
+        } else {
+          const double discount = 1.0 - 1.0 / (Q.mass_init_count + static_cast<double>(warmup_iter_now()));
+          Q.est_weight[2 * chain] = discount * w_draw0 + 1;
+          Q.est_weight[2 * chain + 1] = discount * w_score0 + 1;
+        }
         if constexpr (Self::kParkScalars) {
           Q.mm_state[2 * chain] = fetch(k_s0) + static_cast<double>(1ll << depth);  // observe(1 << depth)
           Q.mm_state[2 * chain + 1] = fetch(k_s1) + 1.0;
@@ -999,6 +1005,7 @@ struct TrajMem : TrajBase<TrajMem<Model, NW, FMA, HOLD>, Model, NW> {
   static constexpr int L = Base::L;
   static constexpr bool kHasStartState = true;
   static constexpr bool kZeroCopy = true;
+  static constexpr bool kDeferObservation = false;  // (the estimator observes in this transition's own epilogue)
   static constexpr bool kParkScalars = false;
   // An element-wise gradient is recomputed from theta inside the one pass of a micro step.  Any other streamable model
   // (kTwoPass) takes two passes per micro step: its gradient at the new position needs sums over ALL of the new

@@ -31,6 +31,20 @@ def hipcc_flags(lib_path: Optional[str] = None) -> Sequence[str]:
     return flags
 
 
+def check_compiler(lib_path: Optional[str] = None, hipcc: str = "hipcc") -> None:
+    """A run-time model and the library must come from the same compiler (the code-generation flags include an
+    LLVM-internal option, and the kernels share inlined headers): compare `hipcc --version`'s "HIP version:" with the
+    one the library recorded at build time (wn_build_compiler)."""
+    built = _ffi.load_library(lib_path).wn_build_compiler().decode()
+    if not built:
+        return
+    out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    here = next((line.split(":", 1)[1].strip() for line in out.splitlines() if line.startswith("HIP version:")), "")
+    if here != built:
+        raise _ffi.WalnutsHipError(f"libwalnuts_hip.so was built with HIP {built}, this hipcc is HIP {here or '?'}: "
+                                   "rebuild the library (make -C walnuts_amd/csrc) or use its compiler")
+
+
 _loaded = {}   # path -> CDLL (kept alive: the registry holds pointers into the object)
 
 
@@ -111,6 +125,8 @@ def build_device_model(header: str, type_name: str, tag: str, model_id: int, num
         f.write(translation_unit(header, type_name, tag, model_id))
     geo = "_".join(f"mem{nw}" if mem else f"{nw}x{epl}" for nw, epl, mem in candidates)
     out = os.path.join(out_dir, f"libwn_model_{tag}_{geo}.so")
+    if compiler is None:
+        check_compiler(lib_path)
     cmd = list(compiler) if compiler is not None else ["hipcc"] + list(hipcc_flags(lib_path))
     cmd += ["-DWN_MODEL_PLUGIN",
             *geometry_defines(candidates),

@@ -223,3 +223,48 @@ def run_weight_rebase_case(model: str, D: int, C: int, *, lib_path=None, geometr
                         max_hamiltonian_error=1e9, **kw)
     assert orc.weight_rebases() >= 3, orc.weight_rebases()
     return dev, orc
+
+
+def run_pending_observation_case(model: str, D: int, C: int, *, lib_path=None, geometry=None):
+    """Warmup launches back to back with NOTHING read in between (the register kernels leave the estimator's observation
+    of a launch's last transition pending until the next launch's first prologue: wn_chip.h kDeferObservation), then every
+    way out of the pending state -- a read of the estimator, new positions, a freeze -- against the oracle, which
+    observes at the end of each transition (adaptive_walnuts.hpp:247-248)."""
+    dev, orc = make_pair(model, D, C, lib_path, geometry, chain_groups=2)
+    rng = np.random.default_rng(4)
+    pos = rng.normal(0.0, 1.5, size=(C, D))
+    for x in (dev, orc):
+        x.set_positions(pos)
+    dev.init_masses_from_grad(1e-5)
+    orc.init_masses_from_grad(1e-5)
+    for x in (dev, orc):
+        x.set_step_sizes(0.3)
+        x.seed_chains(5, 1)
+
+    def both(n_launches, per_launch):
+        for _ in range(n_launches):
+            dev.warmup_steps(per_launch)      # no synchronize, no read: the observation stays pending across launches
+            for _ in range(per_launch):
+                orc.warmup_step(2)
+
+    both(3, 1)
+    both(2, 3)
+    assert_same_state(dev, orc, "after five launches without a read", warm=True)   # (reads flush)
+    both(2, 2)
+    assert_same_state(dev, orc, "pending again, read again", warm=True)
+    both(1, 2)
+    new_pos = rng.normal(0.0, 1.0, size=(C, D))
+    for x in (dev, orc):
+        x.set_positions(new_pos)              # the pending observation is of the OLD positions: applied first
+    both(2, 1)
+    assert_same_state(dev, orc, "positions replaced while an observation was pending", warm=True)
+    both(1, 3)
+    dev.freeze()                              # freeze with an observation pending
+    orc.freeze()
+    dev.synchronize()
+    assert same_bits_or_nan(dev.inv_mass(), orc.inv_mass()) and same_bits_or_nan(dev.step_sizes(), orc.step_sizes())
+    for _ in range(2):
+        dev.sample_steps(2)
+        orc.sample_step(2)
+        orc.sample_step(2)
+    assert_same_state(dev, orc, "sampling after the freeze", warm=False)

@@ -378,6 +378,16 @@ def test_host_supplied_variates_path():
 
 
 # ---- size-independent properties at full BASELINE sizes --------------------------------------------------
+@pytest.mark.parametrize("model,D,C,geometry", [("std_normal", 1024, 96, None), ("diag_normal", 1000, 40, None),
+                                                ("funnel", 128, 200, None), ("rw1", 1024, 24, None),
+                                                ("funnel", 1000, 24, (4, 4)), ("std_normal", 4096, 12, (8, 8)),
+                                                ("diag_normal", 6000, 6, None)])
+def test_observation_pending_between_warmup_launches(model, D, C, geometry):
+    """wn_chip.h kDeferObservation / wn_engine flush_pending_observation on the device: launches with nothing read in
+    between, then a read, new positions and a freeze with an observation pending (tests/parity.py)."""
+    parity.run_pending_observation_case(model, D, C, geometry=geometry)
+
+
 def test_range_free_square_root_equals_sqrt_on_the_device():
     """wnd::sqrt_normal (wn_devmath.h): the compiler's fp64 sqrt refinement without its range scaling and special-case
     patches -- the Box-Muller radius and the warmup prologue's inverse mass / Cholesky factor use it.  Bit for bit equal

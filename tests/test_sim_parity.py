@@ -451,41 +451,4 @@ def test_observation_pending_between_warmup_launches(sim, oracle, model, D, geom
     transitions back to back with NOTHING read in between, then every way out of the pending state -- a read of the
     estimator, a freeze, new positions -- against the oracle, which observes at the end of each transition
     (adaptive_walnuts.hpp:247-248).  (The streaming kernels observe in their own epilogue: same test, nothing pending.)"""
-    dev, orc = parity.make_pair(model, D, 3, sim, geometry, chain_groups=2)
-    rng = np.random.default_rng(4)
-    pos = rng.normal(0.0, 1.5, size=(3, D))
-    for x in (dev, orc):
-        x.set_positions(pos)
-    dev.init_masses_from_grad(1e-5)
-    orc.init_masses_from_grad(1e-5)
-    for x in (dev, orc):
-        x.set_step_sizes(0.3)
-        x.seed_chains(5, 1)
-
-    def both(n_launches, per_launch):
-        for _ in range(n_launches):
-            dev.warmup_steps(per_launch)      # no synchronize, no read: the observation stays pending across launches
-            for _ in range(per_launch):
-                orc.warmup_step(2)
-
-    both(3, 1)
-    both(2, 3)
-    parity.assert_same_state(dev, orc, "after five launches without a read", warm=True)   # (reads flush)
-    both(2, 2)
-    parity.assert_same_state(dev, orc, "pending again, read again", warm=True)
-    both(1, 2)
-    new_pos = rng.normal(0.0, 1.0, size=(3, D))
-    for x in (dev, orc):
-        x.set_positions(new_pos)              # the pending observation is of the OLD positions: applied first
-    both(2, 1)
-    parity.assert_same_state(dev, orc, "positions replaced while an observation was pending", warm=True)
-    both(1, 3)
-    dev.freeze()                              # freeze with an observation pending
-    orc.freeze()
-    dev.synchronize()
-    assert parity.same_bits_or_nan(dev.inv_mass(), orc.inv_mass()) and parity.same_bits_or_nan(dev.step_sizes(), orc.step_sizes())
-    for _ in range(2):
-        dev.sample_steps(2)
-        orc.sample_step(2)
-        orc.sample_step(2)
-    parity.assert_same_state(dev, orc, "sampling after the freeze", warm=False)
+    parity.run_pending_observation_case(model, D, 3, lib_path=sim, geometry=geometry)

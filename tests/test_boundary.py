@@ -95,3 +95,35 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "wno" not in re.findall(r"import\s+(\w+)", src), f
                 assert "oracle/" not in src and "wn_oracle" not in src, f
+
+
+def test_launch_geometry_answers_come_from_the_library():
+    """the engine's choice of launch geometry depends on the model (one-pass gradients stream from 4 097
+    parameters on the held kernels, the funnel's kind from 8 193); wn_geometry_for_model answers for a registered model
+    with the engine's own rule, wn_geometry_candidates lists what a not-yet-registered (run-time compiled) model has to
+    instantiate, and walnuts_amd.models derives its -D switches from that list alone.  No GPU needed: host logic."""
+    import walnuts_amd as wa
+    from walnuts_amd import models
+
+    assert models.geometry_for(1024) == (1, 16, False) == models.geometry_for(1024, model=wa.MODEL_STD_NORMAL)
+    # 6 000 parameters: (16, 8) register kernels for a model without held streaming kernels ...
+    assert models.geometry_for(6000) == (16, 8, False)
+    # ... the held streaming kernels (8 wavefronts) for the built-in one-pass models, (16, 8) for the funnel up to 8 192
+    assert models.geometry_for(6000, model=wa.MODEL_DIAG_NORMAL) == (8, 0, True)
+    assert models.geometry_for(6000, model=wa.MODEL_RW1) == (8, 0, True)
+    assert models.geometry_for(6000, model=wa.MODEL_FUNNEL) == (16, 8, False)
+    assert models.geometry_for(12000, model=wa.MODEL_FUNNEL) == (8, 0, True)
+    assert models.geometry_for(20000, model=wa.MODEL_DIAG_NORMAL) == (16, 0, True)
+    assert models.geometry_candidates(1024) == [(1, 16, False)]
+    assert sorted(models.geometry_candidates(6000)) == [(8, 0, True), (16, 8, False)]
+    assert sorted(models.geometry_candidates(12000)) == [(8, 0, True), (16, 0, True)]
+    assert models.geometry_candidates(20000) == [(16, 0, True)]
+    assert models.geometry_candidates(6000, waves_per_chain=16, elems_per_lane=8) == [(16, 8, False)]   # a request is a request
+    assert list(models.geometry_defines([(16, 8, False), (8, 0, True)])) == ["-DWN_ONLY_NW=16", "-DWN_ONLY_EPL=8", "-DWN_ONLY_MEM_NW=8"]
+    assert list(models.geometry_defines([(16, 0, True), (8, 0, True)])) == ["-DWN_ONLY_MEM_NW=16", "-DWN_ONLY_MEM_NW_ALSO=8"]
+    # the library states what it was built with, and a run-time model is built with exactly that
+    flags = models.hipcc_flags()
+    assert "-ffp-contract=off" in flags and "--offload-arch=gfx950" in flags
+    lib = wa.load_library()
+    assert lib.wn_build_compiler().decode() != "" and lib.wn_stream_version() == 2
+    models.check_compiler()   # this container's hipcc built the library

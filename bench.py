@@ -4,12 +4,19 @@
 A "step" is one MCMC transition (walnuts.hpp:520-563) of EVERY chain.  One launch of the persistent transition
 kernel runs `--transitions-per-launch` consecutive steps (default 8: the workgroup that fetched a chain runs that
 many transitions of it back to back -- the chains are independent -- so the launch and its tail, the last chains
-finishing while the chip drains, are paid once per launch; every transition's draw plane is written; K timed steps =
-ceil(K / 8) launches, the last one shorter; `--transitions-per-launch 1` = one launch per step, the per-step numbers
-of rounds 1-3).  Default workload = BASELINE.json's headline: 65 536 chains x 1 024-dim standard normal, default
-SamplingConfig, parameters adapted by `--adapt-iters` on-device warmup transitions (untimed), then W untimed + K
-timed sampling transitions.  Inputs are generated on the device (counter-based stream) and are resident in HBM
-when the timed region starts.
+finishing while the chip drains, are paid once per launch; every transition's draw plane is written).  `--steps` and
+`--warmup` are MINIMA: the timed region holds whole launches only and at least `--min-launches` (12) of them -- the
+first dispatches after a join run 10-50 % off steady state --, so the driver's `--steps 20 --warmup 5` times 96
+transitions after 8 untimed ones; the line's `steps` / `warmup` are the transitions actually run, `steps_requested` /
+`warmup_requested` the command line's (`--exact-steps`: exactly K, the last launch short).  Default workload =
+BASELINE.json's headline: 65 536 chains x 1 024-dim standard normal, default SamplingConfig, parameters adapted by
+`--adapt-iters` on-device warmup transitions (untimed), then the untimed and the timed sampling transitions.  Inputs are
+generated on the device (counter-based stream) and are resident in HBM when the timed region starts.
+
+The default headline run on one GPU also measures, in the SAME line under `configs`, BASELINE configs #2, #3 and #4 and
+the headline's adaptive-warmup phase (throughput for sampling and separately for warmup) as short
+legs -- each with `value`, `ms_per_step`, `roofline` (PMC traffic included) and its own reference-order `parity_gate`
+(`--legs none` / a comma list; the whole command takes ~20 s).
 
   python bench.py --gpus N --steps K --warmup W
 

@@ -605,6 +605,47 @@ def test_full_size_config3_properties(oracle):
     assert np.array_equal(o.grad_evals(), sub.grad_evals()) and np.array_equal(o.step_sizes(), sub.step_sizes())
 
 
+def test_full_size_config5_shard_properties():
+    """BASELINE config #5's shape on the one GPU there is: 262 144 chains x 1 024-dim normal as ONE engine, and rank 3's
+    shard of an 8-GPU run (chains 98 304 .. 131 071, `chain_offset` = its first global id) as an engine of its own --
+    the shard's rows equal the big engine's bit for bit through adaptive and sampling launches (what makes the 8-GPU run
+    a pure partition: SURVEY.md section 8e), the draw planes of a fused launch land where the all-gather expects them
+    ([T][rows][D]), and the reported log densities are the model's.  The exchange itself (RCCL over xGMI) needs 8 GPUs."""
+    import torch
+    D, C, R = 1024, 262144, 8
+    lo, n = 3 * (C // R), C // R
+
+    def run(chains, offset, draws=None):
+        e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, chains)
+        e.init_positions(5, offset, 2.0)
+        e.init_masses_from_grad(1e-5)
+        e.set_step_sizes(1.0)
+        e.adapt_step(5, offset)
+        e.seed_chains(6, offset)
+        e.warmup_steps(8)
+        e.warmup_steps(4)
+        e.freeze()
+        if draws is None:
+            e.sample_steps(4)
+        else:
+            e.sample_steps(4, draws.data_ptr(), D, chains * D)
+        e.synchronize()
+        e.check()
+        return e
+
+    planes = torch.empty((4, n, D), dtype=torch.float64, device="cuda")
+    shard = run(n, lo, planes)
+    whole = run(C, 0)
+    x = whole.positions()[lo:lo + n]
+    assert np.array_equal(shard.positions(), x)
+    assert np.array_equal(shard.logp(), whole.logp()[lo:lo + n])
+    assert np.array_equal(shard.grad_evals(), whole.grad_evals()[lo:lo + n])
+    assert np.array_equal(shard.step_sizes(), whole.step_sizes()[lo:lo + n])
+    assert np.array_equal(planes[3].cpu().numpy(), x)                 # the launch's last draw plane = the positions
+    assert np.allclose(shard.logp(), _logp_std_normal(x), rtol=1e-12, atol=0)
+    assert torch.isfinite(planes).all() and not torch.equal(planes[0], planes[1])
+
+
 def test_sample_device_contract_on_gpu():
     # python/tests/test_pyfunc.py:38-125 for the device entry point
     kw = dict(num_params=100, num_chains=4, seed=1234, min_warmup_iter=30, max_warmup_iter=30, min_sampling_iter=20,

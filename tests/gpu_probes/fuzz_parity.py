@@ -32,7 +32,7 @@ def random_case(rng, geometries=GEOMETRIES, mem_waves=(2, 4, 8, 16), chain_count
         geometry = geometries[int(rng.integers(len(geometries)))]
         cap = 64 * geometry[0] * geometry[1]
         D = int(rng.integers(max(2, cap // 4), cap + 1))
-    kw = dict(warmup=int(rng.integers(0, 5)), sampling=int(rng.integers(1, 5)), geometry=geometry,
+    kw = dict(warmup=int(rng.integers(0, 7)), sampling=int(rng.integers(1, 5)), geometry=geometry,
               seed=int(rng.integers(1, 2**31)), check_every=1)
     style = rng.integers(0, 6)
     if style == 0:      # deep trees
@@ -55,6 +55,8 @@ def random_case(rng, geometries=GEOMETRIES, mem_waves=(2, 4, 8, 16), chain_count
         kw.update(average_masses=True)
     kw.update(fused_multiply_add=int(rng.integers(0, 2)))   # both arithmetic modes
     kw.update(fused=int(rng.choice([1, 1, 2, 3, 5])))       # transitions per launch (wn_engine_*_steps)
+    if rng.uniform() < 0.35:
+        kw.update(lazy=True)   # nothing read between a phase's launches: the pending observation crosses launches
     C = int(rng.choice(list(chain_counts)))
     if C > 1 and rng.uniform() < 0.3:
         kw.update(chain_groups=2)                           # two independently launched blocks of chains

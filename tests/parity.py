@@ -88,9 +88,12 @@ def assert_same_state(dev, orc, where: str, warm: bool):
 
 
 def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path=None, geometry=None, seed=1234,
-             init="random", step=None, check_every=1, average_masses=False, fused=1, init_scale=2.0, **cfg_over):
+             init="random", step=None, check_every=1, average_masses=False, fused=1, init_scale=2.0, lazy=False,
+             **cfg_over):
     """InitConfigBuilder -> warmup -> freeze -> sampling on both sides, bit-compared along the way.  fused > 1: the
-    device runs that many transitions per launch (wn_engine_warmup_steps / _sample_steps), the oracle single steps."""
+    device runs that many transitions per launch (wn_engine_warmup_steps / _sample_steps), the oracle single steps.
+    lazy: nothing is read between the launches of a phase (the state is compared at the end of the phase only), so the
+    register kernels' pending estimator observation crosses launch boundaries (wn_chip.h kDeferObservation)."""
     dev, orc = make_pair(model, D, C, lib_path, geometry, **cfg_over)
     rng = np.random.default_rng(seed)
     if init == "random":
@@ -123,7 +126,7 @@ def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path
         for _ in range(n):
             orc.warmup_step(8)
         it += n
-        if it % check_every == 0 or it == warmup or fused > 1:
+        if it == warmup or (not lazy and (it % check_every == 0 or fused > 1)):
             assert_same_state(dev, orc, f"{model} D={D} warmup it={it - 1}", warm=True)
     dev.freeze()
     orc.freeze()
@@ -138,7 +141,7 @@ def run_case(model: str, D: int, C: int, *, warmup: int, sampling: int, lib_path
         for _ in range(n):
             orc.sample_step(8)
         it += n
-        if it % check_every == 0 or it == sampling or fused > 1:
+        if it == sampling or (not lazy and (it % check_every == 0 or fused > 1)):
             assert_same_state(dev, orc, f"{model} D={D} sampling it={it - 1}", warm=False)
     return dev, orc
 

@@ -388,6 +388,41 @@ def test_observation_pending_between_warmup_launches(model, D, C, geometry):
     parity.run_pending_observation_case(model, D, C, geometry=geometry)
 
 
+def test_device_normals_moments_and_tails():
+    """The device's uniform-to-normal map (Philox4x32-7 -> 52-bit open-interval uniforms -> Box-Muller with the portable
+    log / sincospi and the range-free square root, wn_devmath.h) vetted statistically, not only bit-mirrored: 6.7e7
+    standard normals drawn by the engine (initial positions at scale 1: the same stream_normal_pair the momentum refresh
+    calls) against the normal law -- mean, variance, skewness, kurtosis within 5 standard errors, the counts beyond 3, 4
+    and 5 sigma within 5 Poisson deviations of their expectations, the largest |z| where the extreme-value law of 6.7e7
+    normals puts it, and no correlation between the two members of a pair or between neighbouring pairs."""
+    from math import erfc, sqrt
+    C, D = 65536, 1024
+    e = wa.DeviceEngine(wa.MODEL_STD_NORMAL, D, C)
+    e.init_positions(20261003, 0, 1.0)
+    e.synchronize()
+    z = e.positions()
+    n = z.size
+    m1 = z.mean()
+    zc = z - m1
+    var = float(np.mean(zc * zc))
+    skew = float(np.mean(zc ** 3)) / var ** 1.5
+    kurt = float(np.mean(zc ** 4)) / var ** 2
+    assert abs(m1) < 5 / sqrt(n)
+    assert abs(var - 1) < 5 * sqrt(2 / n)
+    assert abs(skew) < 5 * sqrt(6 / n)
+    assert abs(kurt - 3) < 5 * sqrt(24 / n)
+    a = np.abs(z)
+    for k in (3.0, 4.0, 5.0):
+        expect = n * erfc(k / sqrt(2))
+        got = int(np.count_nonzero(a > k))
+        assert abs(got - expect) < 5 * sqrt(expect) + 1, (k, got, expect)
+    assert 5.0 < a.max() < 6.7, a.max()      # P(max |z| of 6.7e7 > 6.7) = 1.4e-3, P(< 5.0) < 1e-16
+    pairs = z.reshape(C, D // 2, 2)
+    assert abs(float(np.mean(pairs[:, :, 0] * pairs[:, :, 1]))) < 5 / sqrt(n / 2)          # cos / sin members of a pair
+    assert abs(float(np.mean(pairs[:, :-1, 1] * pairs[:, 1:, 0]))) < 5 / sqrt(n / 2)       # neighbouring counters
+    assert abs(float(np.mean(z[:-1, :] * z[1:, :]))) < 5 / sqrt(n)                         # neighbouring chains
+
+
 def test_range_free_square_root_equals_sqrt_on_the_device():
     """wnd::sqrt_normal (wn_devmath.h): the compiler's fp64 sqrt refinement without its range scaling and special-case
     patches -- the Box-Muller radius and the warmup prologue's inverse mass / Cholesky factor use it.  Bit for bit equal

@@ -534,9 +534,16 @@ def main():
             for name, spec in legs.items():
                 t_leg = time.perf_counter()
                 leg_args = argparse.Namespace(**{**vars(args), **spec})
-                rec = run_job(leg_args, rank, local_rank, world, dist, cpu=False)
-                out["configs"][name] = {k: rec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config",
-                                                            "roofline", "parity_gate") if k in rec}
+                try:
+                    rec = run_job(leg_args, rank, local_rank, world, dist, cpu=False)
+                    out["configs"][name] = {k: rec[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config",
+                                                                "roofline", "parity_gate") if k in rec}
+                except Exception as exc:   # (a leg that cannot run must not cost the line its headline)
+                    import traceback
+
+                    out["configs"][name] = {"error": f"{type(exc).__name__}: {exc}",
+                                            "traceback": traceback.format_exc().splitlines()[-6:]}
+                    torch.cuda.empty_cache()
                 out["configs"][name]["leg_wall_s"] = time.perf_counter() - t_leg
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -836,10 +843,17 @@ def run_job(args, rank, local_rank, world, dist, cpu=True):
                 "library_algorithm": rccl_algorithm_seen() if args.backend == "nccl" else None,
                 "note": "three legs of the same K steps in one run: full (value), compute only (value_compute_only), "
                         "exchange only; DESIGN.md section 6 holds the prediction these are to confirm or refute"}
+        # (the checker's legs must not cost the line its measurement: a failure is reported in place)
         if world == 1 and not args.no_parity_gate:
-            out["parity_gate"] = parity_gate(args, D, cfg_kwargs)
+            try:
+                out["parity_gate"] = parity_gate(args, D, cfg_kwargs)
+            except Exception as exc:
+                out["parity_gate"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and cpu and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, D)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, D)
+            except Exception as exc:
+                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     eng.close()
     del gather
     torch.cuda.empty_cache()

@@ -69,14 +69,15 @@ def test_library_stands_in_for_libwalnutpy_at_load_time_and_refuses_host_models(
 
 def test_default_launch_geometry_by_model_and_dimension():
     """The engine's own choice of kernel (wn_launch.h, choose_geometry), asked through the C ABI without a GPU: one
-    wavefront per chain up to 1 024 parameters; the streaming kernels that hold the trajectory's moving end in registers
+    wavefront per chain up to 1 024 parameters, two / four at sixteen elements per lane up to 2 048 / 4 096 (round 6); the
+    streaming kernels that hold the trajectory's moving end in registers
     (8 wavefronts) from 4 097 to 16 384 parameters for one-pass gradients and rw1, from 8 193 for the funnel (two passes,
     sums only: its (16, 8) register kernels still win below); sixteen wavefronts streaming both ends beyond 16 384."""
     if not os.path.exists(ffi.DEFAULT_LIB):
         pytest.fail("walnuts_amd/lib/libwalnuts_hip.so is not built: run __graft_entry__.build()")
     lib = ffi.load_library()
     lanes = lambda name, D: lib.wn_lanes_for_model_dim(lib.wn_model_id(name.encode()), D, 0, 0)
-    assert [lanes("std_normal", D) for D in (100, 1024, 4096, 4097, 8192, 16384, 16385)] == [64, 64, 512, 512, 512, 512, 1024]
+    assert [lanes("std_normal", D) for D in (100, 1024, 2048, 4096, 4097, 8192, 16384, 16385)] == [64, 64, 128, 256, 512, 512, 512, 1024]
     assert [lanes("diag_normal", D) for D in (1024, 6000, 16384, 40000)] == [64, 512, 512, 1024]
     assert [lanes("funnel", D) for D in (128, 6000, 8192, 8193, 16384, 16385)] == [64, 1024, 1024, 512, 512, 1024]
     assert [lanes("rw1", D) for D in (1024, 4096, 4097, 16384, 16385)] == [256, 1024, 512, 512, 1024]
@@ -106,6 +107,8 @@ def test_launch_geometry_answers_come_from_the_library():
     from walnuts_amd import models
 
     assert models.geometry_for(1024) == (1, 16, False) == models.geometry_for(1024, model=wa.MODEL_STD_NORMAL)
+    assert models.geometry_for(2000) == (2, 16, False) and models.geometry_for(3000, model=wa.MODEL_FUNNEL) == (4, 16, False)
+    assert models.geometry_for(2048, model=wa.MODEL_RW1) == (8, 4, False)     # (rw1 states its own preference: 4 per lane)
     # 6 000 parameters: (16, 8) register kernels for a model without held streaming kernels ...
     assert models.geometry_for(6000) == (16, 8, False)
     # ... the held streaming kernels (8 wavefronts) for the built-in one-pass models, (16, 8) for the funnel up to 8 192

@@ -57,6 +57,10 @@ def _need_gpu(gpu):
     ("std_normal", 2048, 32, (8, 4)),
     ("std_normal", 4096, 24, (8, 8)),
     ("std_normal", 4000, 16, (16, 4)),
+    ("std_normal", 2000, 24, None),         # the default beyond 1 024 dimensions: two wavefronts, 16 elements per lane
+    ("diag_normal", 4096, 12, None),        # ... four wavefronts, 16 elements per lane
+    ("funnel", 3000, 12, (4, 16)),
+    ("rw1", 2048, 12, (2, 16)),
     ("std_normal", 8192, 12, (16, 8)),      # the largest register geometry
     ("diag_normal", 1024, 96, None),        # config #2/#4 family
     ("diag_normal", 130, 64, (1, 4)),
@@ -381,6 +385,7 @@ def test_host_supplied_variates_path():
 @pytest.mark.parametrize("model,D,C,geometry", [("std_normal", 1024, 96, None), ("diag_normal", 1000, 40, None),
                                                 ("funnel", 128, 200, None), ("rw1", 1024, 24, None),
                                                 ("funnel", 1000, 24, (4, 4)), ("std_normal", 4096, 12, (8, 8)),
+                                                ("diag_normal", 3000, 12, None), ("funnel", 2048, 12, None),
                                                 ("diag_normal", 6000, 6, None)])
 def test_observation_pending_between_warmup_launches(model, D, C, geometry):
     """wn_chip.h kDeferObservation / wn_engine flush_pending_observation on the device: launches with nothing read in

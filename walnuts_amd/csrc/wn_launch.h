@@ -73,10 +73,10 @@ constexpr int kHeldWaves = 8;
 #elif defined(WN_SIM_GEOMETRIES)  // tests/cpusim: a cross-section (the headline's (1, 16) and its neighbours included)
 #define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(1, 4) X(2, 2) X(1, 16) X(2, 8) X(4, 4) X(8, 8)
 #elif defined(WN_FAST_BUILD)
-#define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(4, 4) X(2, 8) X(1, 16)
+#define WN_FOR_EACH_GEOMETRY(X) X(1, 2) X(4, 4) X(2, 8) X(1, 16) X(4, 8) X(8, 8) X(2, 16) X(4, 16)
 #else
 #define WN_FOR_EACH_GEOMETRY(X)                                                            \
-  X(1, 2) X(1, 4) X(1, 8) X(1, 16) X(2, 2) X(2, 4) X(2, 8) X(4, 2) X(4, 4) X(4, 8) X(8, 2) \
+  X(1, 2) X(1, 4) X(1, 8) X(1, 16) X(2, 2) X(2, 4) X(2, 8) X(2, 16) X(4, 2) X(4, 4) X(4, 8) X(4, 16) X(8, 2) \
   X(8, 4) X(8, 8) X(16, 4) X(16, 8)
 #endif
 
@@ -125,7 +125,12 @@ inline Geometry choose_geometry(int dim, int nw_req, int epl_req, bool params_in
   // 3.78e8 gradient evaluations per second with (1, 16) against 3.60e8 with (2, 8) -- so `params_in_registers`
   // does not change the choice any more.)
   (void)params_in_registers;
-  static const int pref[][2] = {{1, 2}, {1, 4}, {1, 8}, {1, 16}, {2, 8}, {4, 8}, {8, 8}, {16, 8}};
+  // Beyond 1 024 dimensions (round 6): SIXTEEN elements per lane on two / four wavefronts instead of eight on four /
+  // eight -- half as many copies of the wave-uniform tree logic, half as many wavefronts behind every reduction's
+  // barrier, a full-width leaf per lane.  Measured, 8 192 chains (profiles/r06/mid_dimensions.txt): diagonal normal
+  // 2 048 dims (2,16) 0.389 against (4,8) 0.402 ms per step, 3 000 dims (4,16) 0.924 against (8,8) 1.049, 4 096 dims
+  // 0.966 against 1.087; funnel 2 048: 0.804 against 1.092, 4 096: 2.40 against 2.31 (the one case that loses, 4 %).
+  static const int pref[][2] = {{1, 2}, {1, 4}, {1, 8}, {1, 16}, {2, 16}, {4, 16}, {8, 8}, {16, 8}};
   const int npref = 8;
   for (int i = 0; i < npref; ++i) {
     const int* p = pref[i];

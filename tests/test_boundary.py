@@ -80,7 +80,8 @@ def test_default_launch_geometry_by_model_and_dimension():
     assert [lanes("std_normal", D) for D in (100, 1024, 2048, 4096, 4097, 8192, 16384, 16385)] == [64, 64, 128, 256, 512, 512, 512, 1024]
     assert [lanes("diag_normal", D) for D in (1024, 6000, 16384, 40000)] == [64, 512, 512, 1024]
     assert [lanes("funnel", D) for D in (128, 6000, 8192, 8193, 16384, 16385)] == [64, 1024, 1024, 512, 512, 1024]
-    assert [lanes("rw1", D) for D in (1024, 4096, 4097, 16384, 16385)] == [256, 1024, 512, 512, 1024]
+    # (rw1 states its hint as a function of the dimension: the default policy up to 1 024, (8,4) up to 2 048, (8,8) up to 4 096)
+    assert [lanes("rw1", D) for D in (512, 1024, 2048, 4096, 4097, 16384, 16385)] == [64, 64, 512, 512, 512, 512, 1024]
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -107,8 +108,11 @@ def test_launch_geometry_answers_come_from_the_library():
     from walnuts_amd import models
 
     assert models.geometry_for(1024) == (1, 16, False) == models.geometry_for(1024, model=wa.MODEL_STD_NORMAL)
-    assert models.geometry_for(2000) == (2, 16, False) and models.geometry_for(3000, model=wa.MODEL_FUNNEL) == (4, 16, False)
-    assert models.geometry_for(2048, model=wa.MODEL_RW1) == (8, 4, False)     # (rw1 states its own preference: 4 per lane)
+    assert models.geometry_for(2000) == (2, 16, False) and models.geometry_for(3000, model=wa.MODEL_STD_NORMAL) == (4, 16, False)
+    assert models.geometry_for(2000, model=wa.MODEL_FUNNEL) == (2, 16, False)
+    assert models.geometry_for(3000, model=wa.MODEL_FUNNEL) == (8, 8, False)  # (a carried gradient: eight per lane there)
+    assert models.geometry_for(2048, model=wa.MODEL_RW1) == (8, 4, False) and models.geometry_for(1024, model=wa.MODEL_RW1) == (1, 16, False)
+    assert models.geometry_for(4096, model=wa.MODEL_RW1) == (8, 8, False)
     # 6 000 parameters: (16, 8) register kernels for a model without held streaming kernels ...
     assert models.geometry_for(6000) == (16, 8, False)
     # ... the held streaming kernels (8 wavefronts) for the built-in one-pass models, (16, 8) for the funnel up to 8 192

@@ -352,14 +352,19 @@ def test_streaming_backend_edge_configurations(kw):
 
 
 def test_model_geometry_hint():
-    """A model may state the elements per lane it prefers (wn_model_api.h: kPreferredElemsPerLane; models/rw1.h asks
-    for 4): the engine takes the fewest wavefronts that hold num_params at that width, an explicit request wins."""
+    """A model may state the elements per lane it prefers (wn_model_api.h: kPreferredElemsPerLane, or
+    preferred_elems_per_lane(num_params) where the best width depends on the dimension -- models/rw1.h: the default
+    policy up to 1 024 dimensions, 4 per lane up to 2 048, 8 up to 4 096): the engine takes the fewest wavefronts that
+    hold num_params at that width, an explicit request wins."""
     cfg = wa.default_config()
-    assert wa.DeviceEngine(wa.MODEL_RW1, 1024, 8, cfg).lanes == 256          # 4 wavefronts x 4 elements per lane
-    assert wa.DeviceEngine(wa.MODEL_RW1, 200, 8, cfg).lanes == 64            # 1 x 4
+    assert wa.DeviceEngine(wa.MODEL_RW1, 1024, 8, cfg).lanes == 64           # default policy there: 1 x 16
+    assert wa.DeviceEngine(wa.MODEL_RW1, 1500, 8, cfg).lanes == 512          # 8 wavefronts x 4 elements per lane
+    assert wa.DeviceEngine(wa.MODEL_RW1, 3000, 8, cfg).lanes == 512          # 8 x 8
+    assert wa.DeviceEngine(wa.MODEL_FUNNEL, 3000, 8, cfg).lanes == 512       # the funnel's hint: 8 x 8 there
+    assert wa.DeviceEngine(wa.MODEL_FUNNEL, 2000, 8, cfg).lanes == 128       # ... and the default 2 x 16 below
     assert wa.DeviceEngine(wa.MODEL_STD_NORMAL, 1024, 8, cfg).lanes == 64    # default policy: 1 x 16
-    cfg = wa.default_config(waves_per_chain=1, elems_per_lane=16)
-    assert wa.DeviceEngine(wa.MODEL_RW1, 1024, 8, cfg).lanes == 64
+    cfg = wa.default_config(waves_per_chain=4, elems_per_lane=4)
+    assert wa.DeviceEngine(wa.MODEL_RW1, 1024, 8, cfg).lanes == 256
 
 
 def test_randomised_parity_campaign():

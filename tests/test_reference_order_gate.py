@@ -69,7 +69,9 @@ GPU_CASES = [
     ("four wavefronts per chain", "funnel", 1000, (4, 4), 64, 4, 30, "sampling"),
     ("eight wavefronts per chain", "std_normal", 4096, (8, 8), 32, 4, 30, "sampling"),
     ("two wavefronts, 16 per lane (default at 2 048)", "diag_normal", 2048, None, 48, 4, 30, "sampling"),
-    ("four wavefronts, 16 per lane (default at 4 096)", "funnel", 4096, None, 24, 3, 20, "sampling"),
+    ("four wavefronts, 16 per lane (default at 4 096)", "diag_normal", 4096, None, 24, 3, 20, "sampling"),
+    ("funnel at 4 096: eight wavefronts by its own hint", "funnel", 4096, None, 24, 3, 20, "sampling"),
+    ("rw1 at 3 000: eight wavefronts, eight per lane by its own hint", "rw1", 3000, None, 16, 3, 20, "sampling"),
     ("four wavefronts, 16 per lane, adaptive transitions", "std_normal", 3000, None, 24, 3, 20, "warmup"),
     ("rw1 at 1 024", "rw1", 1024, None, 64, 4, 30, "sampling"),
     ("headline kernel, adaptive transitions", "std_normal", 1024, None, 64, 4, 30, "warmup"),

@@ -16,10 +16,15 @@ struct Rw1Model {
   static constexpr bool kElementwise = false;
   static constexpr bool kGradIsNegTheta = false;
   static constexpr bool kCheapGrad = false;
-  // geometry hint (optional): every evaluation exchanges neighbours across lanes and keeps four vectors per set, so
-  // more, narrower wavefronts win -- measured at 1 024 dimensions: 2.70 ms with (4 waves, 4 elements per lane) against
-  // 2.89 ms with the default (1, 16)
-  static constexpr int kPreferredElemsPerLane = 4;
+  // geometry hint (optional): every evaluation exchanges neighbours across lanes and keeps four vectors per set.
+  // Measured in round 6 (16 384 / 8 192 chains, ms per step; after the DPP neighbour shifts of round 5): one wavefront
+  // per chain -- the default policy -- wins up to 1 024 dimensions (512: 0.75 against 0.87 at four per lane, 768: 1.69
+  // against 1.95, 1 024: 1.80 against 2.01); four elements per lane on eight wavefronts up to 2 048 (1 500: 2.66
+  // against 2.79 for (2,16), 2 048: 2.86 against 3.01); eight per lane on eight wavefronts up to 4 096 (3 000: 5.64
+  // against 7.29 for (16,4), 4 096: 5.86 against 7.60 and 7.93 for (4,16)).  Beyond: the held streaming kernels.
+  static constexpr int preferred_elems_per_lane(int num_params) {
+    return num_params <= 1024 ? 0 : num_params <= 2048 ? 4 : num_params <= 4096 ? 8 : 0;
+  }
   __device__ __forceinline__ static double grad_elem(double, double) { return 0.0; }
   struct Aux {};
 

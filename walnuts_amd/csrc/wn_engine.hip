@@ -431,7 +431,7 @@ void build_engine(wn_engine& e, int model, int num_params, const double* model_p
   e.C = num_chains;
   e.cfg = cfg;
   e.device = cfg.device;
-  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params, ops.preferred_epl,
+  e.geo = wn::choose_geometry(num_params, cfg.waves_per_chain, cfg.elems_per_lane, ops.uses_params, ops.preferred_epl(num_params),
                               ops.hold_tiles(wn::kHeldWaves), ops.register_dim_limit);
   e.Dp = wn::padded_dim(e.geo, num_params);
   e.use_device();
@@ -676,7 +676,7 @@ int wn_geometry_for_model(int model, int num_params, int waves_per_chain, int el
   return guarded(err, [&] {
     if (num_params < 1) throw std::invalid_argument("num_params must be positive");
     const wn::ModelOps& ops = wn::model_ops(model);
-    const wn::Geometry g = wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, ops.uses_params, ops.preferred_epl,
+    const wn::Geometry g = wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, ops.uses_params, ops.preferred_epl(num_params),
                                                ops.hold_tiles(wn::kHeldWaves), ops.register_dim_limit);
     if (nw != nullptr) *nw = g.nw;
     if (epl != nullptr) *epl = g.epl;
@@ -1241,7 +1241,7 @@ int wn_engine_release_stream(wn_engine* e, void* stream, WalnutpyError** err) {
 int wn_lanes_for_model_dim(int model, int num_params, int waves_per_chain, int elems_per_lane) {
   try {
     return 64 * wn::choose_geometry(num_params, waves_per_chain, elems_per_lane, wn::model_ops(model).uses_params,
-                                    wn::model_ops(model).preferred_epl, wn::model_ops(model).hold_tiles(wn::kHeldWaves),
+                                    wn::model_ops(model).preferred_epl(num_params), wn::model_ops(model).hold_tiles(wn::kHeldWaves),
                                     wn::model_ops(model).register_dim_limit).nw;
   } catch (...) {
     return -1;

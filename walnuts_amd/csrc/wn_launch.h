@@ -172,7 +172,7 @@ struct ModelOps {
   const char* name;
   bool uses_params;   // needs a parameter vector of num_params doubles
   bool elementwise;   // has streaming (num_params > 8192) kernels: an element-wise gradient, or a stated streaming form
-  int preferred_epl;  // the model's geometry hint: elements per lane (0 = the default policy)
+  int (*preferred_epl)(int num_params);  // the model's geometry hint: elements per lane (0 = the default policy)
   void (*launch_transition)(const Geometry&, int grid, size_t smem, hipStream_t, const Params&);
   void (*launch_init)(const Geometry&, int grid, size_t smem, hipStream_t, const InitParams&);
   void (*prepare)(const Geometry&, size_t smem);
@@ -196,7 +196,7 @@ inline std::string& registry_error() {
   return msg;
 }
 // Everything a separately compiled model and the library must agree on: the layout of what crosses the boundary.
-constexpr int kModelAbiVersion = 7;
+constexpr int kModelAbiVersion = 8;
 struct ModelAbi {
   int version;
   unsigned sizeof_ops, sizeof_params, sizeof_geometry;

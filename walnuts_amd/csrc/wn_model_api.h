@@ -51,6 +51,8 @@
 //     // dimensions).  A model whose evaluation exchanges data across lanes or keeps many live vectors may prefer
 //     // more, narrower wavefronts (models/rw1.h); an explicit waves_per_chain / elems_per_lane request still wins.
 //     static constexpr int kPreferredElemsPerLane;
+//     // ... or, where the best width depends on the dimension, the same hint as a function (0 = the default policy there):
+//     static constexpr int preferred_elems_per_lane(int num_params);
 //   };
 //
 // What `cx` offers (all of it collective: every lane of the chain's workgroup must make the same calls):

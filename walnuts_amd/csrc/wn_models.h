@@ -96,6 +96,10 @@ struct FunnelModel {  // Neal's funnel, SURVEY.md §8d cfg3 (not in the referenc
   static constexpr bool kElementwise = false;  // the gradient needs sum(x^2): register backend only
   static constexpr bool kGradIsNegTheta = false;
   static constexpr bool kCheapGrad = false;
+  // geometry hint: with the gradient carried (three vectors per set) four wavefronts at sixteen elements per lane lose
+  // 4 % to eight at eight between 2 049 and 4 096 dimensions (profiles/r06/mid_dimensions.txt); up to 2 048 the default
+  // policy's (2,16) wins by 37 %
+  static constexpr int preferred_elems_per_lane(int num_params) { return (num_params > 2048 && num_params <= 4096) ? 8 : 0; }
   __device__ __forceinline__ static double grad_elem(double, double) { return 0.0; }
   struct Aux {
     double v, S, hev, ev;

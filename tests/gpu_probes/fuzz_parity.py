@@ -17,8 +17,8 @@ import numpy as np
 
 import parity
 
-GEOMETRIES = [(1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (8, 8),
-              (16, 4), (16, 8)]
+GEOMETRIES = [(1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8), (2, 16), (4, 2), (4, 4), (4, 8), (4, 16), (8, 2),
+              (8, 4), (8, 8), (16, 4), (16, 8)]
 
 
 def random_case(rng, geometries=GEOMETRIES, mem_waves=(2, 4, 8, 16), chain_counts=(1, 2, 3, 7, 16, 33, 64),
